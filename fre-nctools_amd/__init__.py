@@ -1,0 +1,106 @@
+"""fre-nctools_amd -- MI355X-native conservative regridding behind the FRE-NCtools ABI.
+
+Host-side Python mirror of the reference interface for the conservative-regrid hot path.
+All arithmetic runs in ``libfregrid_hip.so`` (hand-written HIP for gfx950, built from
+``csrc/``); this module only binds its C ABI (``include/fregrid_hip.h``) with ctypes and
+mirrors the reference's call signatures:
+
+* ``create_xgrid_2dx2d_order1/2``, ``get_grid_area``, ``get_maxxgrid``, ``conserve_interp``
+  -- tools/libfrencutils/create_xgrid.c:45,66,621,893 and interp.c:262
+* ``setup_conserve_interp`` / ``do_scalar_conserve_interp``
+  -- tools/fregrid/conserve_interp.c:42,507 (compute branch, plain scalar branch)
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is visible
+when a compute entry point is called, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import FregridHipError, lib, lib_path  # noqa: F401
+from .grids import gnomonic_ed_corners, latlon_corners  # noqa: F401
+from .conserve_interp import (  # noqa: F401
+    CONSERVE_ORDER1, CONSERVE_ORDER2, CHECK_CONSERVE,
+    GridConfig, InterpConfig, FieldConfig, VarConfig, XgridPlan,
+    setup_conserve_interp, do_scalar_conserve_interp,
+)
+
+__all__ = [
+    "create_xgrid_2dx2d_order1", "create_xgrid_2dx2d_order2", "get_grid_area", "get_maxxgrid",
+    "conserve_interp", "setup_conserve_interp", "do_scalar_conserve_interp",
+    "GridConfig", "InterpConfig", "FieldConfig", "VarConfig", "XgridPlan",
+    "gnomonic_ed_corners", "latlon_corners", "lib", "lib_path", "FregridHipError",
+]
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def get_maxxgrid():
+    """create_xgrid.c:45"""
+    return int(lib().get_maxxgrid())
+
+
+def get_grid_area(nlon, nlat, lon, lat):
+    """create_xgrid.c:66 -- returns area[nlat*nlon] (m^2).  Fatal errors exit like the reference."""
+    _lib.require_gpu()
+    lon, lat = _f64(lon), _f64(lat)
+    assert lon.size == (nlon + 1) * (nlat + 1) and lat.size == lon.size
+    area = np.empty(nlon * nlat, dtype=np.float64)
+    lib().get_grid_area(C.byref(C.c_int(nlon)), C.byref(C.c_int(nlat)), _dp(lon), _dp(lat), _dp(area))
+    return area
+
+
+def _create_xgrid(order, nlon_in, nlat_in, nlon_out, nlat_out, lon_in, lat_in, lon_out, lat_out, mask_in):
+    _lib.require_gpu()
+    lon_in, lat_in, lon_out, lat_out = _f64(lon_in), _f64(lat_in), _f64(lon_out), _f64(lat_out)
+    assert lon_in.size == (nlon_in + 1) * (nlat_in + 1) == lat_in.size
+    assert lon_out.size == (nlon_out + 1) * (nlat_out + 1) == lat_out.size
+    mask = _f64(np.ones(nlon_in * nlat_in) if mask_in is None else mask_in)
+    assert mask.size == nlon_in * nlat_in
+    cap = get_maxxgrid()                       # caller-allocated MAXXGRID arrays, as in the reference
+    i_in, j_in, i_out, j_out = (np.empty(cap, dtype=np.int32) for _ in range(4))
+    area = np.empty(cap, dtype=np.float64)
+    args = [C.byref(C.c_int(nlon_in)), C.byref(C.c_int(nlat_in)), C.byref(C.c_int(nlon_out)),
+            C.byref(C.c_int(nlat_out)), _dp(lon_in), _dp(lat_in), _dp(lon_out), _dp(lat_out), _dp(mask),
+            _ip(i_in), _ip(j_in), _ip(i_out), _ip(j_out), _dp(area)]
+    if order == 1:
+        n = lib().create_xgrid_2dx2d_order1(*args)
+        return n, i_in[:n].copy(), j_in[:n].copy(), i_out[:n].copy(), j_out[:n].copy(), area[:n].copy()
+    clon, clat = np.empty(cap, dtype=np.float64), np.empty(cap, dtype=np.float64)
+    n = lib().create_xgrid_2dx2d_order2(*args, _dp(clon), _dp(clat))
+    return (n, i_in[:n].copy(), j_in[:n].copy(), i_out[:n].copy(), j_out[:n].copy(), area[:n].copy(),
+            clon[:n].copy(), clat[:n].copy())
+
+
+def create_xgrid_2dx2d_order1(nlon_in, nlat_in, nlon_out, nlat_out, lon_in, lat_in, lon_out, lat_out, mask_in=None):
+    """create_xgrid.c:621 -- returns (nxgrid, i_in, j_in, i_out, j_out, xgrid_area)."""
+    return _create_xgrid(1, nlon_in, nlat_in, nlon_out, nlat_out, lon_in, lat_in, lon_out, lat_out, mask_in)
+
+
+def create_xgrid_2dx2d_order2(nlon_in, nlat_in, nlon_out, nlat_out, lon_in, lat_in, lon_out, lat_out, mask_in=None):
+    """create_xgrid.c:893 -- returns (nxgrid, i_in, j_in, i_out, j_out, xgrid_area, xgrid_clon, xgrid_clat)."""
+    return _create_xgrid(2, nlon_in, nlat_in, nlon_out, nlat_out, lon_in, lat_in, lon_out, lat_out, mask_in)
+
+
+def conserve_interp(nx_src, ny_src, nx_dst, ny_dst, x_src, y_src, x_dst, y_dst, mask_src, data_src):
+    """interp.c:262 -- first-order remap; returns data_dst[ny_dst*nx_dst]."""
+    _lib.require_gpu()
+    x_src, y_src, x_dst, y_dst = _f64(x_src), _f64(y_src), _f64(x_dst), _f64(y_dst)
+    mask = _f64(np.ones(nx_src * ny_src) if mask_src is None else mask_src)
+    data_src = _f64(data_src)
+    out = np.empty(nx_dst * ny_dst, dtype=np.float64)
+    lib().conserve_interp(nx_src, ny_src, nx_dst, ny_dst, _dp(x_src), _dp(y_src), _dp(x_dst), _dp(y_dst),
+                          _dp(mask), _dp(data_src), _dp(out))
+    return out

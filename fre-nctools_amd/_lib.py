@@ -1,0 +1,124 @@
+"""ctypes binding of libfregrid_hip.so (C ABI: include/fregrid_hip.h).
+
+The library is built in-tree by ``make -C fre-nctools_amd/csrc`` (or ``__graft_entry__.build()``).
+Loading fails loudly when it is missing -- there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class FregridHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfregrid_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfregrid_hip.so")
+
+
+# every symbol include/fregrid_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = [
+    "get_maxxgrid", "get_grid_area", "create_xgrid_2dx2d_order1", "create_xgrid_2dx2d_order2", "conserve_interp",
+    "get_maxxgrid_", "get_grid_area_", "create_xgrid_2dx2d_order1_", "create_xgrid_2dx2d_order2_",
+    "fg_last_error", "fg_device_count", "fg_plan_create", "fg_plan_create_dev", "fg_plan_create_empty",
+    "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
+    "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
+    "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_stream", "fg_plan_sync",
+    "fg_plan_stats", "fg_gnomonic_ed_corners", "fg_latlon_corners",
+]
+
+
+def lib():
+    """Load (once) and return the ctypes handle with argument types declared."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build the HIP extension first (make -C fre-nctools_amd/csrc, or "
+            "python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    L = C.CDLL(path)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    dpp = C.POINTER(dp)
+    cip = C.POINTER(C.c_int)
+
+    L.get_maxxgrid.restype = C.c_int
+    L.get_grid_area.argtypes = [cip, cip, dp, dp, dp]
+    L.get_grid_area.restype = None
+    L.create_xgrid_2dx2d_order1.argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp]
+    L.create_xgrid_2dx2d_order1.restype = C.c_int
+    L.create_xgrid_2dx2d_order2.argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp] * 3
+    L.create_xgrid_2dx2d_order2.restype = C.c_int
+    L.conserve_interp.argtypes = [C.c_int] * 4 + [dp] * 7
+    L.conserve_interp.restype = None
+
+    L.fg_last_error.restype = C.c_char_p
+    L.fg_device_count.restype = C.c_int
+    L.fg_plan_create.argtypes = [C.c_int, C.c_int, ip, ip, dpp, dpp, dpp, C.c_int, C.c_int, dp, dp, C.c_int, C.POINTER(vp)]
+    L.fg_plan_create.restype = C.c_long
+    L.fg_plan_create_dev.argtypes = [C.c_int, C.c_int, ip, ip, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                     C.c_int, C.c_int, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.c_int,
+                                     C.POINTER(vp)]
+    L.fg_plan_create_dev.restype = C.c_long
+    L.fg_plan_create_empty.argtypes = [C.c_int, C.c_int, ip, ip, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.fg_plan_create_empty.restype = C.c_int
+    L.fg_plan_destroy.argtypes = [vp]
+    L.fg_plan_destroy.restype = None
+    L.fg_plan_set_stream.argtypes = [vp, vp]
+    L.fg_plan_set_stream.restype = C.c_int
+    L.fg_pool_release.restype = None
+    L.fg_plan_nxgrid.argtypes = [vp]
+    L.fg_plan_nxgrid.restype = C.c_long
+    L.fg_plan_ncells_in.argtypes = [vp]
+    L.fg_plan_ncells_in.restype = C.c_long
+    L.fg_plan_cell_sums_dev.argtypes = [vp]
+    L.fg_plan_cell_sums_dev.restype = vp
+    L.fg_plan_copy_cell_sums.argtypes = [vp, vp]
+    L.fg_plan_copy_cell_sums.restype = C.c_int
+    L.fg_plan_finalize.argtypes = [vp, vp]
+    L.fg_plan_finalize.restype = C.c_int
+    L.fg_plan_get_xgrid.argtypes = [vp] + [ip] * 5 + [dp] * 3
+    L.fg_plan_get_xgrid.restype = C.c_int
+    L.fg_plan_get_cell_struct.argtypes = [vp, C.c_int] + [dp] * 5 + [ip] + [dp] * 2
+    L.fg_plan_get_cell_struct.restype = C.c_int
+    L.fg_plan_get_cell_area.argtypes = [vp, dp, dp]
+    L.fg_plan_get_cell_area.restype = C.c_int
+    L.fg_plan_set_xgrid.argtypes = [vp, C.c_long] + [ip] * 5 + [dp] * 3
+    L.fg_plan_set_xgrid.restype = C.c_int
+    L.fg_plan_apply.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, dp]
+    L.fg_plan_apply.restype = C.c_int
+    L.fg_plan_stream.argtypes = [vp]
+    L.fg_plan_stream.restype = vp
+    L.fg_plan_sync.argtypes = [vp]
+    L.fg_plan_sync.restype = C.c_int
+    L.fg_plan_stats.argtypes = [vp, C.POINTER(C.c_long), C.c_int]
+    L.fg_plan_stats.restype = C.c_int
+    L.fg_gnomonic_ed_corners.argtypes = [C.c_int, C.c_double, C.c_int, dp, dp]
+    L.fg_gnomonic_ed_corners.restype = C.c_int
+    L.fg_latlon_corners.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp]
+    L.fg_latlon_corners.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def last_error():
+    return lib().fg_last_error().decode("utf-8", "replace")
+
+
+def check(code):
+    if code < 0:
+        raise FregridHipError(code, last_error())
+    return code
+
+
+def require_gpu():
+    n = lib().fg_device_count()
+    if n < 1:
+        raise FregridHipError(-2, "no HIP device visible (" + last_error() + "): the regrid hot path runs on an "
+                              "MI355X-class GPU only; there is no CPU fallback")
+    return n

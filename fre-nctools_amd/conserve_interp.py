@@ -1,0 +1,378 @@
+"""Host mirror of tools/fregrid/conserve_interp.c over the device-resident plan API.
+
+``setup_conserve_interp`` / ``do_scalar_conserve_interp`` keep the reference's names, argument
+order and meaning (conserve_interp.c:42, :507); the config structs are small Python stand-ins
+for ``Grid_config`` / ``Interp_config`` / ``Field_config`` / ``Var_config``
+(tools/libfrencutils/globals.h:67-216) holding only the members this path reads.
+
+PyTorch is used for device buffers and (when a process group is initialised) for the one
+collective of the path: the sum of the per-source-cell (area, clon, clat) partial sums over
+ranks -- conserve_interp.c:203-221 does the same with mpp_gather + a serial sum.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+# option bits, tools/libfrencutils/globals.h:46-61
+CONSERVE_ORDER1 = 1
+CONSERVE_ORDER2 = 2
+READ = 256
+WRITE = 512
+CHECK_CONSERVE = 1024
+MAXVAL = 1.0e20            # conserve_interp.c:36
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
+
+
+@dataclass
+class GridConfig:
+    """Grid_config (globals.h:170-216): nx, ny and corner arrays lonc/latc [(ny+1),(nx+1)] radians.
+    For an output grid split over ranks pass the rank's band (nxc, nyc and its corners), as
+    get_output_grid_by_size does (fregrid_util.c:645-654)."""
+    nx: int
+    ny: int
+    lonc: np.ndarray
+    latc: np.ndarray
+    cell_area: Optional[np.ndarray] = None     # filled by setup_conserve_interp (get_grid_area semantics)
+
+    @property
+    def nxc(self):
+        return self.nx
+
+    @property
+    def nyc(self):
+        return self.ny
+
+
+@dataclass
+class VarConfig:
+    """Var_config (globals.h:67-100), members read by do_scalar_conserve_interp."""
+    name: str = "var"
+    interp_method: int = CONSERVE_ORDER1
+    has_missing: int = 0
+    missing: float = -MAXVAL
+
+
+@dataclass
+class FieldConfig:
+    """Field_config (globals.h:102-112) for ONE tile.  data is [nz, ny, nx] (order 1) or
+    [nz, ny+2, nx+2] (order 2, halo 1); grad_x/grad_y [nz, ny, nx]; grad_mask [ny, nx] int."""
+    data: Optional[np.ndarray] = None
+    grad_x: Optional[np.ndarray] = None
+    grad_y: Optional[np.ndarray] = None
+    grad_mask: Optional[np.ndarray] = None
+    var: List[VarConfig] = field(default_factory=lambda: [VarConfig()])
+
+
+class XgridPlan:
+    """RAII wrapper of an ``fg_plan`` (include/fregrid_hip.h)."""
+
+    def __init__(self, handle, order, device):
+        self._h = C.c_void_p(handle)
+        self.order = order
+        self.device = device
+
+    # -- construction -------------------------------------------------------------------
+    @classmethod
+    def create(cls, order, grids_in, grid_out, masks=None, device=0):
+        """Search with host corner arrays (copied to the device)."""
+        _lib.require_gpu()
+        L = lib()
+        nt = len(grids_in)
+        nx = (C.c_int * nt)(*[g.nx for g in grids_in])
+        ny = (C.c_int * nt)(*[g.ny for g in grids_in])
+        keep = []
+        dpt = C.POINTER(C.c_double)
+
+        def arr(a, n):
+            a = _f64(a).reshape(-1)
+            assert a.size == n, (a.size, n)
+            keep.append(a)
+            return _dp(a)
+
+        lon = (dpt * nt)(*[arr(g.lonc, (g.nx + 1) * (g.ny + 1)) for g in grids_in])
+        lat = (dpt * nt)(*[arr(g.latc, (g.nx + 1) * (g.ny + 1)) for g in grids_in])
+        if masks is None:
+            msk = None
+        else:
+            msk = (dpt * nt)(*[arr(m, g.nx * g.ny) if m is not None else dpt() for m, g in zip(masks, grids_in)])
+        lo = arr(grid_out.lonc, (grid_out.nx + 1) * (grid_out.ny + 1))
+        la = arr(grid_out.latc, (grid_out.nx + 1) * (grid_out.ny + 1))
+        h = C.c_void_p()
+        check(L.fg_plan_create(order, nt, nx, ny, lon, lat, msk, grid_out.nx, grid_out.ny, lo, la, device, C.byref(h)))
+        return cls(h.value, order, device)
+
+    @classmethod
+    def create_dev(cls, order, nx_in, ny_in, lon_in_t, lat_in_t, nx_out, ny_out, lon_out_t, lat_out_t,
+                   mean_dlat=0.0, mean_dlon=0.0, device=0, stream=None, masks_t=None):
+        """Search with corner arrays already on the device (torch float64 CUDA tensors)."""
+        L = lib()
+        nt = len(nx_in)
+        nx = (C.c_int * nt)(*nx_in)
+        ny = (C.c_int * nt)(*ny_in)
+        lon = (C.c_void_p * nt)(*[t.data_ptr() for t in lon_in_t])
+        lat = (C.c_void_p * nt)(*[t.data_ptr() for t in lat_in_t])
+        msk = None
+        if masks_t is not None:
+            msk = (C.c_void_p * nt)(*[(t.data_ptr() if t is not None else None) for t in masks_t])
+        h = C.c_void_p()
+        use = 0 if stream is None else 1
+        sptr = C.c_void_p(0 if stream is None else int(stream))
+        check(L.fg_plan_create_dev(order, nt, nx, ny, lon, lat, msk, nx_out, ny_out,
+                                   C.c_void_p(lon_out_t.data_ptr()), C.c_void_p(lat_out_t.data_ptr()),
+                                   float(mean_dlat), float(mean_dlon), device, sptr, use, C.byref(h)))
+        return cls(h.value, order, device)
+
+    @classmethod
+    def create_empty(cls, order, nx_in, ny_in, nx_out, ny_out, device=0):
+        _lib.require_gpu()
+        nt = len(nx_in)
+        h = C.c_void_p()
+        check(lib().fg_plan_create_empty(order, nt, (C.c_int * nt)(*nx_in), (C.c_int * nt)(*ny_in),
+                                         nx_out, ny_out, device, C.byref(h)))
+        return cls(h.value, order, device)
+
+    def destroy(self):
+        if self._h is not None and self._h.value:
+            lib().fg_plan_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # -- accessors ----------------------------------------------------------------------
+    @property
+    def nxgrid(self):
+        return int(lib().fg_plan_nxgrid(self._h))
+
+    @property
+    def ncells_in(self):
+        return int(lib().fg_plan_ncells_in(self._h))
+
+    def cell_sums_ptr(self):
+        return lib().fg_plan_cell_sums_dev(self._h)
+
+    def copy_cell_sums(self, dst_t):
+        check(lib().fg_plan_copy_cell_sums(self._h, C.c_void_p(dst_t.data_ptr())))
+
+    def stats(self):
+        s = (C.c_long * 8)()
+        check(lib().fg_plan_stats(self._h, s, 8))
+        names = ["pairs", "nonempty", "nxgrid", "borderline", "bins", "bin_entries", "deferred", "_"]
+        return dict(zip(names, [int(v) for v in s]))
+
+    def finalize(self, total_sums_ptr=None):
+        check(lib().fg_plan_finalize(self._h, C.c_void_p(total_sums_ptr or 0)))
+
+    def sync(self):
+        check(lib().fg_plan_sync(self._h))
+
+    def stream(self):
+        return lib().fg_plan_stream(self._h)
+
+    def set_stream(self, stream):
+        check(lib().fg_plan_set_stream(self._h, C.c_void_p(int(stream))))
+
+    def get_xgrid(self):
+        """dict with t_in,i_in,j_in,i_out,j_out (int32), area and c1/c2 (order 2)."""
+        n = self.nxgrid
+        ints = {k: np.empty(n, dtype=np.int32) for k in ("t_in", "i_in", "j_in", "i_out", "j_out")}
+        area = np.empty(n, dtype=np.float64)
+        c1 = np.empty(n, dtype=np.float64) if self.order == 2 else None
+        c2 = np.empty(n, dtype=np.float64) if self.order == 2 else None
+        check(lib().fg_plan_get_xgrid(self._h, _ip(ints["t_in"]), _ip(ints["i_in"]), _ip(ints["j_in"]),
+                                      _ip(ints["i_out"]), _ip(ints["j_out"]), _dp(area), _dp(c1), _dp(c2)))
+        out = dict(ints)
+        out["area"] = area
+        if self.order == 2:
+            out["c1"], out["c2"] = c1, c2
+        return out
+
+    def get_cell_area(self, ncells_out):
+        a_in = np.empty(self.ncells_in, dtype=np.float64)
+        a_out = np.empty(ncells_out, dtype=np.float64)
+        check(lib().fg_plan_get_cell_area(self._h, _dp(a_in), _dp(a_out)))
+        return a_in, a_out
+
+    def get_cell_struct(self, which, ncells):
+        d = {k: np.empty(ncells, dtype=np.float64) for k in ("lat_min", "lat_max", "lon_min", "lon_max", "lon_avg")}
+        nv = np.empty(ncells, dtype=np.int32)
+        vlon = np.empty((ncells, 8), dtype=np.float64)
+        vlat = np.empty((ncells, 8), dtype=np.float64)
+        check(lib().fg_plan_get_cell_struct(self._h, which, _dp(d["lat_min"]), _dp(d["lat_max"]), _dp(d["lon_min"]),
+                                            _dp(d["lon_max"]), _dp(d["lon_avg"]), _ip(nv), _dp(vlon), _dp(vlat)))
+        d.update(nvert=nv, vlon=vlon, vlat=vlat)
+        return d
+
+    def set_xgrid(self, t_in, i_in, j_in, i_out, j_out, area, di_in=None, dj_in=None):
+        a = [np.ascontiguousarray(v, dtype=np.int32) for v in (t_in, i_in, j_in, i_out, j_out)]
+        area = _f64(area)
+        di = _f64(di_in) if di_in is not None else None
+        dj = _f64(dj_in) if dj_in is not None else None
+        check(lib().fg_plan_set_xgrid(self._h, area.size, *[_ip(v) for v in a], _dp(area), _dp(di), _dp(dj)))
+
+    def apply(self, data_t, out_t, nz=1, grad_x_t=None, grad_y_t=None, grad_mask_t=None,
+              has_missing=False, missing=-MAXVAL, want_gsum=False):
+        """Sweep on device tensors (torch float64 / int32 CUDA tensors)."""
+        g = C.c_double(0.0)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        check(lib().fg_plan_apply(self._h, ptr(data_t), ptr(grad_x_t), ptr(grad_y_t), ptr(grad_mask_t),
+                                  1 if has_missing else 0, float(missing), nz, ptr(out_t),
+                                  C.byref(g) if want_gsum else None))
+        return g.value if want_gsum else None
+
+
+@dataclass
+class InterpConfig:
+    """Interp_config (globals.h:144-158).  The arrays are host copies of the plan's exchange
+    cells; ``plan`` keeps them resident in HBM for do_scalar_conserve_interp."""
+    nxgrid: int = 0
+    i_in: Optional[np.ndarray] = None
+    j_in: Optional[np.ndarray] = None
+    i_out: Optional[np.ndarray] = None
+    j_out: Optional[np.ndarray] = None
+    t_in: Optional[np.ndarray] = None
+    di_in: Optional[np.ndarray] = None
+    dj_in: Optional[np.ndarray] = None
+    area: Optional[np.ndarray] = None
+    plan: Optional[XgridPlan] = None
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opcode, device=0, fetch=True):
+    """conserve_interp.c:42, compute branch (:127-358).  Fills interp[n] for each output tile.
+
+    With torch.distributed initialised (world_size > 1) each rank passes its own band of the
+    output grid and the per-source-cell sums are all-reduced (RCCL) before the centroid pass.
+    """
+    order = 2 if (opcode & CONSERVE_ORDER2) else 1
+    if not (opcode & (CONSERVE_ORDER1 | CONSERVE_ORDER2)):
+        raise ValueError("conserve_interp: interp_method should be CONSERVE_ORDER1 or CONSERVE_ORDER2")
+    torch = _torch()
+    plans = []
+    for n in range(ntiles_out):
+        plans.append(XgridPlan.create(order, grid_in[:ntiles_in], grid_out[n], device=device))
+    # cell areas (fregrid_util.c:363-408) come for free from the search
+    for n in range(ntiles_out):
+        a_in, a_out = plans[n].get_cell_area(grid_out[n].nx * grid_out[n].ny)
+        grid_out[n].cell_area = a_out
+        if n == 0:
+            off = 0
+            for g in grid_in[:ntiles_in]:
+                g.cell_area = a_in[off:off + g.nx * g.ny].copy()
+                off += g.nx * g.ny
+    if order == 2:
+        ncell = plans[0].ncells_in
+        total = torch.zeros(3 * ncell, dtype=torch.float64, device=f"cuda:{device}")
+        for p in plans:
+            part = torch.empty_like(total)
+            p.copy_cell_sums(part)
+            total += part
+        dist = torch.distributed
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(total)              # the one exchange step of the path
+        torch.cuda.synchronize(device)
+        for p in plans:
+            p.finalize(total.data_ptr())
+    else:
+        for p in plans:
+            p.finalize(None)
+    for n in range(ntiles_out):
+        ic = interp[n]
+        ic.plan = plans[n]
+        ic.nxgrid = plans[n].nxgrid
+        if fetch:
+            x = plans[n].get_xgrid()
+            ic.t_in, ic.i_in, ic.j_in, ic.i_out, ic.j_out, ic.area = (x["t_in"], x["i_in"], x["j_in"], x["i_out"],
+                                                                       x["j_out"], x["area"])
+            if order == 2:
+                ic.di_in, ic.dj_in = x["c1"], x["c2"]
+    print("NOTE: done calculating index and weight for conservative interpolation")   # :446
+    return interp
+
+
+def pack_field(order, field_in, ntiles_in, nz, key="data"):
+    """Concatenate per-tile arrays into the device layout [nz][tiles back to back]."""
+    lv = []
+    for k in range(nz):
+        parts = []
+        for t in range(ntiles_in):
+            a = getattr(field_in[t], key)
+            a = np.asarray(a)
+            a = a.reshape(nz, -1) if a.ndim != 2 or a.shape[0] != nz else a
+            parts.append(a[k].reshape(-1))
+        lv.append(np.concatenate(parts))
+    return np.ascontiguousarray(np.stack(lv))
+
+
+def do_scalar_conserve_interp(interp, varid, ntiles_in, grid_in, ntiles_out, grid_out, field_in, field_out,
+                              opcode, nz, device=0):
+    """conserve_interp.c:507 -- plain scalar branch (order 1 :561-616, order 2 :743-813, :815-907)."""
+    torch = _torch()
+    var = field_in[0].var[varid]
+    order = 2 if var.interp_method == CONSERVE_ORDER2 else 1
+    has_missing = int(var.has_missing)
+    missing = var.missing if has_missing else -MAXVAL
+    if nz > 1 and has_missing:
+        raise ValueError("conserve_interp: has_missing should be false when nz > 1")
+    dev = f"cuda:{device}"
+    data = torch.from_numpy(pack_field(order, field_in, ntiles_in, nz, "data").astype(np.float64)).to(dev)
+    gx = gy = gm = None
+    if order == 2:
+        gx = torch.from_numpy(pack_field(order, field_in, ntiles_in, nz, "grad_x").astype(np.float64)).to(dev)
+        gy = torch.from_numpy(pack_field(order, field_in, ntiles_in, nz, "grad_y").astype(np.float64)).to(dev)
+        if has_missing:
+            gm = torch.from_numpy(np.concatenate([np.asarray(field_in[t].grad_mask, dtype=np.int32).reshape(-1)
+                                                  for t in range(ntiles_in)])).to(dev)
+    gsum_out = 0.0
+    for m in range(ntiles_out):
+        nx2, ny2 = grid_out[m].nxc, grid_out[m].nyc
+        out = torch.empty(nz * nx2 * ny2, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(device)
+        g = interp[m].plan.apply(data, out, nz=nz, grad_x_t=gx, grad_y_t=gy, grad_mask_t=gm,
+                                 has_missing=bool(has_missing), missing=missing,
+                                 want_gsum=bool(opcode & CHECK_CONSERVE))
+        interp[m].plan.sync()
+        field_out[m].data = out.cpu().numpy().reshape(nz, ny2, nx2)
+        if g is not None:
+            gsum_out += g
+    if opcode & CHECK_CONSERVE:                                       # :874-907
+        halo = 1 if order == 2 else 0
+        gsum_in = 0.0
+        for n in range(ntiles_in):
+            nx1, ny1 = grid_in[n].nx, grid_in[n].ny
+            d = np.asarray(field_in[n].data, dtype=np.float64).reshape(nz, ny1 + 2 * halo, nx1 + 2 * halo)
+            d = d[:, halo:halo + ny1, halo:halo + nx1]
+            ca = np.asarray(grid_in[n].cell_area).reshape(ny1, nx1)
+            gsum_in += float(np.sum(np.where(d != missing, d * ca[None], 0.0)))
+        dist = torch.distributed
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([gsum_out], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)                                         # mpp_sum_double, :902
+            gsum_out = float(t.item())
+        print("the flux(data*area) sum of %s: input = %g, output = %g, diff = %g. "
+              % (var.name, gsum_in, gsum_out, gsum_out - gsum_in))
+        return gsum_in, gsum_out
+    return None

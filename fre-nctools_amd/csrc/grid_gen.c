@@ -1,0 +1,311 @@
+/*
+ * grid_gen.c -- host-side synthetic grid generators (C, libm only).
+ *
+ * fregrid needs cell-corner longitudes/latitudes in radians.  The reference gets
+ * them from make_hgrid supergrid files; on a machine without those files (the
+ * benchmark box) we generate the same grids directly:
+ *
+ *   fg_gnomonic_ed_corners   equal-distance gnomonic cubed sphere, 6 tiles
+ *       follows tools/make_hgrid/create_gnomonic_cubic_grid.c:
+ *         gnomonic_ed :1465-1536, mirror_latlon :1569-1590, symm_ed :1596-1632,
+ *         mirror_grid :1637-1752, rot_3d :1759-1804, tile-edge consistency :345-385,
+ *         west shift by pi/18 and clean-up :336-343, radians->degrees :717-720,
+ *       and the degrees->radians read-back of tools/fregrid/fregrid_util.c:227-232.
+ *   fg_latlon_corners        regular lat-lon target grid
+ *       follows tools/fregrid/fregrid_util.c:564-603,645-654 (get_output_grid_by_size).
+ *
+ * Same operation order as the reference so the corners agree to the last bit
+ * with glibc libm (checked in tests/test_grid_gen.py against oracle/_ref).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fregrid_hip.h"
+
+#define FG_PI 3.14159265358979323846
+#define FG_R2D (180 / FG_PI)
+#define FG_D2R (FG_PI / 180)
+#define FG_RADIUS 6371000.0
+
+static void ll2xyz(double lon, double lat, double *p)
+{
+  p[0] = cos(lat) * cos(lon);
+  p[1] = cos(lat) * sin(lon);
+  p[2] = sin(lat);
+}
+
+/* mosaic_util.c:228-252 */
+static void xyz2ll(double xx, double yy, double zz, double *lon, double *lat)
+{
+  double dist = sqrt(xx * xx + yy * yy + zz * zz);
+  xx /= dist; yy /= dist; zz /= dist;
+  if (fabs(xx) + fabs(yy) < 1.e-10) *lon = 0;
+  else *lon = atan2(yy, xx);
+  *lat = asin(zz);
+  if (*lon < 0.) *lon = 2. * FG_PI + *lon;
+}
+
+/* reflect (lon0,lat0) through the plane spanned by the centre and the two mirror points */
+static void reflect_ll(double lon1, double lat1, double lon2, double lat2,
+                       double lon0, double lat0, double *lon, double *lat)
+{
+  double p0[3], p1[3], p2[3], pp[3], nb[3], pdot;
+  ll2xyz(lon0, lat0, p0);
+  ll2xyz(lon1, lat1, p1);
+  ll2xyz(lon2, lat2, p2);
+  nb[0] = p1[1] * p2[2] - p1[2] * p2[1];
+  nb[1] = p1[2] * p2[0] - p1[0] * p2[2];
+  nb[2] = p1[0] * p2[1] - p1[1] * p2[0];
+  pdot = sqrt(nb[0] * nb[0] + nb[1] * nb[1] + nb[2] * nb[2]);
+  for (int k = 0; k < 3; k++) nb[k] = nb[k] / pdot;
+  pdot = p0[0] * nb[0] + p0[1] * nb[1] + p0[2] * nb[2];
+  for (int k = 0; k < 3; k++) pp[k] = p0[k] - 2 * pdot * nb[k];
+  xyz2ll(pp[0], pp[1], pp[2], lon, lat);
+}
+
+/* first face, equal distance along the four edges */
+static void face_equal_dist(int ni, double *lam, double *the)
+{
+  int nip = ni + 1;
+  double rsq3 = 1. / sqrt(3.);
+  double alpha = asin(rsq3);
+  double dely = 2. * alpha / ni;
+
+  for (int j = 0; j < nip; j++) {
+    lam[j * nip] = 0.75 * FG_PI;
+    lam[j * nip + ni] = 1.25 * FG_PI;
+    the[j * nip] = -alpha + dely * j;
+    the[j * nip + ni] = the[j * nip];
+  }
+  for (int i = 1; i < ni; i++) {
+    reflect_ll(lam[0], the[0], lam[ni * nip + ni], the[ni * nip + ni],
+               lam[i * nip], the[i * nip], &lam[i], &the[i]);
+    lam[ni * nip + i] = lam[i];
+    the[ni * nip + i] = -the[i];
+  }
+  size_t np = (size_t)nip * nip;
+  double *x = (double *)malloc(np * sizeof(double));
+  double *y = (double *)malloc(np * sizeof(double));
+  double *z = (double *)malloc(np * sizeof(double));
+  double p[3];
+  int corner[4] = {0, ni, ni * nip, ni * nip + ni};
+  for (int c = 0; c < 4; c++) {
+    ll2xyz(lam[corner[c]], the[corner[c]], p);
+    x[corner[c]] = p[0]; y[corner[c]] = p[1]; z[corner[c]] = p[2];
+  }
+  /* project the west and south edges onto the cube face x = -1/sqrt(3) */
+  for (int j = 1; j < ni; j++) {
+    int n = j * nip;
+    ll2xyz(lam[n], the[n], p);
+    x[n] = p[0];
+    y[n] = -p[1] * rsq3 / x[n];
+    z[n] = -p[2] * rsq3 / x[n];
+  }
+  for (int i = 1; i < ni; i++) {
+    ll2xyz(lam[i], the[i], p);
+    x[i] = p[0];
+    y[i] = -p[1] * rsq3 / x[i];
+    z[i] = -p[2] * rsq3 / x[i];
+  }
+  for (size_t k = 0; k < np; k++) x[k] = -rsq3;
+  for (int j = 1; j < nip; j++)
+    for (int i = 1; i < nip; i++) {
+      y[j * nip + i] = y[i];
+      z[j * nip + i] = z[j * nip];
+    }
+  for (size_t k = 0; k < np; k++) xyz2ll(x[k], y[k], z[k], &lam[k], &the[k]);
+  free(x); free(y); free(z);
+}
+
+/* symmetrise about the face centre lines */
+static void face_symmetrise(int ni, double *lam, double *the)
+{
+  int nip = ni + 1;
+  for (int j = 1; j < nip; j++)
+    for (int i = 1; i < ni; i++) lam[j * nip + i] = lam[i];
+  for (int j = 0; j < nip; j++)
+    for (int i = 0; i < ni / 2; i++) {
+      int ip = ni - i;
+      double avg = 0.5 * (lam[j * nip + i] - lam[j * nip + ip]);
+      lam[j * nip + i] = avg + FG_PI;
+      lam[j * nip + ip] = FG_PI - avg;
+      avg = 0.5 * (the[j * nip + i] + the[j * nip + ip]);
+      the[j * nip + i] = avg;
+      the[j * nip + ip] = avg;
+    }
+  for (int j = 0; j < ni / 2; j++) {
+    int jp = ni - j;
+    for (int i = 1; i < ni; i++) {
+      double avg = 0.5 * (lam[j * nip + i] + lam[jp * nip + i]);
+      lam[j * nip + i] = avg;
+      lam[jp * nip + i] = avg;
+      avg = 0.5 * (the[j * nip + i] - the[jp * nip + i]);
+      the[j * nip + i] = avg;
+      the[jp * nip + i] = -avg;
+    }
+  }
+}
+
+/* rotate a (lon, lat, r) point about a Cartesian axis by `deg` degrees; the
+ * spherical<->Cartesian pair uses the generator's own convention (z = -r sin(lat),
+ * lat = acos(z/r) - pi/2), create_gnomonic_cubic_grid.c:1811-1835 */
+static void rotate_ll(int axis, double lon, double lat, double r, double deg,
+                      double *lon2, double *lat2, double *r2)
+{
+  double x1 = r * cos(lon) * cos(lat);
+  double y1 = r * sin(lon) * cos(lat);
+  double z1 = -r * sin(lat);
+  double angle = deg * FG_D2R;
+  double c = cos(angle), s = sin(angle);
+  double x2, y2, z2;
+  if (axis == 1)      { x2 = x1;               y2 = c * y1 + s * z1;  z2 = -s * y1 + c * z1; }
+  else if (axis == 2) { x2 = c * x1 - s * z1;  y2 = y1;               z2 = s * x1 + c * z1; }
+  else                { x2 = c * x1 + s * y1;  y2 = -s * x1 + c * y1; z2 = z1; }
+  *r2 = sqrt(x2 * x2 + y2 * y2 + z2 * z2);
+  if ((fabs(x2) + fabs(y2)) < 1.e-10) *lon2 = 0.;
+  else *lon2 = atan2(y2, x2);
+  *lat2 = acos(z2 / (*r2)) - FG_PI / 2.;
+}
+
+static double sgn1(double v) { return v >= 0 ? 1 : -1; }
+
+/* symmetrise tile 1 about greenwich/equator, then rotate it into the other five tiles */
+static void six_tiles(int ni, double *x, double *y)
+{
+  int nip = ni + 1;
+  int half = (int)ceil(nip / 2.);
+  for (int j = 0; j < half; j++) {
+    int jp = ni - j;
+    for (int i = 0; i < half; i++) {
+      int ip = ni - i;
+      int a = j * nip + i, b = j * nip + ip, c = jp * nip + i, d = jp * nip + ip;
+      double x1 = 0.25 * (fabs(x[a]) + fabs(x[b]) + fabs(x[c]) + fabs(x[d]));
+      x[a] = x1 * sgn1(x[a]); x[b] = x1 * sgn1(x[b]);
+      x[c] = x1 * sgn1(x[c]); x[d] = x1 * sgn1(x[d]);
+      double y1 = 0.25 * (fabs(y[a]) + fabs(y[b]) + fabs(y[c]) + fabs(y[d]));
+      y[a] = y1 * sgn1(y[a]); y[b] = y1 * sgn1(y[b]);
+      y[c] = y1 * sgn1(y[c]); y[d] = y1 * sgn1(y[d]);
+      if (nip % 2) {
+        if (i == (nip - 1) / 2) { x[a] = 0.0; x[c] = 0.0; }
+      }
+    }
+  }
+  int mid = (nip - 1) / 2;
+  for (int nt = 1; nt < 6; nt++)
+    for (int j = 0; j < nip; j++)
+      for (int i = 0; i < nip; i++) {
+        double x1 = x[j * nip + i], y1 = y[j * nip + i], z1 = FG_RADIUS;
+        double x2 = 0, y2 = 0, z2 = 0;
+        switch (nt) {
+        case 1:
+          rotate_ll(3, x1, y1, z1, -90., &x2, &y2, &z2);
+          break;
+        case 2:
+          rotate_ll(3, x1, y1, z1, -90., &x2, &y2, &z2);
+          rotate_ll(1, x2, y2, z2, 90., &x1, &y1, &z1);
+          x2 = x1; y2 = y1; z2 = z1;
+          if (nip % 2) {
+            if ((i == mid) && (i == j)) { x2 = 0; y2 = FG_PI * 0.5; }
+            if ((j == mid) && (i < mid)) x2 = 0;
+            if ((j == mid) && (i > mid)) x2 = FG_PI;
+          }
+          break;
+        case 3:
+          rotate_ll(3, x1, y1, z1, -180., &x2, &y2, &z2);
+          rotate_ll(1, x2, y2, z2, 90., &x1, &y1, &z1);
+          x2 = x1; y2 = y1; z2 = z1;
+          if (nip % 2) { if (j == mid) x2 = FG_PI; }
+          break;
+        case 4:
+          rotate_ll(3, x1, y1, z1, 90., &x2, &y2, &z2);
+          rotate_ll(2, x2, y2, z2, 90., &x1, &y1, &z1);
+          x2 = x1; y2 = y1; z2 = z1;
+          break;
+        case 5:
+          rotate_ll(2, x1, y1, z1, 90., &x2, &y2, &z2);
+          rotate_ll(3, x2, y2, z2, 0., &x1, &y1, &z1);
+          x2 = x1; y2 = y1; z2 = z1;
+          if (nip % 2) {
+            if ((i == mid) && (i == j)) { x2 = 0; y2 = -FG_PI * 0.5; }
+            if ((i == mid) && (j > mid)) x2 = 0;
+            if ((i == mid) && (j < mid)) x2 = FG_PI;
+          }
+          break;
+        }
+        x[nt * nip * nip + j * nip + i] = x2;
+        y[nt * nip * nip + j * nip + i] = y2;
+      }
+}
+
+int fg_gnomonic_ed_corners(int ni, double shift_fac, int via_degrees, double *lonc, double *latc)
+{
+  if (ni < 2) return -1;
+  int nip = ni + 1;
+  size_t np = (size_t)nip * nip;
+  double *lam = (double *)malloc(np * sizeof(double));
+  double *the = (double *)malloc(np * sizeof(double));
+  face_equal_dist(ni, lam, the);
+  face_symmetrise(ni, lam, the);
+  double *xc = lonc, *yc = latc;
+  for (size_t k = 0; k < np; k++) { xc[k] = lam[k] - FG_PI; yc[k] = the[k]; }
+  free(lam); free(the);
+  six_tiles(ni, xc, yc);
+
+  for (size_t n = 0; n < 6 * np; n++) {
+    if (shift_fac > 1.e-4) xc[n] -= FG_PI / 18.;
+    if (xc[n] < 0.) xc[n] += 2. * FG_PI;
+    if (fabs(xc[n]) < 1.e-10) xc[n] = 0;
+    if (fabs(yc[n]) < 1.e-10) yc[n] = 0;
+  }
+  /* make shared tile edges bitwise identical */
+  size_t T = np;
+  for (int j = 0; j < nip; j++) {
+    xc[T + j * nip] = xc[j * nip + ni];                     yc[T + j * nip] = yc[j * nip + ni];
+    xc[2 * T + j * nip] = xc[ni * nip + ni - j];            yc[2 * T + j * nip] = yc[ni * nip + ni - j];
+  }
+  for (int i = 0; i < nip; i++) {
+    xc[4 * T + ni * nip + i] = xc[(ni - i) * nip];          yc[4 * T + ni * nip + i] = yc[(ni - i) * nip];
+    xc[5 * T + ni * nip + i] = xc[i];                       yc[5 * T + ni * nip + i] = yc[i];
+    xc[2 * T + i] = xc[T + ni * nip + i];                   yc[2 * T + i] = yc[T + ni * nip + i];
+    xc[3 * T + i] = xc[T + (ni - i) * nip + ni];            yc[3 * T + i] = yc[T + (ni - i) * nip + ni];
+  }
+  for (int j = 0; j < nip; j++) {
+    xc[5 * T + j * nip + ni] = xc[T + ni - j];              yc[5 * T + j * nip + ni] = yc[T + ni - j];
+    xc[3 * T + j * nip] = xc[2 * T + j * nip + ni];         yc[3 * T + j * nip] = yc[2 * T + j * nip + ni];
+    xc[4 * T + j * nip] = xc[2 * T + ni * nip + ni - j];    yc[4 * T + j * nip] = yc[2 * T + ni * nip + ni - j];
+  }
+  for (int i = 0; i < nip; i++) {
+    xc[4 * T + i] = xc[3 * T + ni * nip + i];               yc[4 * T + i] = yc[3 * T + ni * nip + i];
+    xc[5 * T + i] = xc[3 * T + (ni - i) * nip + ni];        yc[5 * T + i] = yc[3 * T + (ni - i) * nip + ni];
+  }
+  for (int j = 0; j < nip; j++) {
+    xc[5 * T + j * nip] = xc[4 * T + j * nip + ni];         yc[5 * T + j * nip] = yc[4 * T + j * nip + ni];
+  }
+  if (via_degrees) {
+    /* grid files hold degrees (create_gnomonic_cubic_grid.c:717-720); fregrid converts back
+       (fregrid_util.c:230-231) */
+    for (size_t n = 0; n < 6 * np; n++) {
+      double xd = xc[n] * FG_R2D, yd = yc[n] * FG_R2D;
+      xc[n] = xd * FG_D2R;
+      yc[n] = yd * FG_D2R;
+    }
+  }
+  return 0;
+}
+
+int fg_latlon_corners(int nlon, int nlat, double lonbegin, double lonend, double latbegin,
+                      double latend, int center_y, double *lonc, double *latc)
+{
+  if (nlon < 1 || nlat < 1) return -1;
+  double lon_range = lonend - lonbegin, lat_range = latend - latbegin;
+  double dlon = lon_range / nlon;
+  double dlat = center_y ? lat_range / nlat : lat_range / (nlat - 1);
+  for (int j = 0; j <= nlat; j++) {
+    double latv = center_y ? (latbegin + j * dlat) * FG_D2R : (latbegin + (j - 0.5) * dlat) * FG_D2R;
+    for (int i = 0; i <= nlon; i++) {
+      lonc[(size_t)j * (nlon + 1) + i] = (lonbegin + i * dlon) * FG_D2R;
+      latc[(size_t)j * (nlon + 1) + i] = latv;
+    }
+  }
+  return 0;
+}

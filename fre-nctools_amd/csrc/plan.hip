@@ -1,0 +1,819 @@
+// plan.hip -- host orchestration and the C ABI of libfregrid_hip.so (see include/fregrid_hip.h).
+//
+// A plan owns, in HBM, everything one destination tile needs: per-cell records of the
+// source tiles and of the destination tile, the exchange cells in canonical order and the
+// destination-row CSR layout for the sweep.  Device memory comes from a small caching pool
+// so that repeated plan creation (one per destination tile / per benchmark step) does not
+// pay hipMalloc/hipFree.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "fregrid_hip.h"
+#include "xgrid_device.h"
+
+// ----------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return fail(FG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" const char *fg_last_error(void) { return g_err.c_str(); }
+
+extern "C" int fg_device_count(void)
+{
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { fail(FG_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); return FG_ERR_HIP; }
+  return n;
+}
+
+// ----------------------------------------------------------------------------- memory pool
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void *>> free_;   // (device, class bytes) -> blocks
+  std::map<void *, std::pair<int, size_t>> live_;
+  static size_t klass(size_t n)
+  {
+    size_t c = 256;
+    while (c < n) c += (c < (1u << 20) ? c : (c >> 2));           // x2 up to 1 MiB, then x1.25
+    return c;
+  }
+  void *get(int dev, size_t n)
+  {
+    if (n == 0) n = 1;
+    size_t c = klass(n);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_.find({dev, c});
+      if (it != free_.end() && !it->second.empty()) {
+        void *p = it->second.back(); it->second.pop_back();
+        live_[p] = {dev, c};
+        return p;
+      }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, c) != hipSuccess) {
+      release_all();
+      if (hipMalloc(&p, c) != hipSuccess) return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    live_[p] = {dev, c};
+    return p;
+  }
+  void put(void *p)
+  {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = live_.find(p);
+    if (it == live_.end()) return;
+    free_[it->second].push_back(p);
+    live_.erase(it);
+  }
+  void release_all()
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &kv : free_) for (void *p : kv.second) (void)hipFree(p);
+    free_.clear();
+  }
+};
+Pool g_pool;
+}  // namespace
+
+extern "C" void fg_pool_release(void) { g_pool.release_all(); }
+
+// ----------------------------------------------------------------------------- plan
+struct fg_plan {
+  int order = 0, device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  int ntiles = 0;
+  std::vector<int> nx_in, ny_in, cell_off;
+  int nsrc = 0;                 // flattened source cells
+  int nx_out = 0, ny_out = 0, ndst = 0;
+  long f_stride = 0;            // elements in one level of the source field array
+  bool searched = false, finalized = false, have_geom = false;
+
+  std::vector<void *> owned;    // every pool block of this plan
+  FgTile *tiles_dev = nullptr;
+  double *mask_dev = nullptr;
+  FgCells S{}, D{};
+  // exchange cells
+  long nx = 0;
+  int *x_src = nullptr, *x_dst = nullptr;
+  double *x_area = nullptr, *x_c1 = nullptr, *x_c2 = nullptr;
+  int *xoff = nullptr, *nacc = nullptr;
+  double *sums = nullptr, *cen = nullptr;
+  // sweep
+  FgCsr csr{};
+  int *src_idx_f = nullptr;
+  double *row_sum = nullptr, *red_partial = nullptr, *red_result = nullptr;
+  long row_sum_cap = 0;
+  long stats[FG_NSTATS] = {0};
+
+  template <typename T> T *alloc(size_t count)
+  {
+    void *p = g_pool.get(device, count * sizeof(T));
+    if (p) owned.push_back(p);
+    return (T *)p;
+  }
+  void release(void *p)
+  {
+    if (!p) return;
+    for (size_t k = 0; k < owned.size(); k++) if (owned[k] == p) { owned.erase(owned.begin() + k); break; }
+    g_pool.put(p);
+  }
+};
+
+static bool alloc_cells(fg_plan *pl, FgCells *c, size_t n)
+{
+  c->lat_min = pl->alloc<double>(n); c->lat_max = pl->alloc<double>(n);
+  c->lon_min = pl->alloc<double>(n); c->lon_max = pl->alloc<double>(n);
+  c->lon_avg = pl->alloc<double>(n); c->area = pl->alloc<double>(n);
+  c->nv = pl->alloc<int>(n);
+  c->verts = pl->alloc<double>(n * 16);
+  return c->lat_min && c->lat_max && c->lon_min && c->lon_max && c->lon_avg && c->area && c->nv && c->verts;
+}
+
+static int plan_base(int order, int ntiles_in, const int *nx_in, const int *ny_in, int nx_out, int ny_out,
+                     int device, fg_plan **out)
+{
+  if (order != FG_CONSERVE_ORDER1 && order != FG_CONSERVE_ORDER2) return fail(FG_ERR_ARG, "order must be 1 or 2");
+  if (ntiles_in < 1 || !nx_in || !ny_in || nx_out < 1 || ny_out < 1 || !out) return fail(FG_ERR_ARG, "bad grid sizes");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(FG_ERR_HIP, "no HIP device visible: libfregrid_hip needs an MI355X-class GPU");
+  if (device < 0 || device >= ndev) return fail(FG_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+  HIPCHK(hipSetDevice(device));
+  fg_plan *pl = new fg_plan();
+  pl->order = order; pl->device = device; pl->ntiles = ntiles_in;
+  long off = 0, foff = 0;
+  for (int m = 0; m < ntiles_in; m++) {
+    if (nx_in[m] < 1 || ny_in[m] < 1) { delete pl; return fail(FG_ERR_ARG, "bad source tile size"); }
+    pl->nx_in.push_back(nx_in[m]); pl->ny_in.push_back(ny_in[m]); pl->cell_off.push_back((int)off);
+    off += (long)nx_in[m] * ny_in[m];
+    foff += (order == 2) ? (long)(nx_in[m] + 2) * (ny_in[m] + 2) : (long)nx_in[m] * ny_in[m];
+  }
+  if (off > 2000000000L || (long)nx_out * ny_out > 2000000000L) { delete pl; return fail(FG_ERR_ARG, "grid too large for 32-bit cell indices"); }
+  pl->nsrc = (int)off; pl->f_stride = foff;
+  pl->nx_out = nx_out; pl->ny_out = ny_out; pl->ndst = nx_out * ny_out;
+  hipError_t e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete pl; return fail(FG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  *out = pl;
+  return 0;
+}
+
+extern "C" void fg_plan_destroy(fg_plan *pl)
+{
+  if (!pl) return;
+  (void)hipSetDevice(pl->device);
+  if (pl->stream || !pl->own_stream) (void)hipStreamSynchronize(pl->stream);
+  if (pl->stream && pl->own_stream) (void)hipStreamDestroy(pl->stream);
+  for (void *p : pl->owned) g_pool.put(p);
+  delete pl;
+}
+
+static void choose_bins(const fg_plan *pl, double mean_dlat, double mean_dlon, FgBins *b)
+{
+  const double PI = 3.14159265358979323846;
+  double h = 2.0 * mean_dlat, w = 2.0 * mean_dlon;
+  int nblat = (h > 0) ? (int)ceil(PI / h) : 1;
+  int nblon = (w > 0) ? (int)ceil(2.0 * PI / w) : 1;
+  if (nblat < 1) nblat = 1; if (nblat > 8192) nblat = 8192;
+  if (nblon < 1) nblon = 1; if (nblon > 16384) nblon = 16384;
+  (void)pl;
+  b->nblat = nblat; b->nblon = nblon;
+  b->inv_wlat = nblat / PI;
+  b->inv_wlon = nblon / (2.0 * PI);
+}
+
+// the search proper; all grid pointers are device pointers
+static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
+                        const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
+                        double mean_dlat, double mean_dlon)
+{
+  hipStream_t st = pl->stream;
+  const int nsrc = pl->nsrc, ndst = pl->ndst, order = pl->order;
+
+  // tile descriptors: source tiles + the destination tile as entry [ntiles]
+  std::vector<FgTile> th(pl->ntiles + 1);
+  for (int m = 0; m < pl->ntiles; m++) th[m] = FgTile{d_lon_in[m], d_lat_in[m], pl->nx_in[m], pl->ny_in[m], pl->cell_off[m]};
+  th[pl->ntiles] = FgTile{d_lon_out, d_lat_out, pl->nx_out, pl->ny_out, 0};
+  pl->tiles_dev = pl->alloc<FgTile>(pl->ntiles + 1);
+  if (!pl->tiles_dev) return fail(FG_ERR_HIP, "out of device memory");
+  HIPCHK(hipMemcpyAsync(pl->tiles_dev, th.data(), sizeof(FgTile) * th.size(), hipMemcpyHostToDevice, st));
+
+  bool any_mask = false;
+  if (d_mask_in) for (int m = 0; m < pl->ntiles; m++) if (d_mask_in[m]) any_mask = true;
+  if (any_mask) {
+    pl->mask_dev = pl->alloc<double>(nsrc);
+    if (!pl->mask_dev) return fail(FG_ERR_HIP, "out of device memory");
+    std::vector<double> ones;
+    for (int m = 0; m < pl->ntiles; m++) {
+      size_t nc = (size_t)pl->nx_in[m] * pl->ny_in[m];
+      if (d_mask_in[m]) HIPCHK(hipMemcpyAsync(pl->mask_dev + pl->cell_off[m], d_mask_in[m], nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+      else {
+        ones.assign(nc, 1.0);
+        HIPCHK(hipMemcpyAsync(pl->mask_dev + pl->cell_off[m], ones.data(), nc * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+      }
+    }
+  }
+
+  if (!alloc_cells(pl, &pl->S, nsrc) || !alloc_cells(pl, &pl->D, ndst)) return fail(FG_ERR_HIP, "out of device memory");
+  unsigned *err_dev = pl->alloc<unsigned>(4);
+  unsigned long long *stats_dev = pl->alloc<unsigned long long>(FG_NSTATS);
+  unsigned long long *total_dev = pl->alloc<unsigned long long>(4);
+  int *defer_cnt = pl->alloc<int>(4);
+  if (!err_dev || !stats_dev || !total_dev || !defer_cnt) return fail(FG_ERR_HIP, "out of device memory");
+  HIPCHK(hipMemsetAsync(err_dev, 0, 4 * sizeof(unsigned), st));
+  HIPCHK(hipMemsetAsync(stats_dev, 0, FG_NSTATS * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(defer_cnt, 0, 4 * sizeof(int), st));
+
+  fgd_cell_struct(pl->tiles_dev, pl->ntiles, nsrc, pl->S, err_dev, st);
+  fgd_cell_struct(pl->tiles_dev + pl->ntiles, 1, ndst, pl->D, err_dev, st);
+  pl->have_geom = true;
+
+  // --- bins over the destination cells
+  FgBins bins;
+  choose_bins(pl, mean_dlat, mean_dlon, &bins);
+  const long nbins = (long)bins.nblat * bins.nblon;
+  int4 *dbins = pl->alloc<int4>(ndst);
+  int *bin_cnt = pl->alloc<int>(nbins + 1);
+  int *bin_start = pl->alloc<int>(nbins + 1);
+  long scan_n = (nbins + 1 > (long)nsrc + 1) ? nbins + 1 : (long)nsrc + 1;
+  if (scan_n < ndst + 1) scan_n = ndst + 1;
+  unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(scan_n));
+  if (!dbins || !bin_cnt || !bin_start || !scan_ws) return fail(FG_ERR_HIP, "out of device memory");
+  HIPCHK(hipMemsetAsync(bin_cnt, 0, (nbins + 1) * sizeof(int), st));
+  fgd_bin_count(ndst, pl->D, bins, dbins, bin_cnt, st);
+  fgd_exclusive_scan(bin_cnt, nbins + 1, bin_start, scan_ws, total_dev, st);
+  unsigned long long nentries = 0;
+  HIPCHK(hipMemcpyAsync(&nentries, total_dev, sizeof nentries, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (nentries > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
+  int *bin_cells = pl->alloc<int>(nentries ? nentries : 1);
+  if (!bin_cells) return fail(FG_ERR_HIP, "out of device memory");
+  HIPCHK(hipMemsetAsync(bin_cnt, 0, (nbins + 1) * sizeof(int), st));       // reused as fill cursor
+  fgd_bin_fill(ndst, bins, dbins, bin_start, bin_cnt, bin_cells, st);
+
+  // --- candidate pairs
+  int *cand_cnt = pl->alloc<int>(nsrc + 1);
+  int *cand_off = pl->alloc<int>(nsrc + 1);
+  if (!cand_cnt || !cand_off) return fail(FG_ERR_HIP, "out of device memory");
+  HIPCHK(hipMemsetAsync(cand_cnt + nsrc, 0, sizeof(int), st));
+  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, pl->D, bins, dbins, bin_start, bin_cells, cand_cnt, nullptr, nullptr, nullptr, st);
+  fgd_exclusive_scan(cand_cnt, nsrc + 1, cand_off, scan_ws, total_dev, st);
+  unsigned long long npairs64 = 0;
+  unsigned errh[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(&npairs64, total_dev, sizeof npairs64, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(errh, err_dev, sizeof errh, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (errh[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
+  if (npairs64 > 2000000000ull) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
+  const int npairs = (int)npairs64;
+
+  int *pair_src = pl->alloc<int>(npairs + 1), *pair_dst = pl->alloc<int>(npairs + 1);
+  double *tmp_area = pl->alloc<double>(npairs + 1);
+  double *tmp_clon = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
+  double *tmp_clat = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
+  int *defer_list = pl->alloc<int>(npairs + 1);
+  pl->nacc = pl->alloc<int>(nsrc + 1);
+  pl->xoff = pl->alloc<int>(nsrc + 1);
+  if (!pair_src || !pair_dst || !tmp_area || !defer_list || !pl->nacc || !pl->xoff ||
+      (order == 2 && (!tmp_clon || !tmp_clat))) return fail(FG_ERR_HIP, "out of device memory");
+  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, pl->D, bins, dbins, bin_start, bin_cells, cand_cnt, cand_off, pair_src, pair_dst, st);
+
+  // --- clip, area, centroid integrals
+  fgd_clip(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
+           defer_list, defer_cnt, stats_dev, err_dev, st);
+
+  // --- compaction into canonical order
+  HIPCHK(hipMemsetAsync(pl->nacc + nsrc, 0, sizeof(int), st));
+  fgd_count_accepted(nsrc, cand_off, cand_cnt, tmp_area, pl->nacc, st);
+  fgd_exclusive_scan(pl->nacc, nsrc + 1, pl->xoff, scan_ws, total_dev, st);
+  unsigned long long nx64 = 0, statsh[FG_NSTATS];
+  int deferh = 0;
+  HIPCHK(hipMemcpyAsync(&nx64, total_dev, sizeof nx64, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(errh, err_dev, sizeof errh, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(statsh, stats_dev, sizeof statsh, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&deferh, defer_cnt, sizeof deferh, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (errh[0] & 2u) return fail(FG_ERR_PARALLEL, "the line between <x1_0,y1_0> and  <x1_1,y1_1> should not parallel to "
+                                                 "the line between <x2_0,y2_0> and  <x2_1,y2_1>");
+  if (errh[0] & 4u) return fail(FG_ERR_MAXV, "clipped polygon exceeds 16 vertices");
+  pl->nx = (long)nx64;
+  pl->x_src = pl->alloc<int>(pl->nx + 1); pl->x_dst = pl->alloc<int>(pl->nx + 1);
+  pl->x_area = pl->alloc<double>(pl->nx + 1);
+  if (order == 2) { pl->x_c1 = pl->alloc<double>(pl->nx + 1); pl->x_c2 = pl->alloc<double>(pl->nx + 1); }
+  if (!pl->x_src || !pl->x_dst || !pl->x_area || (order == 2 && (!pl->x_c1 || !pl->x_c2))) return fail(FG_ERR_HIP, "out of device memory");
+  fgd_scatter_xcells(order, npairs, pair_src, pair_dst, cand_off, cand_cnt, pl->xoff, tmp_area, tmp_clon, tmp_clat,
+                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, st);
+  if (order == 2) {
+    pl->sums = pl->alloc<double>(3 * (size_t)nsrc);
+    if (!pl->sums) return fail(FG_ERR_HIP, "out of device memory");
+    fgd_cell_sums(nsrc, pl->xoff, pl->nacc, pl->x_area, pl->x_c1, pl->x_c2, pl->sums, st);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+
+  pl->stats[FG_STAT_PAIRS] = npairs;
+  pl->stats[FG_STAT_NONEMPTY] = (long)statsh[FG_STAT_NONEMPTY];
+  pl->stats[FG_STAT_NXGRID] = pl->nx;
+  pl->stats[FG_STAT_BORDERLINE] = (long)statsh[FG_STAT_BORDERLINE];
+  pl->stats[FG_STAT_BINS] = nbins;
+  pl->stats[FG_STAT_BIN_ENTRIES] = (long)nentries;
+  pl->stats[FG_STAT_DEFERRED] = deferh;
+
+  // scratch no longer needed
+  void *scratch[] = {dbins, bin_cnt, bin_start, scan_ws, bin_cells, cand_cnt, cand_off, pair_src, pair_dst,
+                     tmp_area, tmp_clon, tmp_clat, defer_list, err_dev, stats_dev, total_dev, defer_cnt};
+  for (void *p : scratch) pl->release(p);
+  pl->searched = true;
+  return pl->nx;
+}
+
+// mean cell extents from a strided sample of corner arrays (host or device-copied-to-host)
+static void sample_extents(int nx, int ny, const double *lon, const double *lat, double *mdlat, double *mdlon)
+{
+  const double PI = 3.14159265358979323846;
+  long ncell = (long)nx * ny;
+  long step = ncell / 4096; if (step < 1) step = 1;
+  double sl = 0, sw = 0; long cnt = 0;
+  for (long c = 0; c < ncell; c += step) {
+    int i = (int)(c % nx), j = (int)(c / nx);
+    long n0 = (long)j * (nx + 1) + i, n1 = n0 + 1, n3 = n0 + nx + 1, n2 = n3 + 1;
+    double y[4] = {lat[n0], lat[n1], lat[n2], lat[n3]}, x[4] = {lon[n0], lon[n1], lon[n2], lon[n3]};
+    double ymin = y[0], ymax = y[0], w = 0;
+    for (int k = 1; k < 4; k++) { if (y[k] < ymin) ymin = y[k]; if (y[k] > ymax) ymax = y[k]; }
+    for (int k = 0; k < 4; k++) {
+      double d = fabs(remainder(x[(k + 1) & 3] - x[k], 2.0 * PI));
+      if (d > w) w = d;
+    }
+    if (w > PI / 2) continue;      // polar caps: not representative
+    sl += ymax - ymin; sw += w; cnt++;
+  }
+  if (cnt == 0) { *mdlat = PI / 180; *mdlon = PI / 180; return; }
+  *mdlat = sl / cnt; *mdlon = sw / cnt;
+  if (*mdlat < 1e-7) *mdlat = 1e-7;
+  if (*mdlon < 1e-7) *mdlon = 1e-7;
+}
+
+extern "C" long fg_plan_create(int order, int ntiles_in, const int *nx_in, const int *ny_in,
+                               const double *const *lon_in, const double *const *lat_in,
+                               const double *const *mask_in,
+                               int nx_out, int ny_out, const double *lon_out, const double *lat_out,
+                               int device, fg_plan **plan_out)
+{
+  if (!lon_in || !lat_in || !lon_out || !lat_out) return fail(FG_ERR_ARG, "null grid pointer");
+  fg_plan *pl = nullptr;
+  int rc = plan_base(order, ntiles_in, nx_in, ny_in, nx_out, ny_out, device, &pl);
+  if (rc) return rc;
+  hipStream_t st = pl->stream;
+  std::vector<const double *> dlon(ntiles_in), dlat(ntiles_in), dmask(ntiles_in, nullptr);
+  std::vector<void *> staged;
+  auto up = [&](const double *h, size_t n) -> const double * {
+    double *d = pl->alloc<double>(n);
+    if (!d) return nullptr;
+    if (hipMemcpyAsync(d, h, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
+    staged.push_back(d);
+    return d;
+  };
+  bool ok = true;
+  for (int m = 0; m < ntiles_in && ok; m++) {
+    size_t np = (size_t)(nx_in[m] + 1) * (ny_in[m] + 1);
+    dlon[m] = up(lon_in[m], np); dlat[m] = up(lat_in[m], np);
+    if (mask_in && mask_in[m]) { dmask[m] = up(mask_in[m], (size_t)nx_in[m] * ny_in[m]); ok = ok && dmask[m]; }
+    ok = ok && dlon[m] && dlat[m];
+  }
+  size_t npo = (size_t)(nx_out + 1) * (ny_out + 1);
+  const double *dlo = ok ? up(lon_out, npo) : nullptr, *dla = ok ? up(lat_out, npo) : nullptr;
+  if (!ok || !dlo || !dla) { fg_plan_destroy(pl); return fail(FG_ERR_HIP, "grid upload failed (out of device memory?)"); }
+  double mdlat, mdlon;
+  sample_extents(nx_out, ny_out, lon_out, lat_out, &mdlat, &mdlon);
+  long nx = plan_search(pl, dlon.data(), dlat.data(), mask_in ? dmask.data() : nullptr, dlo, dla, mdlat, mdlon);
+  if (nx < 0) { fg_plan_destroy(pl); return nx; }
+  for (void *p : staged) pl->release(p);
+  *plan_out = pl;
+  return nx;
+}
+
+// Same as fg_plan_create but every grid pointer is a DEVICE pointer (inputs already in HBM).
+// mean_dlat/mean_dlon: typical destination cell extent in radians (<=0: derive by copying a
+// strided sample of the destination corners to the host).
+extern "C" long fg_plan_create_dev(int order, int ntiles_in, const int *nx_in, const int *ny_in,
+                                   const double *const *d_lon_in, const double *const *d_lat_in,
+                                   const double *const *d_mask_in,
+                                   int nx_out, int ny_out, const double *d_lon_out, const double *d_lat_out,
+                                   double mean_dlat, double mean_dlon, int device, void *stream,
+                                   int use_caller_stream, fg_plan **plan_out)
+{
+  if (!d_lon_in || !d_lat_in || !d_lon_out || !d_lat_out) return fail(FG_ERR_ARG, "null grid pointer");
+  fg_plan *pl = nullptr;
+  int rc = plan_base(order, ntiles_in, nx_in, ny_in, nx_out, ny_out, device, &pl);
+  if (rc) return rc;
+  if (use_caller_stream) {
+    (void)hipStreamDestroy(pl->stream);
+    pl->stream = (hipStream_t)stream; pl->own_stream = false;
+  }
+  if (!(mean_dlat > 0) || !(mean_dlon > 0)) {
+    size_t npo = (size_t)(nx_out + 1) * (ny_out + 1);
+    std::vector<double> hl(npo), ha(npo);
+    if (hipMemcpy(hl.data(), d_lon_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(ha.data(), d_lat_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+      fg_plan_destroy(pl); return fail(FG_ERR_HIP, "copy of destination corners failed");
+    }
+    sample_extents(nx_out, ny_out, hl.data(), ha.data(), &mean_dlat, &mean_dlon);
+  }
+  long nx = plan_search(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon);
+  if (nx < 0) { fg_plan_destroy(pl); return nx; }
+  *plan_out = pl;
+  return nx;
+}
+
+extern "C" int fg_plan_set_stream(fg_plan *pl, void *stream)
+{
+  if (!pl) return fail(FG_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(pl->device));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  if (pl->own_stream && pl->stream) (void)hipStreamDestroy(pl->stream);
+  pl->stream = (hipStream_t)stream; pl->own_stream = false;
+  return 0;
+}
+
+// a plan without a search: exchange cells are supplied later by fg_plan_set_xgrid
+extern "C" int fg_plan_create_empty(int order, int ntiles_in, const int *nx_in, const int *ny_in,
+                                    int nx_out, int ny_out, int device, fg_plan **plan_out)
+{
+  fg_plan *pl = nullptr;
+  int rc = plan_base(order, ntiles_in, nx_in, ny_in, nx_out, ny_out, device, &pl);
+  if (rc) return rc;
+  std::vector<FgTile> th(pl->ntiles);
+  for (int m = 0; m < pl->ntiles; m++) th[m] = FgTile{nullptr, nullptr, pl->nx_in[m], pl->ny_in[m], pl->cell_off[m]};
+  pl->tiles_dev = pl->alloc<FgTile>(pl->ntiles + 1);
+  if (!pl->tiles_dev || hipMemcpy(pl->tiles_dev, th.data(), sizeof(FgTile) * th.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    fg_plan_destroy(pl); return fail(FG_ERR_HIP, "out of device memory");
+  }
+  *plan_out = pl;
+  return 0;
+}
+
+extern "C" long fg_plan_nxgrid(const fg_plan *pl) { return pl ? pl->nx : FG_ERR_ARG; }
+extern "C" long fg_plan_ncells_in(const fg_plan *pl) { return pl ? pl->nsrc : FG_ERR_ARG; }
+extern "C" double *fg_plan_cell_sums_dev(fg_plan *pl) { return (pl && pl->order == 2) ? pl->sums : nullptr; }
+extern "C" int fg_plan_copy_cell_sums(fg_plan *pl, double *dst_dev)
+{
+  if (!pl || !dst_dev) return fail(FG_ERR_ARG, "null argument");
+  if (pl->order != 2 || !pl->sums) return fail(FG_ERR_STATE, "plan holds no order-2 cell sums");
+  HIPCHK(hipSetDevice(pl->device));
+  HIPCHK(hipMemcpyAsync(dst_dev, pl->sums, 3 * (size_t)pl->nsrc * sizeof(double), hipMemcpyDeviceToDevice, pl->stream));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  return 0;
+}
+extern "C" void *fg_plan_stream(fg_plan *pl) { return pl ? (void *)pl->stream : nullptr; }
+extern "C" int fg_plan_sync(fg_plan *pl)
+{
+  if (!pl) return fail(FG_ERR_ARG, "null plan");
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  return 0;
+}
+extern "C" int fg_plan_stats(const fg_plan *pl, long *stats, int n)
+{
+  if (!pl || !stats) return fail(FG_ERR_ARG, "null argument");
+  for (int k = 0; k < n && k < FG_NSTATS; k++) stats[k] = pl->stats[k];
+  return 0;
+}
+
+static int build_csr(fg_plan *pl)
+{
+  hipStream_t st = pl->stream;
+  const int ndst = pl->ndst;
+  const long nx = pl->nx;
+  HIPCHK(hipSetDevice(pl->device));
+  if (!pl->src_idx_f) {
+    pl->src_idx_f = pl->alloc<int>(pl->nsrc + 1);
+    if (!pl->src_idx_f) return fail(FG_ERR_HIP, "out of device memory");
+    fgd_src_field_index(pl->order, pl->tiles_dev, pl->ntiles, pl->nsrc, pl->src_idx_f, st);
+  }
+  int *row_cnt = pl->alloc<int>(ndst + 1);
+  int *perm = pl->alloc<int>(nx + 1);
+  unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(ndst + 1));
+  unsigned long long *total_dev = pl->alloc<unsigned long long>(4);
+  pl->csr.row_ptr = pl->alloc<int>(ndst + 1);
+  pl->csr.idx_f = pl->alloc<int>(nx + 1); pl->csr.idx_g = pl->alloc<int>(nx + 1);
+  pl->csr.area = pl->alloc<double>(nx + 1);
+  if (pl->order == 2) { pl->csr.di = pl->alloc<double>(nx + 1); pl->csr.dj = pl->alloc<double>(nx + 1); }
+  if (!row_cnt || !perm || !scan_ws || !total_dev || !pl->csr.row_ptr || !pl->csr.idx_f || !pl->csr.idx_g || !pl->csr.area ||
+      (pl->order == 2 && (!pl->csr.di || !pl->csr.dj))) return fail(FG_ERR_HIP, "out of device memory");
+  HIPCHK(hipMemsetAsync(row_cnt, 0, (ndst + 1) * sizeof(int), st));
+  fgd_csr_count(nx, pl->x_dst, row_cnt, st);
+  fgd_exclusive_scan(row_cnt, ndst + 1, pl->csr.row_ptr, scan_ws, total_dev, st);
+  HIPCHK(hipMemsetAsync(row_cnt, 0, (ndst + 1) * sizeof(int), st));
+  fgd_csr_fill(nx, pl->x_dst, pl->csr.row_ptr, row_cnt, perm, st);
+  fgd_csr_sort_rows(ndst, pl->csr.row_ptr, perm, st);
+  fgd_csr_gather(pl->order, nx, perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, pl->csr, st);
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  pl->release(row_cnt); pl->release(perm); pl->release(scan_ws); pl->release(total_dev);
+  if (!pl->red_partial) { pl->red_partial = pl->alloc<double>(1024); pl->red_result = pl->alloc<double>(4); }
+  if (!pl->red_partial || !pl->red_result) return fail(FG_ERR_HIP, "out of device memory");
+  return 0;
+}
+
+extern "C" int fg_plan_finalize(fg_plan *pl, const double *total_cell_sums_dev)
+{
+  if (!pl) return fail(FG_ERR_ARG, "null plan");
+  if (!pl->searched) return fail(FG_ERR_STATE, "fg_plan_finalize: plan holds no search result");
+  if (pl->finalized) return fail(FG_ERR_STATE, "fg_plan_finalize: already finalized");
+  HIPCHK(hipSetDevice(pl->device));
+  if (pl->order == 2) {
+    pl->cen = pl->alloc<double>(2 * (size_t)pl->nsrc);
+    if (!pl->cen) return fail(FG_ERR_HIP, "out of device memory");
+    const double *tot = total_cell_sums_dev ? total_cell_sums_dev : pl->sums;
+    fgd_centroids(pl->nsrc, pl->S, tot, pl->cen, pl->stream);
+    fgd_distances(pl->nx, pl->nsrc, pl->x_src, pl->x_area, pl->cen, pl->x_c1, pl->x_c2, pl->stream);
+  }
+  int rc = build_csr(pl);
+  if (rc) return rc;
+  pl->finalized = true;
+  return 0;
+}
+
+extern "C" int fg_plan_get_xgrid(const fg_plan *pl, int *t_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                                 double *area, double *c1, double *c2)
+{
+  if (!pl) return fail(FG_ERR_ARG, "null plan");
+  if (!pl->searched) return fail(FG_ERR_STATE, "plan holds no exchange cells");
+  HIPCHK(hipSetDevice(pl->device));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  const long nx = pl->nx;
+  if (nx == 0) return 0;
+  if (t_in || i_in || j_in) {
+    std::vector<int> s(nx);
+    HIPCHK(hipMemcpy(s.data(), pl->x_src, nx * sizeof(int), hipMemcpyDeviceToHost));
+    int m = 0;
+    for (long k = 0; k < nx; k++) {
+      int sv = s[k];
+      while (m + 1 < pl->ntiles && sv >= pl->cell_off[m + 1]) m++;
+      while (m > 0 && sv < pl->cell_off[m]) m--;
+      int loc = sv - pl->cell_off[m];
+      if (t_in) t_in[k] = m;
+      if (i_in) i_in[k] = loc % pl->nx_in[m];
+      if (j_in) j_in[k] = loc / pl->nx_in[m];
+    }
+  }
+  if (i_out || j_out) {
+    std::vector<int> d(nx);
+    HIPCHK(hipMemcpy(d.data(), pl->x_dst, nx * sizeof(int), hipMemcpyDeviceToHost));
+    for (long k = 0; k < nx; k++) {
+      if (i_out) i_out[k] = d[k] % pl->nx_out;
+      if (j_out) j_out[k] = d[k] / pl->nx_out;
+    }
+  }
+  if (area) HIPCHK(hipMemcpy(area, pl->x_area, nx * sizeof(double), hipMemcpyDeviceToHost));
+  if (pl->order == 2) {
+    if (c1) HIPCHK(hipMemcpy(c1, pl->x_c1, nx * sizeof(double), hipMemcpyDeviceToHost));
+    if (c2) HIPCHK(hipMemcpy(c2, pl->x_c2, nx * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+extern "C" int fg_plan_get_cell_area(const fg_plan *pl, double *area_in, double *area_out)
+{
+  if (!pl) return fail(FG_ERR_ARG, "null plan");
+  if (!pl->have_geom) return fail(FG_ERR_STATE, "plan holds no cell records");
+  HIPCHK(hipSetDevice(pl->device));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  if (area_in) HIPCHK(hipMemcpy(area_in, pl->S.area, (size_t)pl->nsrc * sizeof(double), hipMemcpyDeviceToHost));
+  if (area_out) HIPCHK(hipMemcpy(area_out, pl->D.area, (size_t)pl->ndst * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// per-cell records of the source (which = 0) or destination (which = 1) cells, for the
+// get_grid_cell_struct parity test.  Host arrays; vlon/vlat are [ncells][8].
+extern "C" int fg_plan_get_cell_struct(const fg_plan *pl, int which, double *lat_min, double *lat_max, double *lon_min,
+                                       double *lon_max, double *lon_avg, int *nvert, double *vlon, double *vlat)
+{
+  if (!pl) return fail(FG_ERR_ARG, "null plan");
+  if (!pl->have_geom) return fail(FG_ERR_STATE, "plan holds no cell records");
+  HIPCHK(hipSetDevice(pl->device));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  const FgCells &c = which ? pl->D : pl->S;
+  size_t n = which ? pl->ndst : pl->nsrc;
+  if (lat_min) HIPCHK(hipMemcpy(lat_min, c.lat_min, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (lat_max) HIPCHK(hipMemcpy(lat_max, c.lat_max, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (lon_min) HIPCHK(hipMemcpy(lon_min, c.lon_min, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (lon_max) HIPCHK(hipMemcpy(lon_max, c.lon_max, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (lon_avg) HIPCHK(hipMemcpy(lon_avg, c.lon_avg, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (nvert) HIPCHK(hipMemcpy(nvert, c.nv, n * sizeof(int), hipMemcpyDeviceToHost));
+  if (vlon || vlat) {
+    std::vector<double> v(n * 16);
+    HIPCHK(hipMemcpy(v.data(), c.verts, n * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < n; k++)
+      for (int l = 0; l < 8; l++) {
+        if (vlon) vlon[k * 8 + l] = v[k * 16 + l];
+        if (vlat) vlat[k * 8 + l] = v[k * 16 + 8 + l];
+      }
+  }
+  return 0;
+}
+
+extern "C" int fg_plan_set_xgrid(fg_plan *pl, long nxgrid, const int *t_in, const int *i_in, const int *j_in,
+                                 const int *i_out, const int *j_out, const double *area,
+                                 const double *di_in, const double *dj_in)
+{
+  if (!pl) return fail(FG_ERR_ARG, "null plan");
+  if (nxgrid < 0 || (nxgrid > 0 && (!t_in || !i_in || !j_in || !i_out || !j_out || !area))) return fail(FG_ERR_ARG, "null exchange-cell array");
+  if (pl->order == 2 && nxgrid > 0 && (!di_in || !dj_in)) return fail(FG_ERR_ARG, "order 2 needs di_in/dj_in");
+  if (pl->finalized || pl->searched) return fail(FG_ERR_STATE, "fg_plan_set_xgrid needs a plan from fg_plan_create_empty");
+  HIPCHK(hipSetDevice(pl->device));
+  std::vector<int> s(nxgrid), d(nxgrid);
+  for (long k = 0; k < nxgrid; k++) {
+    int m = t_in[k];
+    if (m < 0 || m >= pl->ntiles || i_in[k] < 0 || i_in[k] >= pl->nx_in[m] || j_in[k] < 0 || j_in[k] >= pl->ny_in[m] ||
+        i_out[k] < 0 || i_out[k] >= pl->nx_out || j_out[k] < 0 || j_out[k] >= pl->ny_out)
+      return fail(FG_ERR_ARG, "exchange cell %ld has an index outside its grid", k);
+    s[k] = pl->cell_off[m] + j_in[k] * pl->nx_in[m] + i_in[k];
+    d[k] = j_out[k] * pl->nx_out + i_out[k];
+  }
+  pl->nx = nxgrid;
+  pl->x_src = pl->alloc<int>(nxgrid + 1); pl->x_dst = pl->alloc<int>(nxgrid + 1);
+  pl->x_area = pl->alloc<double>(nxgrid + 1);
+  if (pl->order == 2) { pl->x_c1 = pl->alloc<double>(nxgrid + 1); pl->x_c2 = pl->alloc<double>(nxgrid + 1); }
+  if (!pl->x_src || !pl->x_dst || !pl->x_area || (pl->order == 2 && (!pl->x_c1 || !pl->x_c2))) return fail(FG_ERR_HIP, "out of device memory");
+  if (nxgrid > 0) {
+    HIPCHK(hipMemcpy(pl->x_src, s.data(), nxgrid * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pl->x_dst, d.data(), nxgrid * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pl->x_area, area, nxgrid * sizeof(double), hipMemcpyHostToDevice));
+    if (pl->order == 2) {
+      HIPCHK(hipMemcpy(pl->x_c1, di_in, nxgrid * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(pl->x_c2, dj_in, nxgrid * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  pl->searched = true;
+  int rc = build_csr(pl);
+  if (rc) return rc;
+  pl->finalized = true;
+  return 0;
+}
+
+extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad_x, const double *grad_y,
+                             const int *grad_mask, int has_missing, double missing, int nz,
+                             double *out, double *gsum_out)
+{
+  if (!pl || !data || !out) return fail(FG_ERR_ARG, "null argument");
+  if (!pl->finalized) return fail(FG_ERR_STATE, "fg_plan_apply: call fg_plan_finalize first");
+  if (nz < 1) return fail(FG_ERR_ARG, "nz must be >= 1");
+  if (nz > 1 && has_missing) return fail(FG_ERR_ARG, "conserve_interp: has_missing should be false when nz > 1");
+  if (pl->order == 2 && (!grad_x || !grad_y)) return fail(FG_ERR_ARG, "order 2 needs grad_x and grad_y");
+  if (pl->order == 2 && has_missing && !grad_mask) return fail(FG_ERR_ARG, "order 2 with missing values needs grad_mask");
+  HIPCHK(hipSetDevice(pl->device));
+  double miss = has_missing ? missing : -1.e20;                  // conserve_interp.c:541-542
+  double *rs = nullptr;
+  if (gsum_out) {
+    long need = (long)nz * pl->ndst;
+    if (need > pl->row_sum_cap) {
+      pl->release(pl->row_sum);
+      pl->row_sum = pl->alloc<double>(need);
+      if (!pl->row_sum) { pl->row_sum_cap = 0; return fail(FG_ERR_HIP, "out of device memory"); }
+      pl->row_sum_cap = need;
+    }
+    rs = pl->row_sum;
+  }
+  fgd_apply(pl->order, pl->ndst, pl->csr, data, grad_x, grad_y, grad_mask, has_missing, miss, nz,
+            pl->f_stride, pl->nsrc, out, rs, pl->stream);
+  if (gsum_out) {
+    fgd_reduce_sum(rs, (long)nz * pl->ndst, pl->red_partial, pl->red_result, pl->stream);
+    HIPCHK(hipMemcpyAsync(gsum_out, pl->red_result, sizeof(double), hipMemcpyDeviceToHost, pl->stream));
+    HIPCHK(hipStreamSynchronize(pl->stream));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ----------------------------------------------------------------------------- (B1)
+// libfrencutils drop-ins.  Fatal errors follow mosaic_util.c:57-65.
+static void fatal(const char *msg)
+{
+  fprintf(stderr, "FATAL Error: %s\n", msg);
+  exit(1);
+}
+
+#ifndef MAXXGRID
+#define MAXXGRID 5e6          /* create_xgrid.h:22-28, serial build */
+#endif
+
+extern "C" int get_maxxgrid(void) { return MAXXGRID; }
+extern "C" int get_maxxgrid_(void) { return get_maxxgrid(); }
+
+static int b1_device(void)
+{
+  const char *e = getenv("FREGRID_HIP_DEVICE");
+  return e ? atoi(e) : 0;
+}
+
+extern "C" void get_grid_area(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area)
+{
+  // a 1x1 dummy destination keeps the plan machinery uniform; only the source records are used
+  int nx = *nlon, ny = *nlat, one = 1;
+  const double dl[4] = {0, 0.01, 0, 0.01}, da[4] = {0, 0, 0.01, 0.01};
+  const double *lons[1] = {lon}, *lats[1] = {lat};
+  fg_plan *pl = nullptr;
+  long rc = fg_plan_create(FG_CONSERVE_ORDER1, 1, &nx, &ny, lons, lats, nullptr, one, one, dl, da, b1_device(), &pl);
+  if (rc < 0) fatal(fg_last_error());
+  if (fg_plan_get_cell_area(pl, area, nullptr)) fatal(fg_last_error());
+  fg_plan_destroy(pl);
+}
+extern "C" void get_grid_area_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area)
+{
+  get_grid_area(nlon, nlat, lon, lat, area);
+}
+
+static int b1_create_xgrid(int order, const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
+                           const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,
+                           const double *mask_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                           double *xgrid_area, double *xgrid_clon, double *xgrid_clat)
+{
+  int nx1 = *nlon_in, ny1 = *nlat_in;
+  const double *lons[1] = {lon_in}, *lats[1] = {lat_in}, *masks[1] = {mask_in};
+  fg_plan *pl = nullptr;
+  long nx = fg_plan_create(order, 1, &nx1, &ny1, lons, lats, masks, *nlon_out, *nlat_out, lon_out, lat_out, b1_device(), &pl);
+  if (nx < 0) fatal(fg_last_error());
+  if (nx >= (long)MAXXGRID)                                     // create_xgrid.c:1087-1088
+    fatal("nxgrid is greater than MAXXGRID/nthreads, increase MAXXGRID, decrease nthreads, or increase number of MPI ranks");
+  if (fg_plan_get_xgrid(pl, nullptr, i_in, j_in, i_out, j_out, xgrid_area, xgrid_clon, xgrid_clat)) fatal(fg_last_error());
+  fg_plan_destroy(pl);
+  return (int)nx;
+}
+
+extern "C" int create_xgrid_2dx2d_order1(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
+                                         const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,
+                                         const double *mask_in, int *i_in, int *j_in, int *i_out, int *j_out, double *xgrid_area)
+{
+  return b1_create_xgrid(FG_CONSERVE_ORDER1, nlon_in, nlat_in, nlon_out, nlat_out, lon_in, lat_in, lon_out, lat_out, mask_in,
+                         i_in, j_in, i_out, j_out, xgrid_area, nullptr, nullptr);
+}
+extern "C" int create_xgrid_2dx2d_order2(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
+                                         const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,
+                                         const double *mask_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                                         double *xgrid_area, double *xgrid_clon, double *xgrid_clat)
+{
+  return b1_create_xgrid(FG_CONSERVE_ORDER2, nlon_in, nlat_in, nlon_out, nlat_out, lon_in, lat_in, lon_out, lat_out, mask_in,
+                         i_in, j_in, i_out, j_out, xgrid_area, xgrid_clon, xgrid_clat);
+}
+extern "C" int create_xgrid_2dx2d_order1_(const int *a, const int *b, const int *c, const int *d, const double *e, const double *f,
+                                          const double *g, const double *h, const double *m, int *i1, int *j1, int *i2, int *j2, double *xa)
+{
+  return create_xgrid_2dx2d_order1(a, b, c, d, e, f, g, h, m, i1, j1, i2, j2, xa);
+}
+extern "C" int create_xgrid_2dx2d_order2_(const int *a, const int *b, const int *c, const int *d, const double *e, const double *f,
+                                          const double *g, const double *h, const double *m, int *i1, int *j1, int *i2, int *j2,
+                                          double *xa, double *xl, double *xt)
+{
+  return create_xgrid_2dx2d_order2(a, b, c, d, e, f, g, h, m, i1, j1, i2, j2, xa, xl, xt);
+}
+
+static int plan_apply_frac(fg_plan *pl, const double *data, double *out)
+{
+  fgd_apply_frac(pl->ndst, pl->csr, data, out, pl->stream);
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// interp.c:262-305: first-order remap with weights xarea / (sum of xarea over the destination cell)
+extern "C" void conserve_interp(int nx_src, int ny_src, int nx_dst, int ny_dst, const double *x_src,
+                                const double *y_src, const double *x_dst, const double *y_dst,
+                                const double *mask_src, const double *data_src, double *data_dst)
+{
+  const double *lons[1] = {x_src}, *lats[1] = {y_src}, *masks[1] = {mask_src};
+  fg_plan *pl = nullptr;
+  long nx = fg_plan_create(FG_CONSERVE_ORDER1, 1, &nx_src, &ny_src, lons, lats, masks, nx_dst, ny_dst, x_dst, y_dst, b1_device(), &pl);
+  if (nx < 0) fatal(fg_last_error());
+  if (nx >= (long)MAXXGRID)
+    fatal("The xgrid size is too large for resources.\n nxgrid is greater than MAXXGRID/nthreads; increase MAXXGRID,\n"
+          " decrease nthreads, or increase number of MPI ranks.");
+  if (fg_plan_finalize(pl, nullptr)) fatal(fg_last_error());
+  size_t ns = (size_t)nx_src * ny_src, nd = (size_t)nx_dst * ny_dst;
+  double *dsrc = nullptr, *ddst = nullptr;
+  if (hipMalloc(&dsrc, ns * sizeof(double)) != hipSuccess || hipMalloc(&ddst, nd * sizeof(double)) != hipSuccess) fatal("hipMalloc failed");
+  if (hipMemcpy(dsrc, data_src, ns * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) fatal("hipMemcpy failed");
+  if (plan_apply_frac(pl, dsrc, ddst)) fatal(fg_last_error());
+  if (hipMemcpy(data_dst, ddst, nd * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) fatal("hipMemcpy failed");
+  (void)hipFree(dsrc); (void)hipFree(ddst);
+  fg_plan_destroy(pl);
+}
+

@@ -1,0 +1,80 @@
+// xgrid_device.h -- structs and launcher prototypes shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// one grid tile as seen by the kernels (device pointers)
+struct FgTile {
+  const double *lon;   // [(ny+1)*(nx+1)] corner longitudes, radians
+  const double *lat;
+  int nx, ny;
+  int cell_off;        // index of this tile's first cell in the flattened cell numbering
+};
+
+// per-cell records, SoA scalars + one 128-byte vertex record per cell
+// (the quantities of create_xgrid.c:991-1016 plus the cell area of :66-88)
+struct FgCells {
+  double *lat_min, *lat_max, *lon_min, *lon_max, *lon_avg, *area;
+  int *nv;
+  double *verts;       // [ncells][16]: lon[8] then lat[8], after fix_lon
+};
+
+// uniform bins over latitude x (longitude mod 2pi)
+struct FgBins {
+  int nblat, nblon;
+  double inv_wlat, inv_wlon;
+};
+
+enum {
+  FG_STAT_PAIRS = 0,      // candidate pairs after the bounding-box tests
+  FG_STAT_NONEMPTY = 1,   // pairs whose clip is non-empty
+  FG_STAT_NXGRID = 2,
+  FG_STAT_BORDERLINE = 3, // |xarea/min_area - 1e-6| < 1e-15
+  FG_STAT_BINS = 4,
+  FG_STAT_BIN_ENTRIES = 5,
+  FG_STAT_DEFERRED = 6,   // pairs handled by the general (non quad x quad) kernel
+  FG_NSTATS = 8
+};
+
+int  fgd_exclusive_scan(const int *in, long n, int *out, unsigned long long *bsum_ws,
+                        unsigned long long *total_dev, hipStream_t st);
+long fgd_scan_ws_elems(long n);
+
+void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c, unsigned *err, hipStream_t st);
+void fgd_bin_count(int ncells, FgCells c, FgBins b, int4 *cell_bins, int *bin_cnt, hipStream_t st);
+void fgd_bin_fill(int ncells, FgBins b, const int4 *cell_bins, const int *bin_start, int *bin_fill, int *bin_cells, hipStream_t st);
+void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgCells D, FgBins b, const int4 *dbins,
+                    const int *bin_start, const int *bin_cells, int *cand_cnt, const int *cand_off,
+                    int *pair_src, int *pair_dst, hipStream_t st);
+void fgd_clip(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
+              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+              unsigned long long *stats, unsigned *err, hipStream_t st);
+void fgd_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt, const double *tmp_area, int *nacc, hipStream_t st);
+void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
+                        const int *cand_cnt, const int *xoff, const double *tmp_area, const double *tmp_clon,
+                        const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
+                        hipStream_t st);
+void fgd_cell_sums(int nsrc, const int *xoff, const int *nacc, const double *x_area, const double *x_c1,
+                   const double *x_c2, double *sums, hipStream_t st);
+void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st);
+void fgd_distances(long nx, int nsrc, const int *x_src, const double *x_area, const double *cen, double *x_c1,
+                   double *x_c2, hipStream_t st);
+
+// ---- sweep (apply_kernels.hip) ----
+// CSR by destination cell: row_ptr[ndst+1]; per entry: index of the source value in the
+// field array (idx_f), in the gradient arrays (idx_g), area, di, dj.
+struct FgCsr {
+  int *row_ptr;
+  int *idx_f, *idx_g;
+  double *area, *di, *dj;
+};
+void fgd_csr_count(long nx, const int *x_dst, int *row_cnt, hipStream_t st);
+void fgd_csr_fill(long nx, const int *x_dst, const int *row_ptr, int *row_fill, int *perm, hipStream_t st);
+void fgd_csr_sort_rows(int ndst, const int *row_ptr, int *perm, hipStream_t st);
+void fgd_csr_gather(int order, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
+                    const double *x_c2, const int *src_idx_f, FgCsr csr, hipStream_t st);
+void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsrc, int *src_idx_f, hipStream_t st);
+void fgd_apply(int order, int ndst, FgCsr csr, const double *data, const double *gx, const double *gy,
+               const int *gmask, int has_missing, double missing, int nz, long f_stride, long g_stride,
+               double *out, double *row_sum, hipStream_t st);
+void fgd_apply_frac(int ndst, FgCsr csr, const double *data, double *out, hipStream_t st);
+void fgd_reduce_sum(const double *v, long n, double *partial, double *result, hipStream_t st);

@@ -1,0 +1,662 @@
+// xgrid_kernels.hip -- exchange-grid search kernels for gfx950 (MI355X).
+//
+// Pipeline for one destination tile against all source tiles:
+//
+//   k_cell_struct      per cell: lat min/max, fix_lon, lon min/max/avg, <=8 vertices, area
+//                      [get_grid_cell_struct semantics, create_xgrid.c:991-1016; get_grid_area :66-88]
+//   k_bin_count/fill   destination cells -> uniform (lat x lon mod 2pi) bins, CSR by bin
+//   k_candidates       per source cell: walk its bins, apply the reference's exact
+//                      bounding-box rejects (create_xgrid.c:1055-1079) -> candidate pairs
+//                      [get_upbound_nxcells_2dx2d semantics], count pass + fill pass
+//   k_clip_quad        one lane per candidate pair, quad x quad fast path: Sutherland-Hodgman
+//                      clip (create_xgrid.c:1266-1341) with the polygon staged in LDS
+//                      [vertex][lane], then area / centroid integrals and the 1e-6 area test
+//   k_clip_general     same for pairs with pole-fixed cells (5..8 vertices) or fast-path overflow
+//   k_count_accepted / k_scatter_xcells
+//                      compaction into the reference's canonical order (source cell ascending,
+//                      destination cell index ascending) via per-source-cell rank
+//   k_cell_sums, k_centroids, k_distances     order-2 centroid pass (conserve_interp.c:216-221,319-358)
+//
+// No MFMA: this is FP64 VALU + irregular gather work.  All decisions that define the
+// exchange-cell set use the reference's expression trees (see geom.hip.h).
+#include "xgrid_device.h"
+#include "geom.hip.h"
+
+// ---------------------------------------------------------------------------------------
+// exclusive scan of int32 counts (3 kernels: block sums, top-level, apply)
+// ---------------------------------------------------------------------------------------
+#define SCAN_THREADS 256
+#define SCAN_ITEMS   8
+#define SCAN_CHUNK   (SCAN_THREADS * SCAN_ITEMS)
+
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// inclusive scan across a 256-thread block; returns this thread's inclusive value and the block total
+__device__ __forceinline__ unsigned block_incl_scan(unsigned v, unsigned *total)
+{
+  __shared__ unsigned wsum[4];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned inc = wave_incl_scan(v, lane);
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { if (k < w) base += wsum[k]; tot += wsum[k]; }
+  __syncthreads();
+  *total = tot;
+  return inc + base;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const int *in, long n, unsigned long long *bsum)
+{
+  long base = (long)blockIdx.x * SCAN_CHUNK;
+  unsigned s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    long idx = base + (long)k * SCAN_THREADS + threadIdx.x;
+    if (idx < n) s += (unsigned)in[idx];
+  }
+  unsigned tot;
+  block_incl_scan(s, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of the block sums in place (64-bit), total -> *total_out
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(unsigned long long *bsum, int nb, unsigned long long *total_out)
+{
+  __shared__ unsigned long long carry;
+  __shared__ unsigned long long wsum[4];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int start = 0; start < nb; start += SCAN_THREADS) {
+    int idx = start + threadIdx.x;
+    unsigned long long v = (idx < nb) ? bsum[idx] : 0ull;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned long long t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned long long base = carry;
+    for (int k = 0; k < w; k++) base += wsum[k];
+    if (idx < nb) bsum[idx] = base + inc - v;
+    __syncthreads();
+    if (threadIdx.x == SCAN_THREADS - 1) carry = base + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+// out[i] = exclusive prefix (32-bit; the host checks the 64-bit total fits)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int *in, long n, const unsigned long long *bsum, int *out)
+{
+  __shared__ unsigned tile[SCAN_CHUNK];
+  long base = (long)blockIdx.x * SCAN_CHUNK;
+  // thread t owns items t*SCAN_ITEMS .. +SCAN_ITEMS-1 of the chunk (blocked arrangement via LDS)
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    int li = k * SCAN_THREADS + threadIdx.x;
+    long idx = base + li;
+    tile[li] = (idx < n) ? (unsigned)in[idx] : 0u;
+  }
+  __syncthreads();
+  unsigned loc[SCAN_ITEMS];
+  unsigned s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { loc[k] = tile[threadIdx.x * SCAN_ITEMS + k]; s += loc[k]; }
+  unsigned tot;
+  unsigned inc = block_incl_scan(s, &tot);
+  unsigned run = (unsigned)bsum[blockIdx.x] + inc - s;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { tile[threadIdx.x * SCAN_ITEMS + k] = run; run += loc[k]; }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    int li = k * SCAN_THREADS + threadIdx.x;
+    long idx = base + li;
+    if (idx < n) out[idx] = (int)tile[li];
+  }
+}
+
+int fgd_exclusive_scan(const int *in, long n, int *out, unsigned long long *bsum_ws,
+                       unsigned long long *total_dev, hipStream_t st)
+{
+  if (n <= 0) { hipMemsetAsync(total_dev, 0, sizeof(unsigned long long), st); return 0; }
+  int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  k_scan_block_sums<<<nb, SCAN_THREADS, 0, st>>>(in, n, bsum_ws);
+  k_scan_top<<<1, SCAN_THREADS, 0, st>>>(bsum_ws, nb, total_dev);
+  k_scan_apply<<<nb, SCAN_THREADS, 0, st>>>(in, n, bsum_ws, out);
+  return 0;
+}
+
+long fgd_scan_ws_elems(long n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1; }
+
+// ---------------------------------------------------------------------------------------
+// per-cell records
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_struct(const FgTile *tiles, int ntiles, int ncells, FgCells c, unsigned *err)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ncells) return;
+  int t = 0;
+  while (t + 1 < ntiles && s >= tiles[t + 1].cell_off) t++;
+  const FgTile T = tiles[t];
+  int loc = s - T.cell_off;
+  int i = loc % T.nx, j = loc / T.nx;
+  int nxp = T.nx + 1;
+  int n0 = j * nxp + i, n1 = n0 + 1, n3 = n0 + nxp, n2 = n3 + 1;
+  double x[G_FIXCAP], y[G_FIXCAP];
+  x[0] = T.lon[n0]; y[0] = T.lat[n0];
+  x[1] = T.lon[n1]; y[1] = T.lat[n1];
+  x[2] = T.lon[n2]; y[2] = T.lat[n2];
+  x[3] = T.lon[n3]; y[3] = T.lat[n3];
+  double lmin = y[0], lmax = y[0];
+#pragma unroll
+  for (int k = 1; k < 4; k++) { if (y[k] < lmin) lmin = y[k]; if (y[k] > lmax) lmax = y[k]; }
+  c.lat_min[s] = lmin; c.lat_max[s] = lmax;
+  int n = d_fix_lon(x, y, 4, G_PI);
+  if (n < 0 || n > G_MAXV) {
+    atomicOr(err, G_ERRBIT_MAXV);
+    c.nv[s] = 0; c.lon_min[s] = 0; c.lon_max[s] = 0; c.lon_avg[s] = 0; c.area[s] = 0;
+    return;
+  }
+  double xmin = x[0], xmax = x[0], xs = 0;
+  for (int k = 1; k < n; k++) { if (x[k] < xmin) xmin = x[k]; if (x[k] > xmax) xmax = x[k]; }
+  for (int k = 0; k < n; k++) xs += x[k];
+  xs /= n;
+  c.lon_min[s] = xmin; c.lon_max[s] = xmax; c.lon_avg[s] = xs;
+  c.nv[s] = n;
+  double *vp = c.verts + (size_t)s * 16;
+  for (int k = 0; k < G_MAXV; k++) {
+    vp[k] = (k < n) ? x[k] : 0.0;
+    vp[8 + k] = (k < n) ? y[k] : 0.0;
+  }
+  c.area[s] = d_poly_area<1>(x, y, n);
+}
+
+// ---------------------------------------------------------------------------------------
+// binning of destination cells
+// ---------------------------------------------------------------------------------------
+// Bin ranges of a bounding box.  Margins of 1e-9 rad make the ranges a superset under
+// the +-2pi shifts of create_xgrid.c:1064-1074.
+__device__ __forceinline__ int4 d_bin_range(double lat_min, double lat_max, double lon_min, double lon_max, FgBins b)
+{
+  const double eps = 1.e-9;
+  int bl0 = (int)floor((lat_min - eps + G_HPI) * b.inv_wlat);
+  int bl1 = (int)floor((lat_max + eps + G_HPI) * b.inv_wlat);
+  bl0 = max(0, min(b.nblat - 1, bl0));
+  bl1 = max(0, min(b.nblat - 1, bl1));
+  long long l0 = (long long)floor((lon_min - eps) * b.inv_wlon);
+  long long l1 = (long long)floor((lon_max + eps) * b.inv_wlon);
+  long long nl = l1 - l0 + 1;
+  int c0;
+  if (nl >= b.nblon) { nl = b.nblon; c0 = 0; }
+  else { c0 = (int)(((l0 % b.nblon) + b.nblon) % b.nblon); }
+  return make_int4(bl0, bl1, c0, (int)nl);
+}
+
+__global__ __launch_bounds__(256) void k_bin_count(int ncells, FgCells c, FgBins b, int4 *cell_bins, int *bin_cnt)
+{
+  int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= ncells) return;
+  if (c.nv[d] == 0) { cell_bins[d] = make_int4(0, -1, 0, 0); return; }
+  int4 r = d_bin_range(c.lat_min[d], c.lat_max[d], c.lon_min[d], c.lon_max[d], b);
+  cell_bins[d] = r;
+  for (int bl = r.x; bl <= r.y; bl++)
+    for (int k = 0; k < r.w; k++) {
+      int col = r.z + k; if (col >= b.nblon) col -= b.nblon;
+      atomicAdd(&bin_cnt[bl * b.nblon + col], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_fill(int ncells, FgBins b, const int4 *cell_bins, const int *bin_start,
+                                                   int *bin_fill, int *bin_cells)
+{
+  int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= ncells) return;
+  int4 r = cell_bins[d];
+  for (int bl = r.x; bl <= r.y; bl++)
+    for (int k = 0; k < r.w; k++) {
+      int col = r.z + k; if (col >= b.nblon) col -= b.nblon;
+      int bin = bl * b.nblon + col;
+      int pos = atomicAdd(&bin_fill[bin], 1);
+      bin_cells[bin_start[bin] + pos] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// candidate pairs
+// ---------------------------------------------------------------------------------------
+// FILL == false: cand_cnt[s] = number of destination cells passing the reference's two
+// bounding-box rejects.  FILL == true: write them at cand_off[s]...
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const double *mask, FgCells D, FgBins b,
+                                                     const int4 *dbins, const int *bin_start, const int *bin_cells,
+                                                     int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsrc) return;
+  int cnt = 0;
+  bool active = S.nv[s] > 0;
+  if (active && mask) active = mask[s] > 0.5;          // MASK_THRESH, create_xgrid.c:1030
+  if (active) {
+    const double lat_in_min = S.lat_min[s], lat_in_max = S.lat_max[s];
+    const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
+    int4 r = d_bin_range(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
+    int wbase = FILL ? cand_off[s] : 0;
+    for (int bl = r.x; bl <= r.y; bl++)
+      for (int k = 0; k < r.w; k++) {
+        int col = r.z + k; if (col >= b.nblon) col -= b.nblon;
+        int bin = bl * b.nblon + col;
+        int e0 = bin_start[bin], e1 = bin_start[bin + 1];
+        for (int e = e0; e < e1; e++) {
+          int d = bin_cells[e];
+          int4 q = dbins[d];
+          // a destination cell sits in several bins: keep it only in the first bin shared
+          // with this source cell (rows: larger of the two first rows; columns: first column of
+          // the source's walk that lies inside the destination's arc)
+          if (bl != max(r.x, q.x)) continue;
+          int off_sd = r.z - q.z; if (off_sd < 0) off_sd += b.nblon;
+          int kstar = 0;
+          if (off_sd >= q.w) { kstar = q.z - r.z; if (kstar < 0) kstar += b.nblon; }
+          if (k != kstar) continue;
+          // create_xgrid.c:1055
+          if (D.lat_min[d] >= lat_in_max || D.lat_max[d] <= lat_in_min) continue;
+          // create_xgrid.c:1062-1079
+          double lon_out_min = D.lon_min[d], lon_out_max = D.lon_max[d];
+          double dx = D.lon_avg[d] - lon_in_avg;
+          if (dx < -G_PI)     { lon_out_min += G_TPI; lon_out_max += G_TPI; }
+          else if (dx > G_PI) { lon_out_min -= G_TPI; lon_out_max -= G_TPI; }
+          if (lon_out_min >= lon_in_max || lon_out_max <= lon_in_min) continue;
+          if (FILL) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = d; }
+          cnt++;
+        }
+      }
+  }
+  if (!FILL) cand_cnt[s] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------
+// clip + area (+ centroid integrals)
+// ---------------------------------------------------------------------------------------
+struct ClipOut { double area, clon, clat; };
+
+// area test and integrals on the clipped polygon held at px/py (stride S); returns area or -1
+template <int ORDER, int S>
+__device__ __forceinline__ void d_finish_pair(const double *px, const double *py, int n_out, double maskv,
+                                              double area_in, double area_out, double lon_in_avg,
+                                              ClipOut *o, unsigned long long *stats)
+{
+  double pa, clon = 0, clat = 0;
+  if (ORDER == 2) d_poly_area_ctr<S>(px, py, n_out, lon_in_avg, &pa, &clon, &clat);
+  else pa = d_poly_area<S>(px, py, n_out);
+  double xarea = pa * maskv;                                   // create_xgrid.c:1083
+  double min_area = (area_in < area_out) ? area_in : area_out; // :1084
+  double ratio = xarea / min_area;
+  if (fabs(ratio - 1.e-6) < 1.e-15) atomicAdd(&stats[FG_STAT_BORDERLINE], 1ull);
+  if (ratio > 1.e-6) { o->area = xarea; o->clon = clon; o->clat = clat; }
+  else o->area = -1.0;
+}
+
+#define CLIP_THREADS 256
+
+// Quad x quad fast path.  LDS: polygon [8][256] double2 (32 KiB) + cutter [4][256] double2 (16 KiB).
+template <int ORDER>
+__global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const int *pair_src, const int *pair_dst,
+                                                            FgCells S, const double *mask, FgCells D,
+                                                            double *tmp_area, double *tmp_clon, double *tmp_clat,
+                                                            int *defer_list, int *defer_cnt,
+                                                            unsigned long long *stats, unsigned *err)
+{
+  __shared__ double2 sh_poly[8][CLIP_THREADS];
+  __shared__ double2 sh_cut[4][CLIP_THREADS];
+  const int tid = threadIdx.x;
+  int p = blockIdx.x * CLIP_THREADS + tid;
+  if (p >= npairs) return;
+  const int s = pair_src[p], d = pair_dst[p];
+  const int n1 = S.nv[s], n2 = D.nv[d];
+  if (n1 > 4 || n2 > 4) { int q = atomicAdd(defer_cnt, 1); defer_list[q] = p; return; }
+
+  const double *sv = S.verts + (size_t)s * 16, *dv = D.verts + (size_t)d * 16;
+  const double lon_in_avg = S.lon_avg[s];
+  double shift = 0.0;
+  {
+    double dx = D.lon_avg[d] - lon_in_avg;           // create_xgrid.c:1064-1074
+    if (dx < -G_PI) shift = G_TPI; else if (dx > G_PI) shift = -G_TPI;
+  }
+  double x1[4], y1[4], x2[4], y2[4];
+  bool wrap = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    x1[k] = sv[k]; y1[k] = sv[8 + k];
+    x2[k] = dv[k]; y2[k] = dv[8 + k];
+    if (shift != 0.0) x2[k] += shift;
+    if (k < n1 && (x1[k] > G_TPI || x1[k] < 0.0)) wrap = true;  // create_xgrid.c:1282
+  }
+  if (wrap) {                                          // :1290
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x1[k] = d_pimod1(x1[k]); x2[k] = d_pimod1(x2[k]); }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    sh_poly[k][tid] = make_double2(x1[k], y1[k]);
+    sh_cut[k][tid] = make_double2(x2[k], y2[k]);
+  }
+  int n_cur = n1;
+  bool overflow = false, parallel = false;
+  double2 e0 = sh_cut[n2 - 1][tid];
+  for (int e = 0; e < n2 && n_cur > 0; e++) {
+    double2 e1 = sh_cut[e][tid];
+    const double x2_0 = e0.x, y2_0 = e0.y, x2_1 = e1.x, y2_1 = e1.y;
+    double2 c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k < n_cur) c[k] = sh_poly[k][tid];
+    double2 lastv = sh_poly[n_cur - 1][tid];
+    double x1_0 = lastv.x, y1_0 = lastv.y;
+    int inside_last = d_inside_edge(x2_0, y2_0, x2_1, y2_1, x1_0, y1_0);
+    int n_new = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (k < n_cur) {
+        double x1_1 = c[k].x, y1_1 = c[k].y;
+        int inside = d_inside_edge(x2_0, y2_0, x2_1, y2_1, x1_1, y1_1);
+        if (inside != inside_last) {
+          double dy1 = y1_1 - y1_0;
+          double dy2 = y2_1 - y2_0;
+          double dx1 = x1_1 - x1_0;
+          double dx2 = x2_1 - x2_0;
+          double ds1 = y1_0 * x1_1 - y1_1 * x1_0;
+          double ds2 = y2_0 * x2_1 - y2_1 * x2_0;
+          double determ = dy2 * dx1 - dy1 * dx2;
+          if (fabs(determ) < 1.0e-30) parallel = true;
+          if (n_new < 8) sh_poly[n_new][tid] = make_double2((dx2 * ds1 - dx1 * ds2) / determ,
+                                                            (dy2 * ds1 - dy1 * ds2) / determ);
+          else overflow = true;
+          n_new++;
+        }
+        if (inside) {
+          if (n_new < 8) sh_poly[n_new][tid] = make_double2(x1_1, y1_1);
+          else overflow = true;
+          n_new++;
+        }
+        x1_0 = x1_1; y1_0 = y1_1; inside_last = inside;
+      }
+    }
+    n_cur = n_new;
+    if (overflow) break;
+    e0 = e1;
+  }
+  if (overflow) { int q = atomicAdd(defer_cnt, 1); defer_list[q] = p; return; }
+  if (parallel) atomicOr(err, G_ERRBIT_PARALLEL);
+  ClipOut o; o.area = -1.0; o.clon = 0; o.clat = 0;
+  if (n_cur > 0) {
+    atomicAdd(&stats[FG_STAT_NONEMPTY], 1ull);
+    const double *px = (const double *)&sh_poly[0][tid];
+    d_finish_pair<ORDER, 2 * CLIP_THREADS>(px, px + 1, n_cur, mask ? mask[s] : 1.0, S.area[s], D.area[d],
+                                            lon_in_avg, &o, stats);
+  }
+  tmp_area[p] = o.area;
+  if (ORDER == 2 && o.area >= 0) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
+}
+
+// General path: up to 8 x 8 vertices, intermediate polygons up to 16.  One wave per block,
+// LDS: two [16][64] double2 ping-pong buffers + cutter [8][64] double2 = 40 KiB.
+#define GEN_THREADS 64
+#define GEN_CAP 16
+template <int ORDER>
+__global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_list, const int *defer_cnt,
+                                                              const int *pair_src, const int *pair_dst,
+                                                              FgCells S, const double *mask, FgCells D,
+                                                              double *tmp_area, double *tmp_clon, double *tmp_clat,
+                                                              unsigned long long *stats, unsigned *err)
+{
+  __shared__ double2 sh_a[GEN_CAP][GEN_THREADS];
+  __shared__ double2 sh_b[GEN_CAP][GEN_THREADS];
+  __shared__ double2 sh_cut[G_MAXV][GEN_THREADS];
+  const int tid = threadIdx.x;
+  const int ndefer = *defer_cnt;
+  for (int q = blockIdx.x * GEN_THREADS + tid; q < ndefer; q += gridDim.x * GEN_THREADS) {
+    const int p = defer_list[q];
+    const int s = pair_src[p], d = pair_dst[p];
+    const int n1 = S.nv[s], n2 = D.nv[d];
+    const double *sv = S.verts + (size_t)s * 16, *dv = D.verts + (size_t)d * 16;
+    const double lon_in_avg = S.lon_avg[s];
+    double shift = 0.0;
+    {
+      double dx = D.lon_avg[d] - lon_in_avg;
+      if (dx < -G_PI) shift = G_TPI; else if (dx > G_PI) shift = -G_TPI;
+    }
+    bool wrap = false;
+    for (int k = 0; k < n1; k++) { double xv = sv[k]; if (xv > G_TPI || xv < 0.0) wrap = true; }
+    for (int k = 0; k < n1; k++) {
+      double xv = sv[k]; if (wrap) xv = d_pimod1(xv);
+      sh_a[k][tid] = make_double2(xv, sv[8 + k]);
+    }
+    for (int k = 0; k < n2; k++) {
+      double xv = dv[k]; if (shift != 0.0) xv += shift; if (wrap) xv = d_pimod1(xv);
+      sh_cut[k][tid] = make_double2(xv, dv[8 + k]);
+    }
+    double2 (*cur)[GEN_THREADS] = sh_a;
+    double2 (*nxt)[GEN_THREADS] = sh_b;
+    int n_cur = n1;
+    bool overflow = false, parallel = false;
+    double2 e0 = sh_cut[n2 - 1][tid];
+    for (int e = 0; e < n2 && n_cur > 0 && !overflow; e++) {
+      double2 e1 = sh_cut[e][tid];
+      const double x2_0 = e0.x, y2_0 = e0.y, x2_1 = e1.x, y2_1 = e1.y;
+      double2 lastv = cur[n_cur - 1][tid];
+      double x1_0 = lastv.x, y1_0 = lastv.y;
+      int inside_last = d_inside_edge(x2_0, y2_0, x2_1, y2_1, x1_0, y1_0);
+      int n_new = 0;
+      for (int k = 0; k < n_cur; k++) {
+        double2 cv = cur[k][tid];
+        double x1_1 = cv.x, y1_1 = cv.y;
+        int inside = d_inside_edge(x2_0, y2_0, x2_1, y2_1, x1_1, y1_1);
+        if (inside != inside_last) {
+          double dy1 = y1_1 - y1_0;
+          double dy2 = y2_1 - y2_0;
+          double dx1 = x1_1 - x1_0;
+          double dx2 = x2_1 - x2_0;
+          double ds1 = y1_0 * x1_1 - y1_1 * x1_0;
+          double ds2 = y2_0 * x2_1 - y2_1 * x2_0;
+          double determ = dy2 * dx1 - dy1 * dx2;
+          if (fabs(determ) < 1.0e-30) parallel = true;
+          if (n_new < GEN_CAP) nxt[n_new][tid] = make_double2((dx2 * ds1 - dx1 * ds2) / determ,
+                                                              (dy2 * ds1 - dy1 * ds2) / determ);
+          else overflow = true;
+          n_new++;
+        }
+        if (inside) {
+          if (n_new < GEN_CAP) nxt[n_new][tid] = make_double2(x1_1, y1_1);
+          else overflow = true;
+          n_new++;
+        }
+        x1_0 = x1_1; y1_0 = y1_1; inside_last = inside;
+      }
+      n_cur = n_new;
+      double2 (*t)[GEN_THREADS] = cur; cur = nxt; nxt = t;
+      e0 = e1;
+    }
+    if (overflow) { atomicOr(err, G_ERRBIT_OVERFLOW); tmp_area[p] = -1.0; continue; }
+    if (parallel) atomicOr(err, G_ERRBIT_PARALLEL);
+    ClipOut o; o.area = -1.0; o.clon = 0; o.clat = 0;
+    if (n_cur > 0) {
+      atomicAdd(&stats[FG_STAT_NONEMPTY], 1ull);
+      const double *px = (const double *)&cur[0][tid];
+      d_finish_pair<ORDER, 2 * GEN_THREADS>(px, px + 1, n_cur, mask ? mask[s] : 1.0, S.area[s], D.area[d],
+                                            lon_in_avg, &o, stats);
+    }
+    tmp_area[p] = o.area;
+    if (ORDER == 2 && o.area >= 0) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// compaction into canonical order
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt,
+                                                         const double *tmp_area, int *nacc)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsrc) return;
+  int o = cand_off[s], c = cand_cnt[s], a = 0;
+  for (int k = 0; k < c; k++) a += (tmp_area[o + k] >= 0.0) ? 1 : 0;
+  nacc[s] = a;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *pair_src, const int *pair_dst,
+                                                         const int *cand_off, const int *cand_cnt, const int *xoff,
+                                                         const double *tmp_area, const double *tmp_clon, const double *tmp_clat,
+                                                         int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2)
+{
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  double a = tmp_area[p];
+  if (!(a >= 0.0)) return;
+  int s = pair_src[p], d = pair_dst[p];
+  int o = cand_off[s], c = cand_cnt[s], rank = 0;
+  for (int k = 0; k < c; k++)                       // destination index ascending == the reference's ij loop
+    rank += (tmp_area[o + k] >= 0.0 && pair_dst[o + k] < d) ? 1 : 0;
+  int pos = xoff[s] + rank;
+  x_src[pos] = s; x_dst[pos] = d; x_area[pos] = a;
+  if (ORDER == 2) { x_c1[pos] = tmp_clon[p]; x_c2[pos] = tmp_clat[p]; }
+}
+
+// ---------------------------------------------------------------------------------------
+// order-2 centroid pass
+// ---------------------------------------------------------------------------------------
+// sums[0..2][nsrc] over this plan's exchange cells, in exchange-cell order (conserve_interp.c:216-221)
+__global__ __launch_bounds__(256) void k_cell_sums(int nsrc, const int *xoff, const int *nacc, const double *x_area,
+                                                    const double *x_c1, const double *x_c2, double *sums)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsrc) return;
+  double a = 0, l = 0, t = 0;
+  int o = xoff[s], c = nacc[s];
+  for (int k = 0; k < c; k++) { a += x_area[o + k]; l += x_c1[o + k]; t += x_c2[o + k]; }
+  sums[s] = a; sums[nsrc + s] = l; sums[2 * (size_t)nsrc + s] = t;
+}
+
+// cen[0][s], cen[1][s] = centroid lon/lat of source cell s (conserve_interp.c:327-348)
+__global__ __launch_bounds__(256) void k_centroids(int nsrc, FgCells S, const double *sums, double *cen)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsrc) return;
+  double a = sums[s], cl = 0, ct = 0;
+  if (a > 0) {
+    double ca = S.area[s];
+    if (fabs(a - ca) / ca < 1.e-3) {
+      cl = sums[nsrc + s] / a;
+      ct = sums[2 * (size_t)nsrc + s] / a;
+    } else {
+      double x[G_MAXV], y[G_MAXV];
+      int n = S.nv[s];
+      const double *vp = S.verts + (size_t)s * 16;
+      for (int k = 0; k < G_MAXV; k++) { x[k] = vp[k]; y[k] = vp[8 + k]; }
+      cl = d_poly_ctrlon<1>(x, y, n, S.lon_avg[s]) / ca;
+      ct = d_poly_ctrlat<1>(x, y, n) / ca;
+    }
+  }
+  cen[s] = cl; cen[nsrc + s] = ct;
+}
+
+// di = clon/area - cen_lon, dj = clat/area - cen_lat (conserve_interp.c:256-257,355-356)
+__global__ __launch_bounds__(256) void k_distances(long nx, int nsrc, const int *x_src, const double *x_area,
+                                                    const double *cen, double *x_c1, double *x_c2)
+{
+  long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nx) return;
+  int s = x_src[n];
+  double a = x_area[n];
+  double di = x_c1[n] / a, dj = x_c2[n] / a;
+  di -= cen[s]; dj -= cen[nsrc + s];
+  x_c1[n] = di; x_c2[n] = dj;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------------------
+static inline int nblk(long n, int t) { return (int)((n + t - 1) / t); }
+
+void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c, unsigned *err, hipStream_t st)
+{
+  if (ncells > 0) k_cell_struct<<<nblk(ncells, 256), 256, 0, st>>>(tiles_dev, ntiles, ncells, c, err);
+}
+
+void fgd_bin_count(int ncells, FgCells c, FgBins b, int4 *cell_bins, int *bin_cnt, hipStream_t st)
+{
+  if (ncells > 0) k_bin_count<<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, cell_bins, bin_cnt);
+}
+
+void fgd_bin_fill(int ncells, FgBins b, const int4 *cell_bins, const int *bin_start, int *bin_fill, int *bin_cells, hipStream_t st)
+{
+  if (ncells > 0) k_bin_fill<<<nblk(ncells, 256), 256, 0, st>>>(ncells, b, cell_bins, bin_start, bin_fill, bin_cells);
+}
+
+void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgCells D, FgBins b, const int4 *dbins,
+                    const int *bin_start, const int *bin_cells, int *cand_cnt, const int *cand_off,
+                    int *pair_src, int *pair_dst, hipStream_t st)
+{
+  if (nsrc <= 0) return;
+  if (fill) k_candidates<true><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, mask, D, b, dbins, bin_start, bin_cells, cand_cnt, cand_off, pair_src, pair_dst);
+  else      k_candidates<false><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, mask, D, b, dbins, bin_start, bin_cells, cand_cnt, cand_off, pair_src, pair_dst);
+}
+
+void fgd_clip(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
+              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+              unsigned long long *stats, unsigned *err, hipStream_t st)
+{
+  if (npairs <= 0) return;
+  if (order == 2) {
+    k_clip_quad<2><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
+    k_clip_general<2><<<1024, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
+  } else {
+    k_clip_quad<1><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
+    k_clip_general<1><<<1024, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
+  }
+}
+
+void fgd_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt, const double *tmp_area, int *nacc, hipStream_t st)
+{
+  if (nsrc > 0) k_count_accepted<<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, cand_off, cand_cnt, tmp_area, nacc);
+}
+
+void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
+                        const int *cand_cnt, const int *xoff, const double *tmp_area, const double *tmp_clon,
+                        const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
+                        hipStream_t st)
+{
+  if (npairs <= 0) return;
+  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, cand_cnt, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2);
+  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, cand_cnt, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2);
+}
+
+void fgd_cell_sums(int nsrc, const int *xoff, const int *nacc, const double *x_area, const double *x_c1,
+                   const double *x_c2, double *sums, hipStream_t st)
+{
+  if (nsrc > 0) k_cell_sums<<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, xoff, nacc, x_area, x_c1, x_c2, sums);
+}
+
+void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st)
+{
+  if (nsrc > 0) k_centroids<<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, sums, cen);
+}
+
+void fgd_distances(long nx, int nsrc, const int *x_src, const double *x_area, const double *cen, double *x_c1,
+                   double *x_c2, hipStream_t st)
+{
+  if (nx > 0) k_distances<<<nblk(nx, 256), 256, 0, st>>>(nx, nsrc, x_src, x_area, cen, x_c1, x_c2);
+}

@@ -1,0 +1,219 @@
+/*
+ * fregrid_hip.h -- C ABI of libfregrid_hip.so, the MI355X (gfx950) implementation of
+ * FRE-NCtools' conservative-regrid hot path.  Plain C: pointers, ints and doubles only.
+ *
+ * Three groups of entry points:
+ *
+ *  (B1) drop-in replacements for libfrencutils symbols -- identical names, argument
+ *       lists, ownership and fatal-error behaviour as the reference, host pointers in/out:
+ *         get_maxxgrid               tools/libfrencutils/create_xgrid.c:45
+ *         get_grid_area              tools/libfrencutils/create_xgrid.c:66    (create_xgrid.h:41)
+ *         create_xgrid_2dx2d_order1  tools/libfrencutils/create_xgrid.c:621   (create_xgrid.h:65)
+ *         create_xgrid_2dx2d_order2  tools/libfrencutils/create_xgrid.c:893   (create_xgrid.h:69)
+ *         conserve_interp            tools/libfrencutils/interp.c:262         (interp.h)
+ *         + trailing-underscore Fortran aliases (create_xgrid.c:60,608,881)
+ *
+ *  (B2) device-resident "plan" API that replaces the pair
+ *         setup_conserve_interp      tools/fregrid/conserve_interp.c:42   (compute branch :127-358)
+ *         do_scalar_conserve_interp  tools/fregrid/conserve_interp.c:507
+ *       so that exchange cells never leave HBM between the search and the sweep.
+ *       INTEGRATION.md shows the conserve_interp_hip.c a maintainer links in place of
+ *       conserve_interp.o (the same swap the reference's own fregrid_gpu makes,
+ *       tools/fregrid_gpu/Makefile.am:28-41).
+ *
+ *  (G)  host grid generators used to synthesise inputs without make_hgrid files.
+ *
+ * Error handling: fg_* functions return 0 (or a count) on success and a negative
+ * FG_ERR_* code on failure; fg_last_error() returns the message.  The B1 symbols
+ * behave like the reference: fatal -> "FATAL Error: <msg>" on stderr and exit(1)
+ * (tools/libfrencutils/mosaic_util.c:57-65).
+ *
+ * All longitudes/latitudes are FP64 radians, cell corners row-major [j*(nx+1)+i].
+ */
+#ifndef FREGRID_HIP_H_
+#define FREGRID_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FG_ERR_ARG        (-1)   /* bad argument                                              */
+#define FG_ERR_HIP        (-2)   /* HIP runtime failure (no device, out of memory, ...)        */
+#define FG_ERR_MAXV       (-3)   /* a cell has more than MAX_V=8 vertices after fix_lon (create_xgrid.c:1007) */
+#define FG_ERR_PARALLEL   (-4)   /* clip hit parallel edges, |determ| < 1e-30 (create_xgrid.c:1314) */
+#define FG_ERR_CAPACITY   (-5)   /* caller's output arrays too small (reference: MAXXGRID fatal, :1087) */
+#define FG_ERR_STATE      (-6)   /* call made in the wrong plan state                          */
+
+/* option bits, same values as tools/libfrencutils/globals.h:46-61 where they exist */
+#define FG_CONSERVE_ORDER1 1
+#define FG_CONSERVE_ORDER2 2
+
+/* ---------------------------------------------------------------- (B1) ---- */
+int  get_maxxgrid(void);
+void get_grid_area(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
+int  create_xgrid_2dx2d_order1(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
+                               const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,
+                               const double *mask_in, int *i_in, int *j_in, int *i_out, int *j_out, double *xgrid_area);
+int  create_xgrid_2dx2d_order2(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
+                               const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,
+                               const double *mask_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                               double *xgrid_area, double *xgrid_clon, double *xgrid_clat);
+void conserve_interp(int nx_src, int ny_src, int nx_dst, int ny_dst, const double *x_src,
+                     const double *y_src, const double *x_dst, const double *y_dst,
+                     const double *mask_src, const double *data_src, double *data_dst);
+/* Fortran aliases */
+int  get_maxxgrid_(void);
+void get_grid_area_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
+int  create_xgrid_2dx2d_order1_(const int *, const int *, const int *, const int *, const double *, const double *,
+                                const double *, const double *, const double *, int *, int *, int *, int *, double *);
+int  create_xgrid_2dx2d_order2_(const int *, const int *, const int *, const int *, const double *, const double *,
+                                const double *, const double *, const double *, int *, int *, int *, int *,
+                                double *, double *, double *);
+
+/* ---------------------------------------------------------------- (B2) ---- */
+typedef struct fg_plan fg_plan;
+
+/* last error message of the calling thread ("" if none) */
+const char *fg_last_error(void);
+
+/* number of HIP devices visible; <0 on failure.  Does not create a context. */
+int fg_device_count(void);
+
+/*
+ * Exchange-grid search between ntiles_in source tiles and ONE destination tile
+ * (or the latitude band of it owned by this rank: pass the band's corner arrays,
+ * exactly as the reference passes grid_out[n].lonc/latc of the compute domain,
+ * conserve_interp.c:187-199).  Host corner arrays are copied to the device.
+ *   order      FG_CONSERVE_ORDER1 | FG_CONSERVE_ORDER2
+ *   mask_in    per-tile source masks (NULL or mask_in[m]==NULL => all ones, conserve_interp.c:160-161)
+ *   device     HIP device ordinal
+ * On success *plan_out owns the device-resident exchange cells in the reference's
+ * canonical order (source tile, j_in, i_in, then destination cell index ascending
+ * == create_xgrid_2dx2d_* with one thread, tiles concatenated as conserve_interp.c:234-316).
+ * Returns nxgrid (>=0) or FG_ERR_*.
+ */
+long fg_plan_create(int order, int ntiles_in, const int *nx_in, const int *ny_in,
+                    const double *const *lon_in, const double *const *lat_in,
+                    const double *const *mask_in,
+                    int nx_out, int ny_out, const double *lon_out, const double *lat_out,
+                    int device, fg_plan **plan_out);
+/*
+ * Same search with every grid pointer already a DEVICE pointer (inputs resident in HBM; this
+ * is what bench.py times).  mean_dlat/mean_dlon: typical destination cell extent in radians
+ * used to size the search bins (<= 0: derived from a strided sample copied back to the host).
+ * use_caller_stream != 0: all work is queued on `stream` (a hipStream_t, e.g. PyTorch's
+ * current stream; NULL = the legacy default stream) instead of a private stream.
+ */
+long fg_plan_create_dev(int order, int ntiles_in, const int *nx_in, const int *ny_in,
+                        const double *const *d_lon_in, const double *const *d_lat_in,
+                        const double *const *d_mask_in,
+                        int nx_out, int ny_out, const double *d_lon_out, const double *d_lat_out,
+                        double mean_dlat, double mean_dlon, int device, void *stream,
+                        int use_caller_stream, fg_plan **plan_out);
+/* A plan without a search; exchange cells are supplied by fg_plan_set_xgrid. */
+int fg_plan_create_empty(int order, int ntiles_in, const int *nx_in, const int *ny_in,
+                         int nx_out, int ny_out, int device, fg_plan **plan_out);
+void fg_plan_destroy(fg_plan *plan);
+/* queue all further work of the plan on the caller's stream (hipStream_t) */
+int fg_plan_set_stream(fg_plan *plan, void *stream);
+/* return the cached device blocks of destroyed plans to the HIP runtime */
+void fg_pool_release(void);
+
+long fg_plan_nxgrid(const fg_plan *plan);
+long fg_plan_ncells_in(const fg_plan *plan);      /* sum over source tiles of nx*ny */
+
+/*
+ * Order 2 only.  Device pointer to the per-source-cell partial sums
+ * [3][ncells_in] = {sum xarea, sum clon, sum clat} over this plan's exchange cells
+ * (conserve_interp.c:216-221).  With several destination tiles or several ranks the
+ * caller adds these arrays up (one RCCL all-reduce over xGMI) and hands the total
+ * to fg_plan_finalize.
+ */
+double *fg_plan_cell_sums_dev(fg_plan *plan);
+/* copy those sums into a caller-owned DEVICE buffer of 3*ncells_in doubles (e.g. a torch tensor) */
+int fg_plan_copy_cell_sums(fg_plan *plan, double *dst_dev);
+
+/*
+ * Turn (clon, clat) into distances from the source-cell centroid
+ * (conserve_interp.c:256-257,319-358) and build the destination-row (CSR) layout
+ * used by the sweep.  total_cell_sums_dev: device pointer [3][ncells_in] with the
+ * sums over ALL destination tiles/ranks, or NULL to use this plan's own sums.
+ * Order 1 plans only build the CSR layout.
+ */
+int fg_plan_finalize(fg_plan *plan, const double *total_cell_sums_dev);
+
+/*
+ * Copy the exchange cells to host arrays of length fg_plan_nxgrid().  Any pointer
+ * may be NULL.  Before fg_plan_finalize: c1/c2 receive the un-normalised xgrid_clon/
+ * xgrid_clat of create_xgrid_2dx2d_order2; after it: di_in/dj_in of Interp_config
+ * (globals.h:144-158).
+ */
+int fg_plan_get_xgrid(const fg_plan *plan, int *t_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                      double *area, double *c1, double *c2);
+
+/* per-cell records (get_grid_cell_struct semantics, create_xgrid.c:991-1016) of the source
+ * cells (which = 0, tiles concatenated) or destination cells (which = 1).  Host arrays, any
+ * may be NULL; vlon/vlat are [ncells][8] (vertices after fix_lon, unused slots 0). */
+int fg_plan_get_cell_struct(const fg_plan *plan, int which, double *lat_min, double *lat_max, double *lon_min,
+                            double *lon_max, double *lon_avg, int *nvert, double *vlon, double *vlat);
+
+/* cell areas computed during the search (get_grid_area semantics): source cells
+ * concatenated over tiles / destination cells.  Host arrays, may be NULL. */
+int fg_plan_get_cell_area(const fg_plan *plan, double *area_in, double *area_out);
+
+/*
+ * Replace the plan's exchange cells by caller-provided ones (the READ branch of
+ * setup_conserve_interp, conserve_interp.c:62-126, after the remap file has been
+ * parsed on the host; also used by tests to sweep with the oracle's weights).
+ * di_in/dj_in are final distances (order 2) or NULL (order 1).  The plan is left
+ * finalized.  Returns 0 or FG_ERR_*.
+ */
+int fg_plan_set_xgrid(fg_plan *plan, long nxgrid, const int *t_in, const int *i_in, const int *j_in,
+                      const int *i_out, const int *j_out, const double *area,
+                      const double *di_in, const double *dj_in);
+
+/*
+ * The sweep: do_scalar_conserve_interp for one destination tile, plain branch
+ * (no weight field / cell_measures / cell_methods=sum / monotonic / target_grid),
+ * conserve_interp.c:561-616 (order 1), :743-813 (order 2), :815-839.
+ * All data pointers are DEVICE pointers:
+ *   data     source field [nz][F]: one level holds the tiles back to back, each tile
+ *            [ny][nx] (order 1) or [ny+2][nx+2] with a 1-cell halo (order 2, the layout
+ *            fregrid_util.c:2137-2145 builds per tile); F = sum over tiles of that size
+ *   grad_x, grad_y   [nz][ncells_in] (tiles back to back, no halo), order 2 only
+ *   grad_mask        int [ncells_in], order 2 with has_missing only (else NULL)
+ *   out      [nz][ny_out][nx_out]
+ *   gsum_out host pointer or NULL: sum of out*area before normalisation (:815-819)
+ * has_missing requires nz == 1 (:544).  Returns 0 or FG_ERR_*.
+ */
+int fg_plan_apply(fg_plan *plan, const double *data, const double *grad_x, const double *grad_y,
+                  const int *grad_mask, int has_missing, double missing, int nz,
+                  double *out, double *gsum_out);
+
+/* HIP stream the plan launches on (hipStream_t as void*), for event timing. */
+void *fg_plan_stream(fg_plan *plan);
+/* wait for everything queued on the plan's stream */
+int fg_plan_sync(fg_plan *plan);
+
+/* per-phase statistics of the last search (counts), for DESIGN.md/bench reporting:
+ * stats[0]=candidate pairs after the bounding-box tests, [1]=pairs with a non-empty clip,
+ * [2]=nxgrid, [3]=pairs whose area ratio is within 1e-9 (relative) of the 1e-6 threshold,
+ * [4]=bins, [5]=bin entries.  n = capacity of stats. */
+int fg_plan_stats(const fg_plan *plan, long *stats, int n);
+
+/* ---------------------------------------------------------------- (G) ----- */
+/* Equal-distance gnomonic cubed sphere ("gnomonic_ed"), C<ni>: cell corners of the six
+ * tiles, lonc/latc[6*(ni+1)*(ni+1)] radians.  shift_fac as make_hgrid (default 18).
+ * via_degrees != 0 reproduces the radians->degrees->radians round trip of the grid file. */
+int fg_gnomonic_ed_corners(int ni, double shift_fac, int via_degrees, double *lonc, double *latc);
+/* Regular lat-lon grid of get_output_grid_by_size (degrees in, radians out),
+ * lonc/latc[(nlat+1)*(nlon+1)]. */
+int fg_latlon_corners(int nlon, int nlat, double lonbegin, double lonend, double latbegin,
+                      double latend, int center_y, double *lonc, double *latc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FREGRID_HIP_H_ */

@@ -1,0 +1,233 @@
+"""ctypes access to the CPU checkers used by the tests (never by the product):
+
+* ``oracle/liboracle.so``       our clean-room C restatement (oracle/xgrid_oracle.c)
+* ``oracle/_ref/libfrenc_ref.so`` the reference's own sources compiled in place (oracle/Makefile);
+  present in the build container and -- as a prebuilt .so -- on the GPU box.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+lp = C.POINTER(C.c_long)
+
+
+def _dp(a):
+    return a.ctypes.data_as(dp) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(ip) if a is not None else None
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+_ORACLE = None
+_REF = None
+
+
+def oracle():
+    global _ORACLE
+    if _ORACLE is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(path)
+        L.orc_fix_lon.argtypes = [dp, dp, C.c_int, C.c_double]
+        L.orc_fix_lon.restype = C.c_int
+        L.orc_poly_area.argtypes = [dp, dp, C.c_int]
+        L.orc_poly_area.restype = C.c_double
+        L.orc_poly_ctrlon.argtypes = [dp, dp, C.c_int, C.c_double]
+        L.orc_poly_ctrlon.restype = C.c_double
+        L.orc_poly_ctrlat.argtypes = [dp, dp, C.c_int]
+        L.orc_poly_ctrlat.restype = C.c_double
+        L.orc_clip_2dx2d.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, dp]
+        L.orc_clip_2dx2d.restype = C.c_int
+        L.orc_get_grid_area.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+        L.orc_get_grid_area.restype = None
+        L.orc_create_xgrid_2dx2d_rows.argtypes = [C.c_int] * 5 + [dp] * 5 + [C.c_int, C.c_int, C.c_long] + [ip] * 4 + [dp] * 3
+        L.orc_create_xgrid_2dx2d_rows.restype = C.c_long
+        L.orc_get_grid_cell_struct.argtypes = [C.c_int, C.c_int, dp, dp] + [dp] * 5 + [ip] + [dp] * 3
+        L.orc_get_grid_cell_struct.restype = C.c_int
+        dpp = C.POINTER(dp)
+        ipp = C.POINTER(ip)
+        L.orc_setup_conserve_interp.argtypes = [C.c_int, C.c_int, ip, ip, dpp, dpp, dpp, C.c_int, ip, ip, dpp, dpp,
+                                                C.c_long, lp] + [ip] * 5 + [dp] * 3
+        L.orc_setup_conserve_interp.restype = C.c_long
+        L.orc_do_scalar_conserve_interp.argtypes = [C.c_int, C.c_long] + [ip] * 5 + [dp] * 3 + [C.c_int, ip, ip,
+                                                    dpp, dpp, dpp, ipp, C.c_int, C.c_double, C.c_int, C.c_int,
+                                                    C.c_int, dp, dp]
+        L.orc_do_scalar_conserve_interp.restype = C.c_int
+        L.orc_gsum_in.argtypes = [C.c_int, C.c_int, ip, ip, dpp, dpp, C.c_int, C.c_double, C.c_int]
+        L.orc_gsum_in.restype = C.c_double
+        _ORACLE = L
+    return _ORACLE
+
+
+def ref_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libfrenc_ref.so"))
+
+
+def ref():
+    """The compiled reference (unmodified sources).  None if it has not been built."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libfrenc_ref.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        cip = C.POINTER(C.c_int)
+        L.fix_lon.argtypes = [dp, dp, C.c_int, C.c_double]
+        L.fix_lon.restype = C.c_int
+        L.poly_area.argtypes = [dp, dp, C.c_int]
+        L.poly_area.restype = C.c_double
+        L.poly_ctrlon.argtypes = [dp, dp, C.c_int, C.c_double]
+        L.poly_ctrlon.restype = C.c_double
+        L.poly_ctrlat.argtypes = [dp, dp, C.c_int]
+        L.poly_ctrlat.restype = C.c_double
+        L.clip_2dx2d.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, dp]
+        L.clip_2dx2d.restype = C.c_int
+        L.get_grid_area.argtypes = [cip, cip, dp, dp, dp]
+        L.get_grid_area.restype = None
+        L.create_xgrid_2dx2d_order1.argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp]
+        L.create_xgrid_2dx2d_order1.restype = C.c_int
+        L.create_xgrid_2dx2d_order2.argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp] * 3
+        L.create_xgrid_2dx2d_order2.restype = C.c_int
+        L.conserve_interp.argtypes = [C.c_int] * 4 + [dp] * 7
+        L.conserve_interp.restype = None
+        _REF = L
+    return _REF
+
+
+# ------------------------------------------------------------------------------ wrappers
+def orc_create_xgrid(order, nx1, ny1, nx2, ny2, lon_in, lat_in, lon_out, lat_out, mask=None,
+                     j1_beg=0, j1_end=None, capacity=None):
+    L = oracle()
+    lon_in, lat_in, lon_out, lat_out = f64(lon_in).ravel(), f64(lat_in).ravel(), f64(lon_out).ravel(), f64(lat_out).ravel()
+    mask = f64(np.ones(nx1 * ny1) if mask is None else mask).ravel()
+    cap = capacity or 8 * (nx1 * ny1 + nx2 * ny2) + 1024
+    ii, ji, io, jo = (np.empty(cap, dtype=np.int32) for _ in range(4))
+    a = np.empty(cap)
+    cl = np.empty(cap) if order == 2 else None
+    ct = np.empty(cap) if order == 2 else None
+    n = L.orc_create_xgrid_2dx2d_rows(order, nx1, ny1, nx2, ny2, _dp(lon_in), _dp(lat_in), _dp(lon_out), _dp(lat_out),
+                                      _dp(mask), j1_beg, ny1 if j1_end is None else j1_end, cap,
+                                      _ip(ii), _ip(ji), _ip(io), _ip(jo), _dp(a), _dp(cl), _dp(ct))
+    if n < 0:
+        raise RuntimeError(f"oracle create_xgrid failed: {n}")
+    out = dict(n=int(n), i_in=ii[:n].copy(), j_in=ji[:n].copy(), i_out=io[:n].copy(), j_out=jo[:n].copy(), area=a[:n].copy())
+    if order == 2:
+        out["clon"], out["clat"] = cl[:n].copy(), ct[:n].copy()
+    return out
+
+
+def ref_create_xgrid(order, nx1, ny1, nx2, ny2, lon_in, lat_in, lon_out, lat_out, mask=None):
+    L = ref()
+    lon_in, lat_in, lon_out, lat_out = f64(lon_in).ravel(), f64(lat_in).ravel(), f64(lon_out).ravel(), f64(lat_out).ravel()
+    mask = f64(np.ones(nx1 * ny1) if mask is None else mask).ravel()
+    cap = 5000000        # MAXXGRID of the serial build: the reference aborts (exit) beyond it
+    ii, ji, io, jo = (np.empty(cap, dtype=np.int32) for _ in range(4))
+    a = np.empty(cap)
+    args = [C.byref(C.c_int(nx1)), C.byref(C.c_int(ny1)), C.byref(C.c_int(nx2)), C.byref(C.c_int(ny2)),
+            _dp(lon_in), _dp(lat_in), _dp(lon_out), _dp(lat_out), _dp(mask), _ip(ii), _ip(ji), _ip(io), _ip(jo), _dp(a)]
+    if order == 1:
+        n = L.create_xgrid_2dx2d_order1(*args)
+        return dict(n=n, i_in=ii[:n].copy(), j_in=ji[:n].copy(), i_out=io[:n].copy(), j_out=jo[:n].copy(), area=a[:n].copy())
+    cl, ct = np.empty(cap), np.empty(cap)
+    n = L.create_xgrid_2dx2d_order2(*args, _dp(cl), _dp(ct))
+    return dict(n=n, i_in=ii[:n].copy(), j_in=ji[:n].copy(), i_out=io[:n].copy(), j_out=jo[:n].copy(), area=a[:n].copy(),
+                clon=cl[:n].copy(), clat=ct[:n].copy())
+
+
+def orc_get_grid_area(nx, ny, lon, lat):
+    lon, lat = f64(lon).ravel(), f64(lat).ravel()
+    a = np.empty(nx * ny)
+    oracle().orc_get_grid_area(nx, ny, _dp(lon), _dp(lat), _dp(a))
+    return a
+
+
+def ref_get_grid_area(nx, ny, lon, lat):
+    lon, lat = f64(lon).ravel(), f64(lat).ravel()
+    a = np.empty(nx * ny)
+    ref().get_grid_area(C.byref(C.c_int(nx)), C.byref(C.c_int(ny)), _dp(lon), _dp(lat), _dp(a))
+    return a
+
+
+def orc_cell_struct(nx, ny, lon, lat):
+    lon, lat = f64(lon).ravel(), f64(lat).ravel()
+    n = nx * ny
+    d = {k: np.empty(n) for k in ("lat_min", "lat_max", "lon_min", "lon_max", "lon_avg", "area")}
+    nv = np.empty(n, dtype=np.int32)
+    vlon, vlat = np.empty((n, 8)), np.empty((n, 8))
+    rc = oracle().orc_get_grid_cell_struct(nx, ny, _dp(lon), _dp(lat), _dp(d["lat_min"]), _dp(d["lat_max"]),
+                                           _dp(d["lon_min"]), _dp(d["lon_max"]), _dp(d["lon_avg"]), _ip(nv),
+                                           _dp(vlon), _dp(vlat), _dp(d["area"]))
+    assert rc == 0
+    d.update(nvert=nv, vlon=vlon, vlat=vlat)
+    return d
+
+
+def _ptr_array(arrs, typ=dp):
+    return (typ * len(arrs))(*[a.ctypes.data_as(typ) for a in arrs])
+
+
+def orc_setup(order, grids_in, grids_out, capacity=None):
+    """grids_*: lists of (nx, ny, lon, lat).  Returns dict of concatenated exchange cells + xoff."""
+    L = oracle()
+    nt, no = len(grids_in), len(grids_out)
+    lon_in = [f64(g[2]).ravel() for g in grids_in]
+    lat_in = [f64(g[3]).ravel() for g in grids_in]
+    lon_out = [f64(g[2]).ravel() for g in grids_out]
+    lat_out = [f64(g[3]).ravel() for g in grids_out]
+    ca = [orc_get_grid_area(g[0], g[1], g[2], g[3]) for g in grids_in]
+    nx_in = np.array([g[0] for g in grids_in], dtype=np.int32)
+    ny_in = np.array([g[1] for g in grids_in], dtype=np.int32)
+    nx_out = np.array([g[0] for g in grids_out], dtype=np.int32)
+    ny_out = np.array([g[1] for g in grids_out], dtype=np.int32)
+    cap = capacity or 4 * (int(np.sum(nx_in * ny_in)) + int(np.sum(nx_out * ny_out))) * no + 1024
+    xoff = np.zeros(no + 1, dtype=np.int64)
+    t, ii, ji, io, jo = (np.empty(cap, dtype=np.int32) for _ in range(5))
+    a, di, dj = np.empty(cap), np.empty(cap), np.empty(cap)
+    n = L.orc_setup_conserve_interp(order, nt, _ip(nx_in), _ip(ny_in), _ptr_array(lon_in), _ptr_array(lat_in),
+                                    _ptr_array(ca), no, _ip(nx_out), _ip(ny_out), _ptr_array(lon_out),
+                                    _ptr_array(lat_out), cap, xoff.ctypes.data_as(lp),
+                                    _ip(t), _ip(ii), _ip(ji), _ip(io), _ip(jo), _dp(a), _dp(di), _dp(dj))
+    if n < 0:
+        raise RuntimeError(f"oracle setup failed: {n}")
+    out = dict(n=int(n), xoff=xoff, t_in=t[:n].copy(), i_in=ii[:n].copy(), j_in=ji[:n].copy(), i_out=io[:n].copy(),
+               j_out=jo[:n].copy(), area=a[:n].copy(), cell_area_in=ca)
+    if order == 2:
+        out["di"], out["dj"] = di[:n].copy(), dj[:n].copy()
+    return out
+
+
+def orc_apply(order, x, nx_in, ny_in, data, grad_x, grad_y, grad_mask, has_missing, missing, nx2, ny2, nz):
+    """x: dict with t_in,i_in,j_in,i_out,j_out,area(,di,dj) for ONE destination tile; data etc.: per-tile lists."""
+    L = oracle()
+    n = len(x["area"])
+    nxi = np.asarray(nx_in, dtype=np.int32)
+    nyi = np.asarray(ny_in, dtype=np.int32)
+    data = [f64(d).ravel() for d in data]
+    gx = [f64(g).ravel() for g in grad_x] if grad_x is not None else None
+    gy = [f64(g).ravel() for g in grad_y] if grad_y is not None else None
+    gm = [np.ascontiguousarray(g, dtype=np.int32).ravel() for g in grad_mask] if grad_mask is not None else None
+    out = np.empty(nz * nx2 * ny2)
+    gs = C.c_double(0)
+    ints = [np.ascontiguousarray(x[k], dtype=np.int32) for k in ("t_in", "i_in", "j_in", "i_out", "j_out")]
+    area = f64(x["area"])
+    di = f64(x["di"]) if order == 2 else None
+    dj = f64(x["dj"]) if order == 2 else None
+    rc = L.orc_do_scalar_conserve_interp(order, n, *[_ip(v) for v in ints], _dp(area), _dp(di), _dp(dj),
+                                         len(data), _ip(nxi), _ip(nyi), _ptr_array(data),
+                                         _ptr_array(gx) if gx else None, _ptr_array(gy) if gy else None,
+                                         _ptr_array(gm, ip) if gm else None,
+                                         1 if has_missing else 0, float(missing), nx2, ny2, nz, _dp(out), C.byref(gs))
+    assert rc == 0
+    return out, gs.value
