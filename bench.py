@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- conservative-regrid hot path on MI355X: exchange-cells/s (+ remapped-points/s).
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on; fits one GPU):
+  C384 cubed sphere (6 tiles, gnomonic_ed) -> 1440x720 regular lat-lon (0.25 deg), conservative_order2.
+
+One "step" = one full weight generation for the job: exchange-grid search for all 6 source tiles
+against this rank's latitude band of the target + the order-2 centroid pass + the destination-row
+(CSR) build.  With N > 1 ranks the target rows are split into N bands (the reference's
+fregrid_parallel decomposition, fregrid_util.c:592-597); the only collective is the all-reduce of the
+per-source-cell (area, clon, clat) sums (RCCL), conserve_interp.c:203-221.  Fixed total work => "strong".
+
+value = steps * (sum over ranks of nxgrid) / max-over-ranks wall time, inputs resident in HBM.
+A second timed region measures the sweep (do_scalar_conserve_interp) on nz levels: remapped-points/s.
+
+Run: python bench.py --gpus 1 --steps 20 --warmup 3
+     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def band_rows(nlat, nranks, r):
+    """Contiguous latitude bands, sizes as mpp_compute_extent (mpp_domain.c:101-158): nearly equal."""
+    base, extra = divmod(nlat, nranks)
+    sizes = [base + (1 if k < extra else 0) for k in range(nranks)]
+    j0 = sum(sizes[:r])
+    return j0, j0 + sizes[r]
+
+
+def synth_fields(fg, lon, lat, ni, nz):
+    """Deterministic smooth fields on the source tiles: f = 2 + sin(lon_c)cos(lat_c) (level-scaled),
+    halo'd [nz][6*(ni+2)^2]; analytic d/dlon, d/dlat stand in for grad_c2l output."""
+    data = np.empty((nz, 6, ni + 2, ni + 2))
+    gx = np.empty((nz, 6, ni, ni))
+    gy = np.empty((nz, 6, ni, ni))
+    for t in range(6):
+        x = np.cos(lat[t]) * np.cos(lon[t]); y = np.cos(lat[t]) * np.sin(lon[t]); z = np.sin(lat[t])
+        avg = lambda a: 0.25 * (a[:-1, :-1] + a[1:, :-1] + a[:-1, 1:] + a[1:, 1:])
+        xm, ym, zm = avg(x), avg(y), avg(z)
+        lc = np.arctan2(ym, xm); tc = np.arcsin(zm / np.sqrt(xm * xm + ym * ym + zm * zm))
+        f = 2.0 + np.sin(lc) * np.cos(tc)
+        for k in range(nz):
+            s = 1.0 + 0.125 * k
+            data[k, t] = np.pad(s * f, 1, mode="edge")
+            gx[k, t] = s * np.cos(lc) * np.cos(tc)
+            gy[k, t] = -s * np.sin(lc) * np.sin(tc)
+    return data.reshape(nz, -1), gx.reshape(nz, -1), gy.reshape(nz, -1)
+
+
+def cpu_baseline(fg, lon, lat, lo, la, ni, nlon, nlat, rows):
+    """The reference algorithm (brute-force pair scan) on the host, single thread, on a bounded sample:
+    `rows` source rows of tile 1 against the full target.  Uses the reference's own code compiled in
+    place (oracle/_ref) when that library is present, else our bit-identical C port (oracle/)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    j0 = ni // 2 - rows // 2
+    sub_lon = np.ascontiguousarray(lon[0][j0:j0 + rows + 1]); sub_lat = np.ascontiguousarray(lat[0][j0:j0 + rows + 1])
+    t0 = time.time()
+    if orc.ref_available():
+        r = orc.ref_create_xgrid(2, ni, rows, nlon, nlat, sub_lon, sub_lat, lo, la)
+        kind = "reference"
+    else:
+        r = orc.orc_create_xgrid(2, ni, rows, nlon, nlat, sub_lon, sub_lat, lo, la)
+        kind = "port"
+    dt = time.time() - t0
+    return {"value": r["n"] / dt, "unit": "exchange-cells/s", "cores": 1, "kind": kind,
+            "sample": f"create_xgrid_2dx2d_order2, C{ni} tile 1 rows {j0}..{j0 + rows - 1} ({rows}x{ni} source cells) "
+                      f"x full {nlon}x{nlat} target: {r['n']} exchange cells in {dt:.2f} s",
+            "seconds": dt}, r, j0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ni", type=int, default=384, help="C<ni> source cubed sphere")
+    ap.add_argument("--nlon", type=int, default=1440)
+    ap.add_argument("--nlat", type=int, default=720)
+    ap.add_argument("--nz", type=int, default=8, help="levels per sweep launch")
+    ap.add_argument("--apply-steps", type=int, default=50)
+    ap.add_argument("--cpu-rows", type=int, default=32, help="source rows in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    fg = ge.load_package()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    ni, nlon, nlat, nz = args.ni, args.nlon, args.nlat, args.nz
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    j0, j1 = band_rows(nlat, world, rank)
+    ny_band = j1 - j0
+    lon_t = [torch.from_numpy(lon[t]).to(dev) for t in range(6)]
+    lat_t = [torch.from_numpy(lat[t]).to(dev) for t in range(6)]
+    lo_t = torch.from_numpy(np.ascontiguousarray(lo[j0:j1 + 1])).to(dev)
+    la_t = torch.from_numpy(np.ascontiguousarray(la[j0:j1 + 1])).to(dev)
+    data_h, gx_h, gy_h = synth_fields(fg, lon, lat, ni, nz)
+    data_t, gx_t, gy_t = (torch.from_numpy(a).to(dev) for a in (data_h, gx_h, gy_h))
+    out_t = torch.empty(nz * ny_band * nlon, dtype=torch.float64, device=dev)
+    ncell_in = 6 * ni * ni
+    total_sums = torch.empty(3 * ncell_in, dtype=torch.float64, device=dev)
+    mean_dlat, mean_dlon = np.pi / nlat, 2 * np.pi / nlon
+    stream = torch.cuda.current_stream().cuda_stream
+    fg.lib().fg_set_profiling(1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    plan = [None]
+
+    def step():
+        if plan[0] is not None:
+            plan[0].destroy()
+        p = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t,
+                                    mean_dlat, mean_dlon, device=local_rank, stream=stream)
+        if world > 1:
+            p.copy_cell_sums(total_sums)
+            dist.all_reduce(total_sums)
+            p.finalize(total_sums.data_ptr())
+        else:
+            p.finalize(None)
+        plan[0] = p
+        return p
+
+    for _ in range(args.warmup):
+        step()
+    barrier(); torch.cuda.synchronize()
+    phase_acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        p = step()
+        for k, v in p.phase_ms().items():
+            phase_acc[k] = phase_acc.get(k, 0.0) + v
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    p = plan[0]
+    nx_local = p.nxgrid
+    stats = p.stats()
+
+    # ---- sweep leg
+    apply_steps = args.apply_steps
+    for _ in range(3):
+        p.apply(data_t, out_t, nz=nz, grad_x_t=gx_t, grad_y_t=gy_t)
+    p.phase_ms()
+    barrier(); torch.cuda.synchronize()
+    ta = time.perf_counter()
+    for _ in range(apply_steps):
+        p.apply(data_t, out_t, nz=nz, grad_x_t=gx_t, grad_y_t=gy_t)
+    torch.cuda.synchronize(); barrier()
+    dta = time.perf_counter() - ta
+    apply_kernel_ms = p.phase_ms()["apply"]
+    gsum_out = p.apply(data_t, out_t, nz=1, grad_x_t=gx_t, grad_y_t=gy_t, want_gsum=True)
+
+    # ---- reductions over ranks
+    red = torch.tensor([dt, dta], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(nx_local), float(gsum_out)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt, dta = float(red[0]), float(red[1])
+    nx_total, gsum_out = int(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        value = args.steps * nx_total / dt
+        ndst = nlon * nlat
+        remap_pts = apply_steps * ndst * nz / dta
+        nsteps = max(args.steps, 1)
+        phases = {k: v / nsteps for k, v in phase_acc.items()}
+        # algorithmic bytes (destination corners counted once because all six source
+        # tiles are searched in one pass): 16 B per corner read, 8 B per source cell (mask), 40 B per xcell written
+        nx_rank0 = nx_local
+        alg_search = 16.0 * (6 * (ni + 1) ** 2 + (nlon + 1) * (ny_band + 1)) + 8.0 * ncell_in + 40.0 * nx_rank0
+        clip_ms = phases.get("clip_quad", 0.0)
+        roof = {"kernel": "k_clip_quad<2>", "bound": "hbm",
+                "achieved": (alg_search / 1e9) / (clip_ms / 1e3) if clip_ms > 0 else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                "algorithmic_bytes_per_launch": alg_search, "kernel_ms": clip_ms,
+                "note": "FP64-VALU/latency bound polygon clipping, not HBM bound (SURVEY.md §8d); "
+                        "the HBM-bound kernel of the path is the sweep, see roofline_apply"}
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
+        # sweep: weights streamed once per launch of nz levels + per level the source fields and the output
+        alg_apply = 32.0 * nx_rank0 + nz * (24.0 * ncell_in + 8.0 * nlon * ny_band)
+        roof_a = {"kernel": "k_apply<2,false>", "bound": "hbm",
+                  "achieved": (alg_apply / 1e9) / (apply_kernel_ms / 1e3) if apply_kernel_ms > 0 else None,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                  "algorithmic_bytes_per_launch": alg_apply, "kernel_ms": apply_kernel_ms, "levels_per_launch": nz}
+        roof_a["frac"] = roof_a["achieved"] / HBM_PEAK_GBS if roof_a["achieved"] else None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                tr = json.load(open(pmc))
+                roof["traffic"] = tr.get("k_clip_quad")
+                roof_a["traffic"] = tr.get("k_apply")
+            except Exception:
+                pass
+        # mass conservation (conserve_interp.c:874-907): input flux uses get_grid_area cell areas
+        a_in = np.concatenate([np.asarray(fg_area) for fg_area in [p.get_cell_area(nlon * ny_band)[0]]])
+        f0 = data_h[0].reshape(6, ni + 2, ni + 2)[:, 1:-1, 1:-1].reshape(-1)
+        gsum_in = float(np.sum(f0 * a_in))
+        line = {
+            "metric": "exchange-cells/s", "value": value, "unit": "exchange-cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / nsteps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C{ni} cubed sphere (6 tiles) -> {nlon}x{nlat} lat-lon, conservative_order2: "
+                                   "exchange-grid search + centroid pass + CSR build per step",
+                       "nxgrid": nx_total, "parallelism": f"{world} latitude band(s) of the target, one per GPU"},
+            "remapped_points_per_s": remap_pts, "apply_ms_per_launch": dta / apply_steps * 1e3, "apply_levels": nz,
+            "mass_rel_err": abs(gsum_out - gsum_in) / abs(gsum_in),
+            "phase_ms": phases, "search_stats": stats,
+            "roofline": roof, "roofline_apply": roof_a,
+        }
+        if world == 1 and args.cpu_rows > 0:
+            cb, _, _ = cpu_baseline(fg, lon, lat, lo, la, ni, nlon, nlat, args.cpu_rows)
+            line["cpu_baseline"] = cb
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

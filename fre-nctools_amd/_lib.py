@@ -28,7 +28,7 @@ EXPORTS = [
     "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
     "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
     "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_stream", "fg_plan_sync",
-    "fg_plan_stats", "fg_gnomonic_ed_corners", "fg_latlon_corners",
+    "fg_plan_stats", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
 
 
@@ -98,6 +98,10 @@ def lib():
     L.fg_plan_sync.restype = C.c_int
     L.fg_plan_stats.argtypes = [vp, C.POINTER(C.c_long), C.c_int]
     L.fg_plan_stats.restype = C.c_int
+    L.fg_set_profiling.argtypes = [C.c_int]
+    L.fg_set_profiling.restype = None
+    L.fg_plan_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    L.fg_plan_phase_ms.restype = C.c_int
     L.fg_gnomonic_ed_corners.argtypes = [C.c_int, C.c_double, C.c_int, dp, dp]
     L.fg_gnomonic_ed_corners.restype = C.c_int
     L.fg_latlon_corners.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp]

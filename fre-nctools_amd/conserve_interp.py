@@ -179,6 +179,14 @@ class XgridPlan:
         names = ["pairs", "nonempty", "nxgrid", "borderline", "bins", "bin_entries", "deferred", "_"]
         return dict(zip(names, [int(v) for v in s]))
 
+    PHASES = ["cell_struct", "bins", "candidates", "clip_quad", "clip_general", "compact", "cell_sums",
+              "search_total", "finalize", "apply"]
+
+    def phase_ms(self):
+        ms = (C.c_float * 10)()
+        check(lib().fg_plan_phase_ms(self._h, ms, 10))
+        return dict(zip(self.PHASES, [float(v) for v in ms]))
+
     def finalize(self, total_sums_ptr=None):
         check(lib().fg_plan_finalize(self._h, C.c_void_p(total_sums_ptr or 0)))
 

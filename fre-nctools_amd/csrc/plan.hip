@@ -95,8 +95,48 @@ Pool g_pool;
 
 extern "C" void fg_pool_release(void) { g_pool.release_all(); }
 
+// ----------------------------------------------------------------------------- phase timing
+// Optional HIP-event timing of the phases of a search / sweep, recorded on the plan's own
+// stream (bench.py reads these for the roofline object; torch.cuda.Event would only see
+// PyTorch's current stream).
+static int g_profiling = 0;
+extern "C" void fg_set_profiling(int on) { g_profiling = on ? 1 : 0; }
+enum { PH_CELL_STRUCT = 0, PH_BINS, PH_CANDIDATES, PH_CLIP_QUAD, PH_CLIP_GENERAL, PH_COMPACT, PH_CELL_SUMS,
+       PH_SEARCH_TOTAL, PH_FINALIZE, PH_APPLY, PH_COUNT };
+struct PhaseTimer {
+  bool on = false;
+  hipStream_t st = nullptr;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans;
+  hipEvent_t open_ev = nullptr; int open_ph = -1;
+  void start(bool enable, hipStream_t s) { on = enable; st = s; }
+  void begin(int ph)
+  {
+    if (!on) return;
+    (void)hipEventCreate(&open_ev); (void)hipEventRecord(open_ev, st); open_ph = ph;
+  }
+  void end()
+  {
+    if (!on || open_ph < 0) return;
+    hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st);
+    spans.push_back({open_ph, {open_ev, e}}); open_ph = -1;
+  }
+  // call after the stream has been synchronised; accumulates into ms[]
+  void collect(float *ms)
+  {
+    for (auto &sp : spans) {
+      float t = 0; (void)hipEventElapsedTime(&t, sp.second.first, sp.second.second);
+      ms[sp.first] += t;
+      (void)hipEventDestroy(sp.second.first); (void)hipEventDestroy(sp.second.second);
+    }
+    spans.clear();
+  }
+};
+
 // ----------------------------------------------------------------------------- plan
 struct fg_plan {
+  float phase_ms[PH_COUNT] = {0};
+  PhaseTimer apply_pt;
+  int apply_spans = 0;
   int order = 0, device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
@@ -182,6 +222,7 @@ extern "C" void fg_plan_destroy(fg_plan *pl)
   (void)hipSetDevice(pl->device);
   if (pl->stream || !pl->own_stream) (void)hipStreamSynchronize(pl->stream);
   if (pl->stream && pl->own_stream) (void)hipStreamDestroy(pl->stream);
+  { float junk[PH_COUNT] = {0}; pl->apply_pt.collect(junk); }
   for (void *p : pl->owned) g_pool.put(p);
   delete pl;
 }
@@ -243,8 +284,14 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   HIPCHK(hipMemsetAsync(stats_dev, 0, FG_NSTATS * sizeof(unsigned long long), st));
   HIPCHK(hipMemsetAsync(defer_cnt, 0, 4 * sizeof(int), st));
 
+  PhaseTimer pt, ptot;
+  pt.start(g_profiling != 0, st); ptot.start(g_profiling != 0, st);
+  for (int k = 0; k < PH_COUNT; k++) pl->phase_ms[k] = 0;
+  ptot.begin(PH_SEARCH_TOTAL);
+  pt.begin(PH_CELL_STRUCT);
   fgd_cell_struct(pl->tiles_dev, pl->ntiles, nsrc, pl->S, err_dev, st);
   fgd_cell_struct(pl->tiles_dev + pl->ntiles, 1, ndst, pl->D, err_dev, st);
+  pt.end();
   pl->have_geom = true;
 
   // --- bins over the destination cells
@@ -258,25 +305,31 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   if (scan_n < ndst + 1) scan_n = ndst + 1;
   unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(scan_n));
   if (!dbins || !bin_cnt || !bin_start || !scan_ws) return fail(FG_ERR_HIP, "out of device memory");
+  pt.begin(PH_BINS);
   HIPCHK(hipMemsetAsync(bin_cnt, 0, (nbins + 1) * sizeof(int), st));
   fgd_bin_count(ndst, pl->D, bins, dbins, bin_cnt, st);
   fgd_exclusive_scan(bin_cnt, nbins + 1, bin_start, scan_ws, total_dev, st);
+  pt.end();
   unsigned long long nentries = 0;
   HIPCHK(hipMemcpyAsync(&nentries, total_dev, sizeof nentries, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   if (nentries > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
   int *bin_cells = pl->alloc<int>(nentries ? nentries : 1);
   if (!bin_cells) return fail(FG_ERR_HIP, "out of device memory");
+  pt.begin(PH_BINS);
   HIPCHK(hipMemsetAsync(bin_cnt, 0, (nbins + 1) * sizeof(int), st));       // reused as fill cursor
   fgd_bin_fill(ndst, bins, dbins, bin_start, bin_cnt, bin_cells, st);
+  pt.end();
 
   // --- candidate pairs
   int *cand_cnt = pl->alloc<int>(nsrc + 1);
   int *cand_off = pl->alloc<int>(nsrc + 1);
   if (!cand_cnt || !cand_off) return fail(FG_ERR_HIP, "out of device memory");
+  pt.begin(PH_CANDIDATES);
   HIPCHK(hipMemsetAsync(cand_cnt + nsrc, 0, sizeof(int), st));
   fgd_candidates(false, nsrc, pl->S, pl->mask_dev, pl->D, bins, dbins, bin_start, bin_cells, cand_cnt, nullptr, nullptr, nullptr, st);
   fgd_exclusive_scan(cand_cnt, nsrc + 1, cand_off, scan_ws, total_dev, st);
+  pt.end();
   unsigned long long npairs64 = 0;
   unsigned errh[4] = {0, 0, 0, 0};
   HIPCHK(hipMemcpyAsync(&npairs64, total_dev, sizeof npairs64, hipMemcpyDeviceToHost, st));
@@ -295,16 +348,26 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pl->xoff = pl->alloc<int>(nsrc + 1);
   if (!pair_src || !pair_dst || !tmp_area || !defer_list || !pl->nacc || !pl->xoff ||
       (order == 2 && (!tmp_clon || !tmp_clat))) return fail(FG_ERR_HIP, "out of device memory");
+  pt.begin(PH_CANDIDATES);
   fgd_candidates(true, nsrc, pl->S, pl->mask_dev, pl->D, bins, dbins, bin_start, bin_cells, cand_cnt, cand_off, pair_src, pair_dst, st);
+  pt.end();
 
   // --- clip, area, centroid integrals
-  fgd_clip(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-           defer_list, defer_cnt, stats_dev, err_dev, st);
+  pt.begin(PH_CLIP_QUAD);
+  fgd_clip_quad(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
+                defer_list, defer_cnt, stats_dev, err_dev, st);
+  pt.end();
+  pt.begin(PH_CLIP_GENERAL);
+  fgd_clip_general(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
+                   defer_list, defer_cnt, stats_dev, err_dev, st);
+  pt.end();
 
   // --- compaction into canonical order
+  pt.begin(PH_COMPACT);
   HIPCHK(hipMemsetAsync(pl->nacc + nsrc, 0, sizeof(int), st));
   fgd_count_accepted(nsrc, cand_off, cand_cnt, tmp_area, pl->nacc, st);
   fgd_exclusive_scan(pl->nacc, nsrc + 1, pl->xoff, scan_ws, total_dev, st);
+  pt.end();
   unsigned long long nx64 = 0, statsh[FG_NSTATS];
   int deferh = 0;
   HIPCHK(hipMemcpyAsync(&nx64, total_dev, sizeof nx64, hipMemcpyDeviceToHost, st));
@@ -320,15 +383,21 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pl->x_area = pl->alloc<double>(pl->nx + 1);
   if (order == 2) { pl->x_c1 = pl->alloc<double>(pl->nx + 1); pl->x_c2 = pl->alloc<double>(pl->nx + 1); }
   if (!pl->x_src || !pl->x_dst || !pl->x_area || (order == 2 && (!pl->x_c1 || !pl->x_c2))) return fail(FG_ERR_HIP, "out of device memory");
+  pt.begin(PH_COMPACT);
   fgd_scatter_xcells(order, npairs, pair_src, pair_dst, cand_off, cand_cnt, pl->xoff, tmp_area, tmp_clon, tmp_clat,
                      pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, st);
+  pt.end();
   if (order == 2) {
     pl->sums = pl->alloc<double>(3 * (size_t)nsrc);
     if (!pl->sums) return fail(FG_ERR_HIP, "out of device memory");
+    pt.begin(PH_CELL_SUMS);
     fgd_cell_sums(nsrc, pl->xoff, pl->nacc, pl->x_area, pl->x_c1, pl->x_c2, pl->sums, st);
+    pt.end();
   }
+  ptot.end();
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
+  pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms);
 
   pl->stats[FG_STAT_PAIRS] = npairs;
   pl->stats[FG_STAT_NONEMPTY] = (long)statsh[FG_STAT_NONEMPTY];
@@ -539,6 +608,8 @@ extern "C" int fg_plan_finalize(fg_plan *pl, const double *total_cell_sums_dev)
   if (!pl->searched) return fail(FG_ERR_STATE, "fg_plan_finalize: plan holds no search result");
   if (pl->finalized) return fail(FG_ERR_STATE, "fg_plan_finalize: already finalized");
   HIPCHK(hipSetDevice(pl->device));
+  PhaseTimer pt; pt.start(g_profiling != 0, pl->stream);
+  pt.begin(PH_FINALIZE);
   if (pl->order == 2) {
     pl->cen = pl->alloc<double>(2 * (size_t)pl->nsrc);
     if (!pl->cen) return fail(FG_ERR_HIP, "out of device memory");
@@ -548,7 +619,28 @@ extern "C" int fg_plan_finalize(fg_plan *pl, const double *total_cell_sums_dev)
   }
   int rc = build_csr(pl);
   if (rc) return rc;
+  pt.end();
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  pl->phase_ms[PH_FINALIZE] = 0; pt.collect(pl->phase_ms);
   pl->finalized = true;
+  return 0;
+}
+
+// phase times (ms) of the last search/finalize/apply when fg_set_profiling(1) was active:
+// [0] cell records [1] binning [2] candidates [3] clip quad [4] clip general [5] compaction
+// [6] cell sums [7] whole search (device span) [8] finalize [9] last apply
+extern "C" int fg_plan_phase_ms(fg_plan *pl, float *ms, int n)
+{
+  if (!pl || !ms) return fail(FG_ERR_ARG, "null argument");
+  if (pl->apply_spans > 0) {               // sweeps are timed without a sync; average them now
+    HIPCHK(hipSetDevice(pl->device));
+    HIPCHK(hipStreamSynchronize(pl->stream));
+    float acc[PH_COUNT] = {0};
+    pl->apply_pt.collect(acc);
+    pl->phase_ms[PH_APPLY] = acc[PH_APPLY] / pl->apply_spans;
+    pl->apply_spans = 0;
+  }
+  for (int k = 0; k < n && k < PH_COUNT; k++) ms[k] = pl->phase_ms[k];
   return 0;
 }
 
@@ -693,8 +785,12 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
     }
     rs = pl->row_sum;
   }
+  pl->apply_pt.start(g_profiling != 0, pl->stream);
+  pl->apply_pt.begin(PH_APPLY);
   fgd_apply(pl->order, pl->ndst, pl->csr, data, grad_x, grad_y, grad_mask, has_missing, miss, nz,
             pl->f_stride, pl->nsrc, out, rs, pl->stream);
+  pl->apply_pt.end();
+  if (pl->apply_pt.on) pl->apply_spans++;
   if (gsum_out) {
     fgd_reduce_sum(rs, (long)nz * pl->ndst, pl->red_partial, pl->red_result, pl->stream);
     HIPCHK(hipMemcpyAsync(gsum_out, pl->red_result, sizeof(double), hipMemcpyDeviceToHost, pl->stream));

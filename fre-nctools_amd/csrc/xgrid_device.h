@@ -45,7 +45,10 @@ void fgd_bin_fill(int ncells, FgBins b, const int4 *cell_bins, const int *bin_st
 void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgCells D, FgBins b, const int4 *dbins,
                     const int *bin_start, const int *bin_cells, int *cand_cnt, const int *cand_off,
                     int *pair_src, int *pair_dst, hipStream_t st);
-void fgd_clip(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
+void fgd_clip_general(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
+              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+              unsigned long long *stats, unsigned *err, hipStream_t st);
+void fgd_clip_quad(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);
 void fgd_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt, const double *tmp_area, int *nacc, hipStream_t st);

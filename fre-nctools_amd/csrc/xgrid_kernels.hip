@@ -615,18 +615,27 @@ void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgCells 
   else      k_candidates<false><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, mask, D, b, dbins, bin_start, bin_cells, cand_cnt, cand_off, pair_src, pair_dst);
 }
 
-void fgd_clip(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
-              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
-              unsigned long long *stats, unsigned *err, hipStream_t st)
+void fgd_clip_quad(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
+                   double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+                   unsigned long long *stats, unsigned *err, hipStream_t st)
 {
   if (npairs <= 0) return;
-  if (order == 2) {
+  if (order == 2)
     k_clip_quad<2><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
-    k_clip_general<2><<<1024, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
-  } else {
+  else
     k_clip_quad<1><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
-    k_clip_general<1><<<1024, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
-  }
+}
+
+void fgd_clip_general(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
+                      double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+                      unsigned long long *stats, unsigned *err, hipStream_t st)
+{
+  if (npairs <= 0) return;
+  int grid = nblk(npairs, GEN_THREADS); if (grid > 1024) grid = 1024;
+  if (order == 2)
+    k_clip_general<2><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
+  else
+    k_clip_general<1><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
 }
 
 void fgd_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt, const double *tmp_area, int *nacc, hipStream_t st)

@@ -197,6 +197,13 @@ void *fg_plan_stream(fg_plan *plan);
 /* wait for everything queued on the plan's stream */
 int fg_plan_sync(fg_plan *plan);
 
+/* Optional HIP-event timing of the library's own launches (on the plan's stream).
+ * fg_plan_phase_ms: [0] cell records [1] binning [2] candidates [3] clip quad kernel
+ * [4] clip general kernel [5] compaction [6] cell sums [7] whole search (device span, includes
+ * the two host round trips) [8] finalize [9] last sweep.  Milliseconds; zeros when profiling is off. */
+void fg_set_profiling(int on);
+int  fg_plan_phase_ms(fg_plan *plan, float *ms, int n);   /* [9] = mean over the sweeps since the last call */
+
 /* per-phase statistics of the last search (counts), for DESIGN.md/bench reporting:
  * stats[0]=candidate pairs after the bounding-box tests, [1]=pairs with a non-empty clip,
  * [2]=nxgrid, [3]=pairs whose area ratio is within 1e-9 (relative) of the 1e-6 threshold,
