@@ -176,7 +176,7 @@ class XgridPlan:
     def stats(self):
         s = (C.c_long * 8)()
         check(lib().fg_plan_stats(self._h, s, 8))
-        names = ["pairs", "nonempty", "nxgrid", "borderline", "bins", "bin_entries", "deferred", "_"]
+        names = ["pairs", "nonempty", "nxgrid", "borderline", "bins", "bin_entries", "deferred", "heavy"]
         return dict(zip(names, [int(v) for v in s]))
 
     PHASES = ["cell_struct", "bins", "candidates", "clip_quad", "clip_general", "compact", "cell_sums",

@@ -230,7 +230,7 @@ extern "C" void fg_plan_destroy(fg_plan *pl)
 static void choose_bins(const fg_plan *pl, double mean_dlat, double mean_dlon, FgBins *b)
 {
   const double PI = 3.14159265358979323846;
-  double h = 2.0 * mean_dlat, w = 2.0 * mean_dlon;
+  double h = 1.5 * mean_dlat, w = 1.5 * mean_dlon;   // a typical cell then covers at most 2x2 bins
   int nblat = (h > 0) ? (int)ceil(PI / h) : 1;
   int nblon = (w > 0) ? (int)ceil(2.0 * PI / w) : 1;
   if (nblat < 1) nblat = 1; if (nblat > 8192) nblat = 8192;
@@ -298,36 +298,39 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   FgBins bins;
   choose_bins(pl, mean_dlat, mean_dlon, &bins);
   const long nbins = (long)bins.nblat * bins.nblon;
-  int4 *dbins = pl->alloc<int4>(ndst);
-  int *bin_cnt = pl->alloc<int>(nbins + 1);
-  int *bin_start = pl->alloc<int>(nbins + 1);
-  long scan_n = (nbins + 1 > (long)nsrc + 1) ? nbins + 1 : (long)nsrc + 1;
+  const long nslots = nbins + bins.nblat;             // regular bins + one wide list per bin row
+  int *bin_cnt = pl->alloc<int>(nslots + 1);
+  int *bin_start = pl->alloc<int>(nslots + 1);
+  long scan_n = (nslots + 1 > (long)nsrc + 1) ? nslots + 1 : (long)nsrc + 1;
   if (scan_n < ndst + 1) scan_n = ndst + 1;
   unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(scan_n));
-  if (!dbins || !bin_cnt || !bin_start || !scan_ws) return fail(FG_ERR_HIP, "out of device memory");
+  if (!bin_cnt || !bin_start || !scan_ws) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_BINS);
-  HIPCHK(hipMemsetAsync(bin_cnt, 0, (nbins + 1) * sizeof(int), st));
-  fgd_bin_count(ndst, pl->D, bins, dbins, bin_cnt, st);
-  fgd_exclusive_scan(bin_cnt, nbins + 1, bin_start, scan_ws, total_dev, st);
+  HIPCHK(hipMemsetAsync(bin_cnt, 0, (nslots + 1) * sizeof(int), st));
+  fgd_bin_build(false, ndst, pl->D, bins, bin_cnt, nullptr, nullptr, st);
+  fgd_exclusive_scan(bin_cnt, nslots + 1, bin_start, scan_ws, total_dev, st);
   pt.end();
   unsigned long long nentries = 0;
   HIPCHK(hipMemcpyAsync(&nentries, total_dev, sizeof nentries, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   if (nentries > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
-  int *bin_cells = pl->alloc<int>(nentries ? nentries : 1);
-  if (!bin_cells) return fail(FG_ERR_HIP, "out of device memory");
+  FgBinEntry *bin_entries = pl->alloc<FgBinEntry>(nentries ? nentries : 1);
+  if (!bin_entries) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_BINS);
-  HIPCHK(hipMemsetAsync(bin_cnt, 0, (nbins + 1) * sizeof(int), st));       // reused as fill cursor
-  fgd_bin_fill(ndst, bins, dbins, bin_start, bin_cnt, bin_cells, st);
+  HIPCHK(hipMemsetAsync(bin_cnt, 0, (nslots + 1) * sizeof(int), st));      // reused as fill cursor
+  fgd_bin_build(true, ndst, pl->D, bins, bin_cnt, bin_start, bin_entries, st);
   pt.end();
 
   // --- candidate pairs
   int *cand_cnt = pl->alloc<int>(nsrc + 1);
   int *cand_off = pl->alloc<int>(nsrc + 1);
-  if (!cand_cnt || !cand_off) return fail(FG_ERR_HIP, "out of device memory");
+  int *heavy_list = pl->alloc<int>(nsrc + 1);
+  int *heavy_cnt = pl->alloc<int>(4);
+  if (!cand_cnt || !cand_off || !heavy_list || !heavy_cnt) return fail(FG_ERR_HIP, "out of device memory");
+  HIPCHK(hipMemsetAsync(heavy_cnt, 0, 4 * sizeof(int), st));
   pt.begin(PH_CANDIDATES);
   HIPCHK(hipMemsetAsync(cand_cnt + nsrc, 0, sizeof(int), st));
-  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, pl->D, bins, dbins, bin_start, bin_cells, cand_cnt, nullptr, nullptr, nullptr, st);
+  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, heavy_cnt, st);
   fgd_exclusive_scan(cand_cnt, nsrc + 1, cand_off, scan_ws, total_dev, st);
   pt.end();
   unsigned long long npairs64 = 0;
@@ -349,7 +352,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   if (!pair_src || !pair_dst || !tmp_area || !defer_list || !pl->nacc || !pl->xoff ||
       (order == 2 && (!tmp_clon || !tmp_clat))) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_CANDIDATES);
-  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, pl->D, bins, dbins, bin_start, bin_cells, cand_cnt, cand_off, pair_src, pair_dst, st);
+  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, st);
   pt.end();
 
   // --- clip, area, centroid integrals
@@ -369,7 +372,8 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   fgd_exclusive_scan(pl->nacc, nsrc + 1, pl->xoff, scan_ws, total_dev, st);
   pt.end();
   unsigned long long nx64 = 0, statsh[FG_NSTATS];
-  int deferh = 0;
+  int deferh = 0, heavyh = 0;
+  HIPCHK(hipMemcpyAsync(&heavyh, heavy_cnt, sizeof heavyh, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&nx64, total_dev, sizeof nx64, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(errh, err_dev, sizeof errh, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(statsh, stats_dev, sizeof statsh, hipMemcpyDeviceToHost, st));
@@ -406,9 +410,10 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pl->stats[FG_STAT_BINS] = nbins;
   pl->stats[FG_STAT_BIN_ENTRIES] = (long)nentries;
   pl->stats[FG_STAT_DEFERRED] = deferh;
+  pl->stats[FG_STAT_HEAVY] = heavyh;
 
   // scratch no longer needed
-  void *scratch[] = {dbins, bin_cnt, bin_start, scan_ws, bin_cells, cand_cnt, cand_off, pair_src, pair_dst,
+  void *scratch[] = {bin_cnt, bin_start, scan_ws, bin_entries, heavy_list, heavy_cnt, cand_cnt, cand_off, pair_src, pair_dst,
                      tmp_area, tmp_clon, tmp_clat, defer_list, err_dev, stats_dev, total_dev, defer_cnt};
   for (void *p : scratch) pl->release(p);
   pl->searched = true;

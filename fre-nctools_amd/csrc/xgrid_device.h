@@ -24,6 +24,14 @@ struct FgBins {
   double inv_wlat, inv_wlon;
 };
 
+// one destination cell as stored in the bin table (bin order): the five numbers the
+// bounding-box rejects need, so the candidate scan streams records instead of chasing indices
+struct FgBinEntry {
+  double lat_min, lat_max, lon_min, lon_max, lon_avg;
+  int d;       // destination cell index
+  int row0;    // first bin row of the cell (de-duplicates wide cells)
+};
+
 enum {
   FG_STAT_PAIRS = 0,      // candidate pairs after the bounding-box tests
   FG_STAT_NONEMPTY = 1,   // pairs whose clip is non-empty
@@ -32,6 +40,7 @@ enum {
   FG_STAT_BINS = 4,
   FG_STAT_BIN_ENTRIES = 5,
   FG_STAT_DEFERRED = 6,   // pairs handled by the general (non quad x quad) kernel
+  FG_STAT_HEAVY = 7,      // source cells whose candidate scan got a whole wave
   FG_NSTATS = 8
 };
 
@@ -40,11 +49,10 @@ int  fgd_exclusive_scan(const int *in, long n, int *out, unsigned long long *bsu
 long fgd_scan_ws_elems(long n);
 
 void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c, unsigned *err, hipStream_t st);
-void fgd_bin_count(int ncells, FgCells c, FgBins b, int4 *cell_bins, int *bin_cnt, hipStream_t st);
-void fgd_bin_fill(int ncells, FgBins b, const int4 *cell_bins, const int *bin_start, int *bin_fill, int *bin_cells, hipStream_t st);
-void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgCells D, FgBins b, const int4 *dbins,
-                    const int *bin_start, const int *bin_cells, int *cand_cnt, const int *cand_off,
-                    int *pair_src, int *pair_dst, hipStream_t st);
+void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start, FgBinEntry *entries, hipStream_t st);
+void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start,
+                    const FgBinEntry *entries, int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
+                    int *heavy_list, int *heavy_cnt, hipStream_t st);
 void fgd_clip_general(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);

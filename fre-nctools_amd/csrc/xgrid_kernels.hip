@@ -4,10 +4,12 @@
 //
 //   k_cell_struct      per cell: lat min/max, fix_lon, lon min/max/avg, <=8 vertices, area
 //                      [get_grid_cell_struct semantics, create_xgrid.c:991-1016; get_grid_area :66-88]
-//   k_bin_count/fill   destination cells -> uniform (lat x lon mod 2pi) bins, CSR by bin
-//   k_candidates       per source cell: walk its bins, apply the reference's exact
-//                      bounding-box rejects (create_xgrid.c:1055-1079) -> candidate pairs
-//                      [get_upbound_nxcells_2dx2d semantics], count pass + fill pass
+//   k_bin_build        destination cells -> uniform (lat x lon mod 2pi) bins, one 48-byte record per
+//                      cell stored in bin order (single insertion; wide cells in per-row lists)
+//   k_candidates(+_heavy)  per source cell: scan the <= 2 contiguous record ranges per bin row,
+//                      apply the reference's exact bounding-box rejects (create_xgrid.c:1055-1079)
+//                      -> candidate pairs [get_upbound_nxcells_2dx2d semantics]; count pass + fill
+//                      pass; source cells at the poles (huge longitude range) get a whole wave
 //   k_clip_quad        one lane per candidate pair, quad x quad fast path: Sutherland-Hodgman
 //                      clip (create_xgrid.c:1266-1341) with the polygon staged in LDS
 //                      [vertex][lane], then area / centroid integrals and the 1e-6 area test
@@ -189,62 +191,117 @@ __global__ __launch_bounds__(256) void k_cell_struct(const FgTile *tiles, int nt
 // ---------------------------------------------------------------------------------------
 // binning of destination cells
 // ---------------------------------------------------------------------------------------
-// Bin ranges of a bounding box.  Margins of 1e-9 rad make the ranges a superset under
-// the +-2pi shifts of create_xgrid.c:1064-1074.
-__device__ __forceinline__ int4 d_bin_range(double lat_min, double lat_max, double lon_min, double lon_max, FgBins b)
+// Uniform bins over latitude x (longitude mod 2pi), sized ~1.5x the mean destination cell.
+// A destination cell whose bounding box covers at most 2x2 bins ("regular") is stored ONCE, in
+// the bin of its (lat_min, lon_min) corner; a source cell therefore finds every regular cell
+// that can overlap it by scanning rows [r0-1, r1] x columns [c0-1, c1] of its own box -- and
+// because bins of one row are adjacent in the table, that is at most two contiguous entry
+// ranges per row.  Cells with a larger footprint (pole caps of a cubed-sphere target, ...) go to
+// a per-latitude-row "wide" list that every source cell of that row tests.
+// Margins of 1e-9 rad make the scan a superset of the pairs that pass the reference's tests,
+// including its +-2pi shifts (create_xgrid.c:1064-1074); see DESIGN.md §3.2.
+__device__ __forceinline__ void d_cell_box(double lat_min, double lat_max, double lon_min, double lon_max, FgBins b,
+                                           int *r0, int *r1, long long *l0, long long *l1)
 {
   const double eps = 1.e-9;
-  int bl0 = (int)floor((lat_min - eps + G_HPI) * b.inv_wlat);
-  int bl1 = (int)floor((lat_max + eps + G_HPI) * b.inv_wlat);
-  bl0 = max(0, min(b.nblat - 1, bl0));
-  bl1 = max(0, min(b.nblat - 1, bl1));
-  long long l0 = (long long)floor((lon_min - eps) * b.inv_wlon);
-  long long l1 = (long long)floor((lon_max + eps) * b.inv_wlon);
-  long long nl = l1 - l0 + 1;
-  int c0;
-  if (nl >= b.nblon) { nl = b.nblon; c0 = 0; }
-  else { c0 = (int)(((l0 % b.nblon) + b.nblon) % b.nblon); }
-  return make_int4(bl0, bl1, c0, (int)nl);
+  int a0 = (int)floor((lat_min - eps + G_HPI) * b.inv_wlat);
+  int a1 = (int)floor((lat_max + eps + G_HPI) * b.inv_wlat);
+  *r0 = max(0, min(b.nblat - 1, a0));
+  *r1 = max(0, min(b.nblat - 1, a1));
+  *l0 = (long long)floor((lon_min - eps) * b.inv_wlon);
+  *l1 = (long long)floor((lon_max + eps) * b.inv_wlon);
 }
+__device__ __forceinline__ int d_colmod(long long l, int nb) { return (int)(((l % nb) + nb) % nb); }
 
-__global__ __launch_bounds__(256) void k_bin_count(int ncells, FgCells c, FgBins b, int4 *cell_bins, int *bin_cnt)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin_build(int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start,
+                                                    FgBinEntry *entries)
 {
   int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ncells) return;
-  if (c.nv[d] == 0) { cell_bins[d] = make_int4(0, -1, 0, 0); return; }
-  int4 r = d_bin_range(c.lat_min[d], c.lat_max[d], c.lon_min[d], c.lon_max[d], b);
-  cell_bins[d] = r;
-  for (int bl = r.x; bl <= r.y; bl++)
-    for (int k = 0; k < r.w; k++) {
-      int col = r.z + k; if (col >= b.nblon) col -= b.nblon;
-      atomicAdd(&bin_cnt[bl * b.nblon + col], 1);
+  if (c.nv[d] == 0) return;
+  FgBinEntry E;
+  E.lat_min = c.lat_min[d]; E.lat_max = c.lat_max[d];
+  E.lon_min = c.lon_min[d]; E.lon_max = c.lon_max[d]; E.lon_avg = c.lon_avg[d];
+  E.d = d;
+  int r0, r1; long long l0, l1;
+  d_cell_box(E.lat_min, E.lat_max, E.lon_min, E.lon_max, b, &r0, &r1, &l0, &l1);
+  E.row0 = r0;
+  const int nbins = b.nblat * b.nblon;
+  if (r1 - r0 <= 1 && l1 - l0 <= 1) {
+    int slot = r0 * b.nblon + d_colmod(l0, b.nblon);
+    int pos = atomicAdd(&slot_cnt[slot], 1);
+    if (FILL) entries[slot_start[slot] + pos] = E;
+  } else {
+    for (int r = r0; r <= r1; r++) {
+      int pos = atomicAdd(&slot_cnt[nbins + r], 1);
+      if (FILL) entries[slot_start[nbins + r] + pos] = E;
     }
-}
-
-__global__ __launch_bounds__(256) void k_bin_fill(int ncells, FgBins b, const int4 *cell_bins, const int *bin_start,
-                                                   int *bin_fill, int *bin_cells)
-{
-  int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= ncells) return;
-  int4 r = cell_bins[d];
-  for (int bl = r.x; bl <= r.y; bl++)
-    for (int k = 0; k < r.w; k++) {
-      int col = r.z + k; if (col >= b.nblon) col -= b.nblon;
-      int bin = bl * b.nblon + col;
-      int pos = atomicAdd(&bin_fill[bin], 1);
-      bin_cells[bin_start[bin] + pos] = d;
-    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
 // candidate pairs
 // ---------------------------------------------------------------------------------------
-// FILL == false: cand_cnt[s] = number of destination cells passing the reference's two
-// bounding-box rejects.  FILL == true: write them at cand_off[s]...
+struct SrcQuery {
+  int ra, rb;          // rows holding regular cells that may overlap: [max(0, r0-1), r1]
+  int r0, r1;          // the source cell's own rows (wide lists)
+  int c_start, n0, n1; // columns [c_start, c_start+n0) and, wrapped, [0, n1)
+};
+
+__device__ __forceinline__ SrcQuery d_src_query(double lat_min, double lat_max, double lon_min, double lon_max, FgBins b)
+{
+  SrcQuery q;
+  long long l0, l1;
+  d_cell_box(lat_min, lat_max, lon_min, lon_max, b, &q.r0, &q.r1, &l0, &l1);
+  q.ra = max(0, q.r0 - 1); q.rb = q.r1;
+  long long count = (l1 - l0 + 1) + 1;
+  if (count >= b.nblon) { q.c_start = 0; q.n0 = b.nblon; q.n1 = 0; }
+  else {
+    q.c_start = d_colmod(l0 - 1, b.nblon);
+    q.n0 = (int)min((long long)(b.nblon - q.c_start), count);
+    q.n1 = (int)count - q.n0;
+  }
+  return q;
+}
+
+// number of table entries the query touches
+__device__ __forceinline__ int d_query_size(const SrcQuery &q, FgBins b, const int *slot_start)
+{
+  int t = 0;
+  for (int r = q.ra; r <= q.rb; r++) {
+    int base = r * b.nblon;
+    t += slot_start[base + q.c_start + q.n0] - slot_start[base + q.c_start];
+    if (q.n1) t += slot_start[base + q.n1] - slot_start[base];
+  }
+  const int nbins = b.nblat * b.nblon;
+  t += slot_start[nbins + q.r1 + 1] - slot_start[nbins + q.r0];
+  return t;
+}
+
+// the reference's two bounding-box rejects, create_xgrid.c:1055 and :1062-1079
+__device__ __forceinline__ bool d_box_pass(const FgBinEntry &E, double lat_in_min, double lat_in_max,
+                                           double lon_in_min, double lon_in_max, double lon_in_avg)
+{
+  if (E.lat_min >= lat_in_max || E.lat_max <= lat_in_min) return false;
+  double lon_out_min = E.lon_min, lon_out_max = E.lon_max;
+  double dx = E.lon_avg - lon_in_avg;
+  if (dx < -G_PI)     { lon_out_min += G_TPI; lon_out_max += G_TPI; }
+  else if (dx > G_PI) { lon_out_min -= G_TPI; lon_out_max -= G_TPI; }
+  if (lon_out_min >= lon_in_max || lon_out_max <= lon_in_min) return false;
+  return true;
+}
+
+#define HEAVY_ENTRIES 96
+
+// One lane per source cell.  FILL == false: cand_cnt[s] = number of destination cells passing the
+// rejects; cells whose query touches more than HEAVY_ENTRIES table entries are appended to
+// heavy_list instead (k_candidates_heavy gives them a whole wave).  FILL == true: write pairs.
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const double *mask, FgCells D, FgBins b,
-                                                     const int4 *dbins, const int *bin_start, const int *bin_cells,
-                                                     int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst)
+__global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const double *mask, FgBins b,
+                                                     const int *slot_start, const FgBinEntry *entries,
+                                                     int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
+                                                     int *heavy_list, int *heavy_cnt)
 {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsrc) return;
@@ -254,38 +311,90 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
   if (active) {
     const double lat_in_min = S.lat_min[s], lat_in_max = S.lat_max[s];
     const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
-    int4 r = d_bin_range(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
-    int wbase = FILL ? cand_off[s] : 0;
-    for (int bl = r.x; bl <= r.y; bl++)
-      for (int k = 0; k < r.w; k++) {
-        int col = r.z + k; if (col >= b.nblon) col -= b.nblon;
-        int bin = bl * b.nblon + col;
-        int e0 = bin_start[bin], e1 = bin_start[bin + 1];
+    SrcQuery q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
+    if (d_query_size(q, b, slot_start) > HEAVY_ENTRIES) {
+      if (!FILL) { int h = atomicAdd(heavy_cnt, 1); heavy_list[h] = s; }
+      return;                                          // cand_cnt[s] comes from the heavy kernel
+    }
+    const int wbase = FILL ? cand_off[s] : 0;
+    const int nbins = b.nblat * b.nblon;
+    for (int r = q.ra; r <= q.rb; r++) {
+      int base = r * b.nblon;
+      for (int seg = 0; seg < 2; seg++) {
+        int e0 = seg ? slot_start[base] : slot_start[base + q.c_start];
+        int e1 = seg ? slot_start[base + q.n1] : slot_start[base + q.c_start + q.n0];
+        if (seg && !q.n1) break;
         for (int e = e0; e < e1; e++) {
-          int d = bin_cells[e];
-          int4 q = dbins[d];
-          // a destination cell sits in several bins: keep it only in the first bin shared
-          // with this source cell (rows: larger of the two first rows; columns: first column of
-          // the source's walk that lies inside the destination's arc)
-          if (bl != max(r.x, q.x)) continue;
-          int off_sd = r.z - q.z; if (off_sd < 0) off_sd += b.nblon;
-          int kstar = 0;
-          if (off_sd >= q.w) { kstar = q.z - r.z; if (kstar < 0) kstar += b.nblon; }
-          if (k != kstar) continue;
-          // create_xgrid.c:1055
-          if (D.lat_min[d] >= lat_in_max || D.lat_max[d] <= lat_in_min) continue;
-          // create_xgrid.c:1062-1079
-          double lon_out_min = D.lon_min[d], lon_out_max = D.lon_max[d];
-          double dx = D.lon_avg[d] - lon_in_avg;
-          if (dx < -G_PI)     { lon_out_min += G_TPI; lon_out_max += G_TPI; }
-          else if (dx > G_PI) { lon_out_min -= G_TPI; lon_out_max -= G_TPI; }
-          if (lon_out_min >= lon_in_max || lon_out_max <= lon_in_min) continue;
-          if (FILL) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = d; }
+          const FgBinEntry E = entries[e];
+          if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
+          if (FILL) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = E.d; }
           cnt++;
         }
       }
+    }
+    for (int r = q.r0; r <= q.r1; r++) {
+      int e0 = slot_start[nbins + r], e1 = slot_start[nbins + r + 1];
+      for (int e = e0; e < e1; e++) {
+        const FgBinEntry E = entries[e];
+        if (r != max(q.r0, E.row0)) continue;          // a wide cell sits in every row it spans
+        if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
+        if (FILL) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = E.d; }
+        cnt++;
+      }
+    }
   }
   if (!FILL) cand_cnt[s] = cnt;
+}
+
+// One wave per heavy source cell (pole caps of the source grid: their longitude range covers
+// hundreds of bins); lanes stride the contiguous entry ranges, ballot + popcount compacts.
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_candidates_heavy(FgCells S, FgBins b, const int *slot_start, const FgBinEntry *entries,
+                                                          int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
+                                                          const int *heavy_list, const int *heavy_cnt)
+{
+  const int lane = threadIdx.x;
+  const int nheavy = *heavy_cnt;
+  const int nbins = b.nblat * b.nblon;
+  for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    const int s = heavy_list[h];
+    const double lat_in_min = S.lat_min[s], lat_in_max = S.lat_max[s];
+    const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
+    SrcQuery q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
+    const int wbase = FILL ? cand_off[s] : 0;
+    int cnt = 0;
+    const int nrows_reg = q.rb - q.ra + 1, nrows_wide = q.r1 - q.r0 + 1;
+    for (int it = 0; it < 2 * nrows_reg + nrows_wide; it++) {
+      int e0, e1, wide_row = -1;
+      if (it < 2 * nrows_reg) {
+        int r = q.ra + (it >> 1), seg = it & 1, base = r * b.nblon;
+        if (seg && !q.n1) continue;
+        e0 = seg ? slot_start[base] : slot_start[base + q.c_start];
+        e1 = seg ? slot_start[base + q.n1] : slot_start[base + q.c_start + q.n0];
+      } else {
+        wide_row = q.r0 + (it - 2 * nrows_reg);
+        e0 = slot_start[nbins + wide_row]; e1 = slot_start[nbins + wide_row + 1];
+      }
+      for (int eb = e0; eb < e1; eb += 64) {
+        int e = eb + lane;
+        bool pass = false;
+        int dcell = 0;
+        if (e < e1) {
+          const FgBinEntry E = entries[e];
+          dcell = E.d;
+          pass = d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg);
+          if (wide_row >= 0 && wide_row != max(q.r0, E.row0)) pass = false;
+        }
+        unsigned long long m = __ballot(pass);
+        if (FILL && pass) {
+          int pos = wbase + cnt + __popcll(m & ((1ull << lane) - 1ull));
+          pair_src[pos] = s; pair_dst[pos] = dcell;
+        }
+        cnt += __popcll(m);
+      }
+    }
+    if (!FILL && lane == 0) cand_cnt[s] = cnt;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -596,23 +705,26 @@ void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c,
   if (ncells > 0) k_cell_struct<<<nblk(ncells, 256), 256, 0, st>>>(tiles_dev, ntiles, ncells, c, err);
 }
 
-void fgd_bin_count(int ncells, FgCells c, FgBins b, int4 *cell_bins, int *bin_cnt, hipStream_t st)
+void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start, FgBinEntry *entries, hipStream_t st)
 {
-  if (ncells > 0) k_bin_count<<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, cell_bins, bin_cnt);
+  if (ncells <= 0) return;
+  if (fill) k_bin_build<true><<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, slot_cnt, slot_start, entries);
+  else      k_bin_build<false><<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, slot_cnt, slot_start, entries);
 }
 
-void fgd_bin_fill(int ncells, FgBins b, const int4 *cell_bins, const int *bin_start, int *bin_fill, int *bin_cells, hipStream_t st)
-{
-  if (ncells > 0) k_bin_fill<<<nblk(ncells, 256), 256, 0, st>>>(ncells, b, cell_bins, bin_start, bin_fill, bin_cells);
-}
-
-void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgCells D, FgBins b, const int4 *dbins,
-                    const int *bin_start, const int *bin_cells, int *cand_cnt, const int *cand_off,
-                    int *pair_src, int *pair_dst, hipStream_t st)
+void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start,
+                    const FgBinEntry *entries, int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
+                    int *heavy_list, int *heavy_cnt, hipStream_t st)
 {
   if (nsrc <= 0) return;
-  if (fill) k_candidates<true><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, mask, D, b, dbins, bin_start, bin_cells, cand_cnt, cand_off, pair_src, pair_dst);
-  else      k_candidates<false><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, mask, D, b, dbins, bin_start, bin_cells, cand_cnt, cand_off, pair_src, pair_dst);
+  int hgrid = nblk(nsrc, 64); if (hgrid > 2048) hgrid = 2048;
+  if (fill) {
+    k_candidates<true><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
+    k_candidates_heavy<true><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
+  } else {
+    k_candidates<false><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
+    k_candidates_heavy<false><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
+  }
 }
 
 void fgd_clip_quad(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
