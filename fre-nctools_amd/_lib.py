@@ -23,6 +23,8 @@ def lib_path():
 # every symbol include/fregrid_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
     "get_maxxgrid", "get_grid_area", "create_xgrid_2dx2d_order1", "create_xgrid_2dx2d_order2", "conserve_interp",
+    "clip_2dx2d", "poly_area", "poly_ctrlon", "poly_ctrlat", "fix_lon", "pimod",
+    "fg_clip_2dx2d_batch", "fg_poly_op_batch",
     "get_maxxgrid_", "get_grid_area_", "create_xgrid_2dx2d_order1_", "create_xgrid_2dx2d_order2_",
     "fg_last_error", "fg_device_count", "fg_plan_create", "fg_plan_create_dev", "fg_plan_create_empty",
     "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
@@ -42,6 +44,14 @@ def lib():
         raise ImportError(
             f"{path} not found: build the HIP extension first (make -C fre-nctools_amd/csrc, or "
             "python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes in one
+    # process break device discovery, so when torch is installed load it FIRST: the dynamic loader then
+    # resolves our libamdhip64.so.7 dependency to the copy torch already mapped (one runtime, shared
+    # device pointers and streams).  Without torch (plain C callers) the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
     dpp = C.POINTER(dp)
@@ -56,6 +66,21 @@ def lib():
     L.create_xgrid_2dx2d_order2.restype = C.c_int
     L.conserve_interp.argtypes = [C.c_int] * 4 + [dp] * 7
     L.conserve_interp.restype = None
+
+    L.clip_2dx2d.argtypes = [dp, dp, C.c_int, dp, dp, C.c_int, dp, dp]
+    L.clip_2dx2d.restype = C.c_int
+    L.poly_area.argtypes = [dp, dp, C.c_int]
+    L.poly_area.restype = C.c_double
+    L.poly_ctrlon.argtypes = [dp, dp, C.c_int, C.c_double]
+    L.poly_ctrlon.restype = C.c_double
+    L.poly_ctrlat.argtypes = [dp, dp, C.c_int]
+    L.poly_ctrlat.restype = C.c_double
+    L.fix_lon.argtypes = [dp, dp, C.c_int, C.c_double]
+    L.fix_lon.restype = C.c_int
+    L.fg_clip_2dx2d_batch.argtypes = [C.c_int, dp, dp, ip, dp, dp, ip, dp, dp, ip]
+    L.fg_clip_2dx2d_batch.restype = C.c_int
+    L.fg_poly_op_batch.argtypes = [C.c_int, C.c_int, dp, dp, ip, dp, dp]
+    L.fg_poly_op_batch.restype = C.c_int
 
     L.fg_last_error.restype = C.c_char_p
     L.fg_device_count.restype = C.c_int

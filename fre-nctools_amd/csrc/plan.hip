@@ -918,3 +918,103 @@ extern "C" void conserve_interp(int nx_src, int ny_src, int nx_dst, int ny_dst, 
   fg_plan_destroy(pl);
 }
 
+
+// ----------------------------------------------------------------------------- polygon primitives
+// Batched device versions + the single-polygon libfrencutils symbols built on them.
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  DevBuf(size_t n) { if (hipMalloc(&p, n ? n : 1) != hipSuccess) p = nullptr; }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}
+
+// lon/lat arrays are [npoly][FG_POLY_STRIDE] (= 24) host arrays; n1/n2 <= 12 vertices each.
+// n_out[p] = vertex count, 0 (empty), -1 (parallel edges: the reference is fatal here) or -2 (too many vertices).
+extern "C" int fg_clip_2dx2d_batch(int npoly, const double *lon1, const double *lat1, const int *n1,
+                                   const double *lon2, const double *lat2, const int *n2,
+                                   double *lon_out, double *lat_out, int *n_out)
+{
+  if (npoly < 0 || !lon1 || !lat1 || !n1 || !lon2 || !lat2 || !n2 || !lon_out || !lat_out || !n_out) return fail(FG_ERR_ARG, "null argument");
+  if (npoly == 0) return 0;
+  HIPCHK(hipSetDevice(b1_device()));
+  size_t nb = (size_t)npoly * FG_POLY_STRIDE * sizeof(double), ni = (size_t)npoly * sizeof(int);
+  DevBuf a(nb), b(nb), c(nb), d(nb), xo(nb), yo(nb), m1(ni), m2(ni), mo(ni);
+  if (!a.p || !b.p || !c.p || !d.p || !xo.p || !yo.p || !m1.p || !m2.p || !mo.p) return fail(FG_ERR_HIP, "out of device memory");
+  HIPCHK(hipMemcpy(a.p, lon1, nb, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(b.p, lat1, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c.p, lon2, nb, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d.p, lat2, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m1.p, n1, ni, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(m2.p, n2, ni, hipMemcpyHostToDevice));
+  fgd_poly_clip(npoly, (double *)a.p, (double *)b.p, (int *)m1.p, (double *)c.p, (double *)d.p, (int *)m2.p,
+                (double *)xo.p, (double *)yo.p, (int *)mo.p, 0);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(lon_out, xo.p, nb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(lat_out, yo.p, nb, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(n_out, mo.p, ni, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// op 0 poly_area, 1 poly_ctrlon(clon), 2 poly_ctrlat, 3 fix_lon(tlon = clon) in place (lon/lat/n updated).
+extern "C" int fg_poly_op_batch(int op, int npoly, double *lon, double *lat, int *n, const double *clon, double *result)
+{
+  if (op < 0 || op > 3 || npoly < 0 || !lon || !lat || !n) return fail(FG_ERR_ARG, "bad argument");
+  if ((op == 1 || op == 3) && !clon) return fail(FG_ERR_ARG, "clon/tlon array required");
+  if (op != 3 && !result) return fail(FG_ERR_ARG, "result array required");
+  if (npoly == 0) return 0;
+  HIPCHK(hipSetDevice(b1_device()));
+  size_t nb = (size_t)npoly * FG_POLY_STRIDE * sizeof(double), ni = (size_t)npoly * sizeof(int), nd = (size_t)npoly * sizeof(double);
+  DevBuf a(nb), b(nb), m(ni), cl(nd), r(nd);
+  if (!a.p || !b.p || !m.p || !cl.p || !r.p) return fail(FG_ERR_HIP, "out of device memory");
+  HIPCHK(hipMemcpy(a.p, lon, nb, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(b.p, lat, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(m.p, n, ni, hipMemcpyHostToDevice));
+  if (clon) HIPCHK(hipMemcpy(cl.p, clon, nd, hipMemcpyHostToDevice));
+  fgd_poly_op(op, npoly, (double *)a.p, (double *)b.p, (int *)m.p, (double *)cl.p, (double *)r.p, 0);
+  HIPCHK(hipDeviceSynchronize());
+  if (op == 3) {
+    HIPCHK(hipMemcpy(lon, a.p, nb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(lat, b.p, nb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n, m.p, ni, hipMemcpyDeviceToHost));
+  } else HIPCHK(hipMemcpy(result, r.p, nd, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// single-polygon libfrencutils symbols (create_xgrid.h:35-46, mosaic_util.h:95-101)
+extern "C" int clip_2dx2d(const double lon1_in[], const double lat1_in[], int n1_in, const double lon2_in[],
+                          const double lat2_in[], int n2_in, double lon_out[], double lat_out[])
+{
+  double a[FG_POLY_STRIDE] = {0}, b[FG_POLY_STRIDE] = {0}, c[FG_POLY_STRIDE] = {0}, d[FG_POLY_STRIDE] = {0};
+  double xo[FG_POLY_STRIDE], yo[FG_POLY_STRIDE];
+  if (n1_in > 12 || n2_in > 12 || n1_in < 1 || n2_in < 1) fatal("clip_2dx2d: this build supports 1..12 vertices per polygon");
+  for (int k = 0; k < n1_in; k++) { a[k] = lon1_in[k]; b[k] = lat1_in[k]; }
+  for (int k = 0; k < n2_in; k++) { c[k] = lon2_in[k]; d[k] = lat2_in[k]; }
+  int no = 0;
+  if (fg_clip_2dx2d_batch(1, a, b, &n1_in, c, d, &n2_in, xo, yo, &no)) fatal(fg_last_error());
+  if (no == -1) fatal("the line between <x1_0,y1_0> and  <x1_1,y1_1> should not parallel to "
+                      "the line between <x2_0,y2_0> and  <x2_1,y2_1>");
+  if (no < 0) fatal("clip_2dx2d: clipped polygon exceeds 24 vertices");
+  for (int k = 0; k < no; k++) { lon_out[k] = xo[k]; lat_out[k] = yo[k]; }
+  return no;
+}
+static double poly_single(int op, const double x[], const double y[], int n, double clon)
+{
+  double a[FG_POLY_STRIDE] = {0}, b[FG_POLY_STRIDE] = {0}, r = 0;
+  if (n < 1 || n > FG_POLY_STRIDE) fatal("polygon primitive: this build supports 1..24 vertices");
+  for (int k = 0; k < n; k++) { a[k] = x[k]; b[k] = y[k]; }
+  if (fg_poly_op_batch(op, 1, a, b, &n, &clon, &r)) fatal(fg_last_error());
+  return r;
+}
+extern "C" double poly_area(const double x[], const double y[], int n) { return poly_single(0, x, y, n, 0.0); }
+extern "C" double poly_ctrlon(const double x[], const double y[], int n, double clon) { return poly_single(1, x, y, n, clon); }
+extern "C" double poly_ctrlat(const double x[], const double y[], int n) { return poly_single(2, x, y, n, 0.0); }
+extern "C" int fix_lon(double x[], double y[], int n, double tlon)
+{
+  double a[FG_POLY_STRIDE] = {0}, b[FG_POLY_STRIDE] = {0};
+  if (n < 1 || n > 8) fatal("fix_lon: this build supports 1..8 vertices");
+  for (int k = 0; k < n; k++) { a[k] = x[k]; b[k] = y[k]; }
+  if (fg_poly_op_batch(3, 1, a, b, &n, &tlon, nullptr)) fatal(fg_last_error());
+  if (n < 0) fatal("fix_lon: vertex capacity exceeded");
+  for (int k = 0; k < n; k++) { x[k] = a[k]; y[k] = b[k]; }
+  return n;
+}
+extern "C" void pimod(double x[], int nn)
+{
+  const double PI = 3.14159265358979323846;
+  for (int i = 0; i < nn; i++) { if (x[i] < -PI) x[i] += 2.0 * PI; else if (x[i] > PI) x[i] -= 2.0 * PI; }
+}

@@ -89,3 +89,9 @@ void fgd_apply(int order, int ndst, FgCsr csr, const double *data, const double 
                double *out, double *row_sum, hipStream_t st);
 void fgd_apply_frac(int ndst, FgCsr csr, const double *data, double *out, hipStream_t st);
 void fgd_reduce_sum(const double *v, long n, double *partial, double *result, hipStream_t st);
+
+// ---- batched polygon primitives (poly_kernels.hip); polygons are rows of [npoly][FG_POLY_STRIDE]
+#define FG_POLY_STRIDE 24
+void fgd_poly_clip(int npoly, const double *lon1, const double *lat1, const int *n1, const double *lon2, const double *lat2,
+                   const int *n2, double *lon_out, double *lat_out, int *n_out, hipStream_t st);
+void fgd_poly_op(int op, int npoly, double *lon, double *lat, int *n, const double *clon, double *result, hipStream_t st);

@@ -63,6 +63,15 @@ int  create_xgrid_2dx2d_order2(const int *nlon_in, const int *nlat_in, const int
 void conserve_interp(int nx_src, int ny_src, int nx_dst, int ny_dst, const double *x_src,
                      const double *y_src, const double *x_dst, const double *y_dst,
                      const double *mask_src, const double *data_src, double *data_dst);
+/* single-polygon primitives (create_xgrid.h:35-46, mosaic_util.h): same signatures as the reference;
+ * each call is one tiny device launch -- use the *_batch forms below for volume */
+int    clip_2dx2d(const double lon1_in[], const double lat1_in[], int n1_in, const double lon2_in[],
+                  const double lat2_in[], int n2_in, double lon_out[], double lat_out[]);   /* create_xgrid.c:1266 */
+double poly_area(const double lon[], const double lat[], int n);                             /* mosaic_util.c:474  */
+double poly_ctrlon(const double lon[], const double lat[], int n, double clon);              /* create_xgrid.c:2170 */
+double poly_ctrlat(const double lon[], const double lat[], int n);                           /* create_xgrid.c:2096 */
+int    fix_lon(double lon[], double lat[], int n, double tlon);                              /* mosaic_util.c:667  */
+void   pimod(double x[], int nn);                                                            /* create_xgrid.c:1343 */
 /* Fortran aliases */
 int  get_maxxgrid_(void);
 void get_grid_area_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
@@ -209,6 +218,16 @@ int  fg_plan_phase_ms(fg_plan *plan, float *ms, int n);   /* [9] = mean over the
  * [2]=nxgrid, [3]=pairs whose area ratio is within 1e-9 (relative) of the 1e-6 threshold,
  * [4]=bins, [5]=bin entries.  n = capacity of stats. */
 int fg_plan_stats(const fg_plan *plan, long *stats, int n);
+
+/* Batched polygon primitives on the device.  Polygons are rows of host arrays [npoly][24];
+ * inputs have at most 12 vertices (8 for fix_lon).  fg_clip_2dx2d_batch: n_out[p] = vertex count,
+ * 0 = empty, -1 = parallel edges (fatal in the reference), -2 = more than 24 vertices.
+ * fg_poly_op_batch: op 0 poly_area, 1 poly_ctrlon (clon[p]), 2 poly_ctrlat -> result[p];
+ * op 3 fix_lon with tlon = clon[p], in place (lon/lat/n updated). */
+int fg_clip_2dx2d_batch(int npoly, const double *lon1, const double *lat1, const int *n1,
+                        const double *lon2, const double *lat2, const int *n2,
+                        double *lon_out, double *lat_out, int *n_out);
+int fg_poly_op_batch(int op, int npoly, double *lon, double *lat, int *n, const double *clon, double *result);
 
 /* ---------------------------------------------------------------- (G) ----- */
 /* Equal-distance gnomonic cubed sphere ("gnomonic_ed"), C<ni>: cell corners of the six

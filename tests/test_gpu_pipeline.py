@@ -1,0 +1,271 @@
+"""GPU parity for the whole path: setup_conserve_interp (search + centroid pass) and
+do_scalar_conserve_interp (the sweep) through the C ABI, against the CPU oracle; plus edge cases
+(regional target, curvilinear target incl. pole caps, masked/missing data, empty overlap, 1x1 grids)
+and the polygon known-answer cases of the reference's embedded test main."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+D2R = np.pi / 180
+RTOL = 1e-10
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def check_xgrid(x, o, order, finalized):
+    assert len(x["area"]) == o["n"]
+    for k in ("t_in", "i_in", "j_in", "i_out", "j_out"):
+        assert np.array_equal(x[k], o[k]), k
+    assert np.max(np.abs(x["area"] - o["area"]) / o["area"]) < RTOL
+    if order == 2 and finalized:
+        # distances are O(cell size) radians; compare against that scale (they cross zero)
+        for a, k in ((x["c1"], "di"), (x["c2"], "dj")):
+            scale = np.max(np.abs(o[k]))
+            assert np.max(np.abs(a - o[k])) < 1e-9 * scale, k
+
+
+def make_fields(ni, lon, lat, nz, order, seed=0):
+    rng = np.random.default_rng(seed)
+    h = 1 if order == 2 else 0
+    data, gx, gy = [], [], []
+    for t in range(len(lon)):
+        data.append(rng.standard_normal((nz, ni + 2 * h, ni + 2 * h)) + 5.0)
+        gx.append(rng.standard_normal((nz, ni, ni)))
+        gy.append(rng.standard_normal((nz, ni, ni)))
+    return data, gx, gy
+
+
+@pytest.mark.parametrize("order,ni,nlon,nlat", [(1, 48, 180, 90), (2, 48, 144, 90), (2, 96, 360, 180)])
+def test_setup_conserve_interp_vs_oracle(fg, gpu_ok, order, ni, nlon, nlat):
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grid_in = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    grid_out = [fg.GridConfig(nlon, nlat, lo, la)]
+    interp = [fg.InterpConfig()]
+    opcode = fg.CONSERVE_ORDER1 if order == 1 else fg.CONSERVE_ORDER2
+    fg.setup_conserve_interp(6, grid_in, 1, grid_out, interp, opcode)
+    if ni == 96:
+        assert interp[0].nxgrid == 256864                 # BASELINE.md §2 (reference count)
+        earth = 4 * np.pi * 6371000.0 ** 2
+        assert abs(np.sum(interp[0].area) / earth - 0.999999998703791) < 1e-12   # reference closure, BASELINE.md §2
+        return                                            # full-list comparison: C48 cases (oracle brute force is O(N^2))
+    o = orc.orc_setup(order, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
+    x = dict(t_in=interp[0].t_in, i_in=interp[0].i_in, j_in=interp[0].j_in, i_out=interp[0].i_out,
+             j_out=interp[0].j_out, area=interp[0].area, c1=interp[0].di_in, c2=interp[0].dj_in)
+    check_xgrid(x, o, order, True)
+    expected_total = {(1, 180): 63752, (2, 144): 55904}[(order, nlon)]
+    assert interp[0].nxgrid == expected_total
+    for t in range(6):
+        assert np.max(np.abs(grid_in[t].cell_area - o["cell_area_in"][t]) / o["cell_area_in"][t]) < RTOL
+
+
+@pytest.mark.parametrize("order,nz,has_missing", [(1, 1, False), (1, 3, False), (2, 1, False), (2, 4, False), (1, 1, True), (2, 1, True)])
+def test_sweep_bitwise_with_oracle_weights(fg, gpu_ok, order, nz, has_missing):
+    """Feed the ORACLE's exchange cells to the device sweep: the CSR row order reproduces the reference's
+    summation order, so the remapped field is bit-identical (bar: 1e-6 relative)."""
+    import torch
+    ni, nlon, nlat = 24, 72, 36
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    o = orc.orc_setup(order, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
+    data, gx, gy = make_fields(ni, lon, lat, nz, order, seed=order * 10 + nz)
+    missing = 1.0e20
+    gm = None
+    if has_missing:
+        h = 1 if order == 2 else 0
+        for t in range(6):
+            m = ((np.add.outer(np.arange(ni + 2 * h), np.arange(ni + 2 * h)) % 10) == 0)
+            data[t][0][m] = missing
+        gm = [((np.add.outer(np.arange(ni), np.arange(ni)) % 7) == 0).astype(np.int32) for _ in range(6)]
+    plan = fg.XgridPlan.create_empty(order, [ni] * 6, [ni] * 6, nlon, nlat)
+    plan.set_xgrid(o["t_in"], o["i_in"], o["j_in"], o["i_out"], o["j_out"], o["area"], o.get("di"), o.get("dj"))
+    dev = "cuda:0"
+    pack = lambda arrs: torch.from_numpy(np.ascontiguousarray(np.stack(
+        [np.concatenate([a[k].ravel() for a in arrs]) for k in range(nz)]))).to(dev)
+    d_t = pack(data)
+    gx_t = pack(gx) if order == 2 else None
+    gy_t = pack(gy) if order == 2 else None
+    gm_t = torch.from_numpy(np.concatenate([g.ravel() for g in gm])).to(dev) if (gm is not None and order == 2) else None
+    out_t = torch.empty(nz * nlon * nlat, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    gs = plan.apply(d_t, out_t, nz=nz, grad_x_t=gx_t, grad_y_t=gy_t, grad_mask_t=gm_t, has_missing=has_missing,
+                    missing=missing, want_gsum=True)
+    plan.sync()
+    out = out_t.cpu().numpy()
+    ref, gs_ref = orc.orc_apply(order, o, [ni] * 6, [ni] * 6, [d.reshape(nz, -1) for d in data],
+                                [g.reshape(nz, -1) for g in gx] if order == 2 else None,
+                                [g.reshape(nz, -1) for g in gy] if order == 2 else None,
+                                gm if order == 2 else None, has_missing, missing, nlon, nlat, nz)
+    assert np.array_equal(_bits(out), _bits(ref))
+    assert abs(gs - gs_ref) <= 1e-12 * abs(gs_ref)
+    plan.destroy()
+
+
+def test_end_to_end_mirror_api_and_conservation(fg, gpu_ok, capsys):
+    """setup_conserve_interp + do_scalar_conserve_interp with --check_conserve (the flow of
+    tests/fregrid/cubedsphere: C48 -> 144x90, conserve_order2)."""
+    ni, nlon, nlat = 48, 144, 90
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grid_in = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    grid_out = [fg.GridConfig(nlon, nlat, lo, la)]
+    interp = [fg.InterpConfig()]
+    opcode = fg.CONSERVE_ORDER2 | fg.CHECK_CONSERVE
+    fg.setup_conserve_interp(6, grid_in, 1, grid_out, interp, opcode)
+    import gridutil
+    field_in, var = [], fg.VarConfig(name="tvar", interp_method=fg.CONSERVE_ORDER2)
+    for t in range(6):
+        lc, tc = gridutil.cell_centres(lon[t], lat[t])
+        f = 2.0 + 0.1 * gridutil.analytic_field(lc, tc)          # 2 + sin(lon+lat), positive
+        field_in.append(fg.FieldConfig(data=np.pad(f, 1, mode="edge")[None], grad_x=(np.cos(lc + tc) * np.ones_like(f))[None],
+                                       grad_y=(np.cos(lc + tc))[None], var=[var]))
+    field_out = [fg.FieldConfig()]
+    gsum_in, gsum_out = fg.do_scalar_conserve_interp(interp, 0, 6, grid_in, 1, grid_out, field_in, field_out, opcode, 1)
+    txt = capsys.readouterr().out
+    assert "the flux(data*area) sum of tvar: input = " in txt            # conserve_interp.c:904
+    assert abs(gsum_out - gsum_in) / abs(gsum_in) < 5e-9                  # the reference's own closure is ~1e-9
+    # against the oracle with the oracle's weights: same fields to 1e-6 relative (north_star), in practice ~1e-13
+    o = orc.orc_setup(2, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
+    ref, gs_ref = orc.orc_apply(2, o, [ni] * 6, [ni] * 6, [f.data.reshape(1, -1) for f in field_in],
+                                [f.grad_x.reshape(1, -1) for f in field_in], [f.grad_y.reshape(1, -1) for f in field_in],
+                                None, False, 0.0, nlon, nlat, 1)
+    got = field_out[0].data.ravel()
+    assert np.max(np.abs(got - ref) / np.abs(ref)) < 1e-9
+    assert abs(gsum_out - gs_ref) / abs(gs_ref) < 1e-11
+
+
+def _plan_vs_oracle(fg, order, gin, gout):
+    grids = [fg.GridConfig(nx, ny, x, y) for (nx, ny, x, y) in gin]
+    plan = fg.XgridPlan.create(order, grids, fg.GridConfig(*gout))
+    plan.finalize()
+    x = plan.get_xgrid()
+    o = orc.orc_setup(order, gin, [gout])
+    check_xgrid(x, o, order, True)
+    st = plan.stats()
+    plan.destroy()
+    return o["n"], st
+
+
+def test_regional_target_window(fg, gpu_ok):
+    """tests/fregrid/remap-file style regional window (15..65N, 230..310E), scaled down."""
+    lon, lat = fg.gnomonic_ed_corners(32)
+    lo, la = fg.latlon_corners(64, 40, 230.0, 310.0, 15.0, 65.0)
+    n, _ = _plan_vs_oracle(fg, 2, [(32, 32, lon[t], lat[t]) for t in range(6)], (64, 40, lo, la))
+    assert n > 0
+
+
+def test_curvilinear_target_with_pole_caps(fg, gpu_ok):
+    """lat-lon source -> cubed-sphere tiles as targets (2dx2d, neither side lat-lon for the clip): tile 3 has a
+    pole vertex (5-vertex cells, wide longitude boxes -> wide lists and the general clip kernel)."""
+    lon, lat = fg.gnomonic_ed_corners(16)
+    lo, la = fg.latlon_corners(90, 45)
+    for t in (0, 2, 5):
+        n, st = _plan_vs_oracle(fg, 2, [(90, 45, lo, la)], (16, 16, lon[t], lat[t]))
+        assert n > 0
+        if t == 2:
+            assert st["deferred"] > 0
+    # cubed sphere -> cubed sphere of another resolution, polar tiles
+    lon2, lat2 = fg.gnomonic_ed_corners(10)
+    n, st = _plan_vs_oracle(fg, 1, [(16, 16, lon[2], lat[2]), (16, 16, lon[5], lat[5])], (10, 10, lon2[2], lat2[2]))
+    assert n > 0
+
+
+def test_coarse_to_fine_and_fine_to_coarse(fg, gpu_ok):
+    lon, lat = fg.gnomonic_ed_corners(8)
+    lo, la = fg.latlon_corners(240, 120)
+    n1, st = _plan_vs_oracle(fg, 2, [(8, 8, lon[t], lat[t]) for t in (0, 2)], (240, 120, lo, la))
+    assert st["heavy"] > 0                      # every source cell sees hundreds of targets
+    lon, lat = fg.gnomonic_ed_corners(64)
+    lo, la = fg.latlon_corners(12, 6)
+    n2, _ = _plan_vs_oracle(fg, 2, [(64, 64, lon[t], lat[t]) for t in (1, 5)], (12, 6, lo, la))
+    assert n1 > 0 and n2 > 0
+
+
+def test_degenerate_sizes_and_empty_overlap(fg, gpu_ok):
+    lo1, la1 = fg.latlon_corners(1, 1, 10.0, 20.0, 10.0, 20.0)
+    lo2, la2 = fg.latlon_corners(1, 1, 15.0, 30.0, 5.0, 15.0)
+    n, _ = _plan_vs_oracle(fg, 2, [(1, 1, lo1, la1)], (1, 1, lo2, la2))
+    assert n == 1
+    lo3, la3 = fg.latlon_corners(4, 4, 100.0, 120.0, -40.0, -20.0)
+    plan = fg.XgridPlan.create(1, [fg.GridConfig(1, 1, lo1, la1)], fg.GridConfig(4, 4, lo3, la3))
+    assert plan.nxgrid == 0
+    plan.finalize()
+    import torch
+    d = torch.ones(1, dtype=torch.float64, device="cuda:0")
+    out = torch.empty(16, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    plan.apply(d, out, nz=1)
+    plan.sync()
+    assert np.all(out.cpu().numpy() == -1.0e20)         # untouched cells -> missing (= -MAXVAL), conserve_interp.c:838
+    plan.destroy()
+    # touching but not overlapping boxes: the reference's strict rejects drop them
+    lo4, la4 = fg.latlon_corners(1, 1, 20.0, 30.0, 10.0, 20.0)
+    plan = fg.XgridPlan.create(1, [fg.GridConfig(1, 1, lo1, la1)], fg.GridConfig(1, 1, lo4, la4))
+    assert plan.nxgrid == 0
+    plan.destroy()
+
+
+def test_conserve_interp_b1(fg, gpu_ok):
+    """interp.c:262 drop-in."""
+    lo1, la1 = fg.latlon_corners(36, 18)
+    lo2, la2 = fg.latlon_corners(20, 10)
+    rng = np.random.default_rng(3)
+    data = rng.standard_normal(36 * 18)
+    got = fg.conserve_interp(36, 18, 20, 10, lo1, la1, lo2, la2, None, data)
+    x = orc.orc_create_xgrid(1, 36, 18, 20, 10, lo1, la1, lo2, la2)
+    dst_area = np.zeros(200)
+    for n in range(x["n"]):
+        dst_area[x["j_out"][n] * 20 + x["i_out"][n]] += x["area"][n]
+    exp = np.zeros(200)
+    for n in range(x["n"]):
+        d = x["j_out"][n] * 20 + x["i_out"][n]
+        exp[d] += data[x["j_in"][n] * 36 + x["i_in"][n]] * (x["area"][n] / dst_area[d])
+    assert np.max(np.abs(got - exp)) < 1e-12
+
+
+def test_polygon_known_answers_on_device(fg, gpu_ok):
+    """Cases 15..26 of the reference's embedded test main through the device clip (clip_2dx2d, fix_lon,
+    poly_area behind their libfrencutils names): vertices bit-exact, areas 1e-10."""
+    L = fg.lib()
+    dp = C.POINTER(C.c_double)
+    P = lambda v: v.ctypes.data_as(dp)
+    cases = json.load(open(os.path.join(GOLD, "clip_cases.json")))["cases"]
+    for c in cases:
+        pad = lambda v: np.array(list(v) + [0.0] * (30 - len(v)))
+        x1, y1 = pad(np.array(c["lon1_deg"]) * D2R), pad(np.array(c["lat1_deg"]) * D2R)
+        x2, y2 = pad(np.array(c["lon2_deg"]) * D2R), pad(np.array(c["lat2_deg"]) * D2R)
+        xo, yo = np.zeros(30), np.zeros(30)
+        n = L.clip_2dx2d(P(x1), P(y1), len(c["lon1_deg"]), P(x2), P(y2), len(c["lon2_deg"]), P(xo), P(yo))
+        ref = c["ref"]
+        assert n == ref["n_clip"], c["case"]
+        assert np.array_equal(_bits(xo[:n]), _bits(np.array(ref["clip_lon"])))
+        assert np.array_equal(_bits(yo[:n]), _bits(np.array(ref["clip_lat"])))
+        if n > 0 and n <= 8:
+            nf = L.fix_lon(P(xo), P(yo), n, np.pi)
+            assert nf == ref["n_out_fixed"]
+            assert np.array_equal(_bits(xo[:nf]), _bits(np.array(ref["out_lon"])))
+            a = L.poly_area(P(xo), P(yo), nf)
+            assert abs(a - ref["area_out"]) <= RTOL * ref["area_out"]
+    # ctrlon / ctrlat on a C48 polar cell against the oracle
+    lon, lat = fg.gnomonic_ed_corners(48)
+    O = orc.oracle()
+    x = np.array([lon[2, 24, 24], lon[2, 24, 25], lon[2, 25, 25], lon[2, 25, 24]] + [0.0] * 20)
+    y = np.array([lat[2, 24, 24], lat[2, 24, 25], lat[2, 25, 25], lat[2, 25, 24]] + [0.0] * 20)
+    xa, ya = x.copy(), y.copy()
+    n = L.fix_lon(P(x), P(y), 4, np.pi)
+    assert n == O.orc_fix_lon(P(xa), P(ya), 4, np.pi) == 5
+    assert np.array_equal(_bits(x[:n]), _bits(xa[:n]))
+    cl = float(np.mean(x[:n]))
+    for f_dev, f_orc, args in ((L.poly_ctrlon, O.orc_poly_ctrlon, (cl,)), (L.poly_ctrlat, O.orc_poly_ctrlat, ())):
+        a, b = f_dev(P(x), P(y), n, *args), f_orc(P(xa), P(ya), n, *args)
+        assert abs(a - b) <= 1e-10 * max(abs(b), 1e6)
