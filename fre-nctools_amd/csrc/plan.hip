@@ -368,7 +368,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   // --- compaction into canonical order
   pt.begin(PH_COMPACT);
   HIPCHK(hipMemsetAsync(pl->nacc + nsrc, 0, sizeof(int), st));
-  fgd_count_accepted(nsrc, cand_off, cand_cnt, tmp_area, pl->nacc, st);
+  fgd_count_accepted(nsrc, cand_off, cand_cnt, tmp_area, pl->nacc, stats_dev, st);
   fgd_exclusive_scan(pl->nacc, nsrc + 1, pl->xoff, scan_ws, total_dev, st);
   pt.end();
   unsigned long long nx64 = 0, statsh[FG_NSTATS];

@@ -416,7 +416,7 @@ __device__ __forceinline__ void d_finish_pair(const double *px, const double *py
   double ratio = xarea / min_area;
   if (fabs(ratio - 1.e-6) < 1.e-15) atomicAdd(&stats[FG_STAT_BORDERLINE], 1ull);
   if (ratio > 1.e-6) { o->area = xarea; o->clon = clon; o->clat = clat; }
-  else o->area = -1.0;
+  else o->area = -2.0;                                         // non-empty clip, below the area threshold
 }
 
 #define CLIP_THREADS 256
@@ -511,7 +511,6 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const in
   if (parallel) atomicOr(err, G_ERRBIT_PARALLEL);
   ClipOut o; o.area = -1.0; o.clon = 0; o.clat = 0;
   if (n_cur > 0) {
-    atomicAdd(&stats[FG_STAT_NONEMPTY], 1ull);
     const double *px = (const double *)&sh_poly[0][tid];
     d_finish_pair<ORDER, 2 * CLIP_THREADS>(px, px + 1, n_cur, mask ? mask[s] : 1.0, S.area[s], D.area[d],
                                             lon_in_avg, &o, stats);
@@ -602,7 +601,6 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
     if (parallel) atomicOr(err, G_ERRBIT_PARALLEL);
     ClipOut o; o.area = -1.0; o.clon = 0; o.clat = 0;
     if (n_cur > 0) {
-      atomicAdd(&stats[FG_STAT_NONEMPTY], 1ull);
       const double *px = (const double *)&cur[0][tid];
       d_finish_pair<ORDER, 2 * GEN_THREADS>(px, px + 1, n_cur, mask ? mask[s] : 1.0, S.area[s], D.area[d],
                                             lon_in_avg, &o, stats);
@@ -615,14 +613,24 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
 // ---------------------------------------------------------------------------------------
 // compaction into canonical order
 // ---------------------------------------------------------------------------------------
+// tmp_area[p]: >= 0 accepted exchange cell, -1 empty clip, -2 non-empty clip below the 1e-6 area ratio.
+// One atomic per block for the statistics (a per-wave atomic on one word would serialise at ~12 ns each).
 __global__ __launch_bounds__(256) void k_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt,
-                                                         const double *tmp_area, int *nacc)
+                                                         const double *tmp_area, int *nacc, unsigned long long *stats)
 {
+  __shared__ unsigned sh_cnt;
+  if (threadIdx.x == 0) sh_cnt = 0;
+  __syncthreads();
   int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nsrc) return;
-  int o = cand_off[s], c = cand_cnt[s], a = 0;
-  for (int k = 0; k < c; k++) a += (tmp_area[o + k] >= 0.0) ? 1 : 0;
-  nacc[s] = a;
+  int a = 0, ne = 0;
+  if (s < nsrc) {
+    int o = cand_off[s], c = cand_cnt[s];
+    for (int k = 0; k < c; k++) { double v = tmp_area[o + k]; a += (v >= 0.0) ? 1 : 0; ne += (v != -1.0) ? 1 : 0; }
+    nacc[s] = a;
+  }
+  if (ne) atomicAdd(&sh_cnt, (unsigned)ne);
+  __syncthreads();
+  if (threadIdx.x == 0 && sh_cnt) atomicAdd(&stats[FG_STAT_NONEMPTY], (unsigned long long)sh_cnt);
 }
 
 template <int ORDER>
@@ -750,9 +758,10 @@ void fgd_clip_general(int order, int npairs, const int *pair_src, const int *pai
     k_clip_general<1><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
 }
 
-void fgd_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt, const double *tmp_area, int *nacc, hipStream_t st)
+void fgd_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt, const double *tmp_area, int *nacc,
+                        unsigned long long *stats, hipStream_t st)
 {
-  if (nsrc > 0) k_count_accepted<<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, cand_off, cand_cnt, tmp_area, nacc);
+  if (nsrc > 0) k_count_accepted<<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, cand_off, cand_cnt, tmp_area, nacc, stats);
 }
 
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
