@@ -175,16 +175,31 @@ def main():
         p.apply(data_t, out_t, nz=nz, grad_x_t=gx_t, grad_y_t=gy_t)
     torch.cuda.synchronize(); barrier()
     dta = time.perf_counter() - ta
+    apply_call_ms = p.phase_ms()["apply"]            # device time of one level-major call (2 transposes + sweep)
+    # the sweep kernel alone, on fields kept interleaved [cell][nz]
+    nb = 8 if nz >= 8 else (4 if nz >= 4 else 2)
+    il = lambda t, n: t[:nb].reshape(nb, n).t().contiguous()
+    data_il, gx_il, gy_il = il(data_t, data_t.shape[1]), il(gx_t, ncell_in), il(gy_t, ncell_in)
+    out_il = torch.empty(ny_band * nlon, nb, dtype=torch.float64, device=dev)
+    for _ in range(3):
+        p.apply_interleaved(nb, data_il, out_il, gx_il, gy_il)
+    p.phase_ms()
+    barrier(); torch.cuda.synchronize()
+    tb = time.perf_counter()
+    for _ in range(apply_steps):
+        p.apply_interleaved(nb, data_il, out_il, gx_il, gy_il)
+    torch.cuda.synchronize(); barrier()
+    dtb = time.perf_counter() - tb
     apply_kernel_ms = p.phase_ms()["apply"]
     gsum_out = p.apply(data_t, out_t, nz=1, grad_x_t=gx_t, grad_y_t=gy_t, want_gsum=True)
 
     # ---- reductions over ranks
-    red = torch.tensor([dt, dta], dtype=torch.float64, device=dev)
+    red = torch.tensor([dt, dta, dtb], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(nx_local), float(gsum_out)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt, dta = float(red[0]), float(red[1])
+    dt, dta, dtb = float(red[0]), float(red[1]), float(red[2])
     nx_total, gsum_out = int(tot[0].item()), float(tot[1].item())
 
     if rank == 0:
@@ -206,11 +221,11 @@ def main():
                         "the HBM-bound kernel of the path is the sweep, see roofline_apply"}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
         # sweep: weights streamed once per launch of nz levels + per level the source fields and the output
-        alg_apply = 32.0 * nx_rank0 + nz * (24.0 * ncell_in + 8.0 * nlon * ny_band)
-        roof_a = {"kernel": "k_apply<2,false>", "bound": "hbm",
+        alg_apply = 32.0 * nx_rank0 + nb * (24.0 * ncell_in + 8.0 * nlon * ny_band)
+        roof_a = {"kernel": f"k_apply_il<2,{nb}>", "bound": "hbm",
                   "achieved": (alg_apply / 1e9) / (apply_kernel_ms / 1e3) if apply_kernel_ms > 0 else None,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                  "algorithmic_bytes_per_launch": alg_apply, "kernel_ms": apply_kernel_ms, "levels_per_launch": nz}
+                  "algorithmic_bytes_per_launch": alg_apply, "kernel_ms": apply_kernel_ms, "levels_per_launch": nb}
         roof_a["frac"] = roof_a["achieved"] / HBM_PEAK_GBS if roof_a["achieved"] else None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -232,7 +247,9 @@ def main():
             "config": {"workload": f"C{ni} cubed sphere (6 tiles) -> {nlon}x{nlat} lat-lon, conservative_order2: "
                                    "exchange-grid search + centroid pass + CSR build per step",
                        "nxgrid": nx_total, "parallelism": f"{world} latitude band(s) of the target, one per GPU"},
-            "remapped_points_per_s": remap_pts, "apply_ms_per_launch": dta / apply_steps * 1e3, "apply_levels": nz,
+            "remapped_points_per_s": remap_pts, "apply_ms_per_call": dta / apply_steps * 1e3, "apply_levels": nz,
+            "apply_device_ms_per_call": apply_call_ms,
+            "remapped_points_per_s_interleaved": apply_steps * ndst * nb / dtb,
             "mass_rel_err": abs(gsum_out - gsum_in) / abs(gsum_in),
             "phase_ms": phases, "search_stats": stats,
             "roofline": roof, "roofline_apply": roof_a,

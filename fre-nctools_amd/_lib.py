@@ -29,7 +29,7 @@ EXPORTS = [
     "fg_last_error", "fg_device_count", "fg_plan_create", "fg_plan_create_dev", "fg_plan_create_empty",
     "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
     "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
-    "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_stream", "fg_plan_sync",
+    "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_stream", "fg_plan_sync",
     "fg_plan_stats", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
 
@@ -117,6 +117,8 @@ def lib():
     L.fg_plan_set_xgrid.restype = C.c_int
     L.fg_plan_apply.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, dp]
     L.fg_plan_apply.restype = C.c_int
+    L.fg_plan_apply_interleaved.argtypes = [vp, C.c_int, vp, vp, vp, vp, dp]
+    L.fg_plan_apply_interleaved.restype = C.c_int
     L.fg_plan_stream.argtypes = [vp]
     L.fg_plan_stream.restype = vp
     L.fg_plan_sync.argtypes = [vp]

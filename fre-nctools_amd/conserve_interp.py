@@ -248,6 +248,15 @@ class XgridPlan:
         return g.value if want_gsum else None
 
 
+    def apply_interleaved(self, nb, data_il_t, out_il_t, grad_x_il_t=None, grad_y_il_t=None, want_gsum=False):
+        """Sweep on interleaved device tensors: data [F, nb], grads [ncells_in, nb], out [ndst, nb]."""
+        g = C.c_double(0.0)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        check(lib().fg_plan_apply_interleaved(self._h, nb, ptr(data_il_t), ptr(grad_x_il_t), ptr(grad_y_il_t),
+                                              ptr(out_il_t), C.byref(g) if want_gsum else None))
+        return g.value if want_gsum else None
+
+
 @dataclass
 class InterpConfig:
     """Interp_config (globals.h:144-158).  The arrays are host copies of the plan's exchange

@@ -50,10 +50,15 @@ __global__ __launch_bounds__(256) void k_csr_gather(long nx, const int *perm, co
   if (e >= nx) return;
   int n = perm[e];
   int s = x_src[n];
-  csr.idx_g[e] = s;
-  csr.idx_f[e] = src_idx_f[s];
-  csr.area[e] = x_area[n];
-  if (ORDER == 2) { csr.di[e] = x_c1[n]; csr.dj[e] = x_c2[n]; }
+  if (ORDER == 2) {
+    FgCsrEntry2 E;
+    E.idx_f = src_idx_f[s]; E.idx_g = s; E.area = x_area[n]; E.di = x_c1[n]; E.dj = x_c2[n];
+    csr.e2[e] = E;
+  } else {
+    FgCsrEntry1 E;
+    E.idx_f = src_idx_f[s]; E.pad = 0; E.area = x_area[n];
+    csr.e1[e] = E;
+  }
 }
 
 // index of source cell s inside one level of the field array: order 1 fields have no halo
@@ -70,42 +75,118 @@ __global__ __launch_bounds__(256) void k_src_field_index(int order, const FgTile
   src_idx_f[s] = foff + (j + 1) * (tiles[t].nx + 2) + i + 1;
 }
 
-// one thread per (destination cell, level)
-template <int ORDER, bool MISSING>
-__global__ __launch_bounds__(256) void k_apply(int ndst, FgCsr csr, const double *data, const double *gx, const double *gy,
-                                                const int *gmask, double missing, long f_stride, long g_stride,
-                                                double *out, double *row_sum)
+// Blocks are dealt round-robin to the 8 XCDs (block b and b+8 share an L2).  Remap so that each XCD
+// sweeps one contiguous band of destination rows: neighbouring destination cells share source cells,
+// and this keeps those gathers inside one XCD's L2 (speed only; any placement is correct).
+__device__ __forceinline__ int d_xcd_block(int b, int nb)
 {
-  int d = blockIdx.x * blockDim.x + threadIdx.x;
-  int k = blockIdx.y;
+  int per = nb >> 3;
+  if (per == 0 || b >= (per << 3)) return b;
+  return (b & 7) * per + (b >> 3);
+}
+
+// Single level, level-major fields (also the has_missing path): one thread per destination cell.
+template <int ORDER, bool MISSING>
+__global__ __launch_bounds__(256) void k_apply1(int ndst, FgCsr csr, const double *f, const double *px, const double *py,
+                                                 const int *gmask, double missing, double *out, double *row_sum)
+{
+  int d = d_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   if (d >= ndst) return;
-  const double *f = data + (size_t)k * f_stride;
-  const double *px = (ORDER == 2) ? gx + (size_t)k * g_stride : nullptr;
-  const double *py = (ORDER == 2) ? gy + (size_t)k * g_stride : nullptr;
   int b = csr.row_ptr[d], e = csr.row_ptr[d + 1];
   double acc = 0.0, asum = 0.0;
   int touched = 0;
   for (int q = b; q < e; q++) {
-    double a = csr.area[q];
-    double v = f[csr.idx_f[q]];
-    if (MISSING) { if (v == missing) continue; }
+    double a, v;
     if (ORDER == 2) {
-      int g = csr.idx_g[q];
+      const FgCsrEntry2 E = csr.e2[q];
+      a = E.area; v = f[E.idx_f];
+      if (MISSING) { if (v == missing) continue; }
       bool flatgrad = false;
-      if (MISSING) flatgrad = gmask[g] != 0;
-      if (!flatgrad) v = (v + px[g] * csr.di[q] + py[g] * csr.dj[q]);
+      if (MISSING) flatgrad = gmask[E.idx_g] != 0;
+      if (!flatgrad) v = (v + px[E.idx_g] * E.di + py[E.idx_g] * E.dj);
+    } else {
+      const FgCsrEntry1 E = csr.e1[q];
+      a = E.area; v = f[E.idx_f];
+      if (MISSING) { if (v == missing) continue; }
     }
     acc += v * a;
     asum += a;
     touched = 1;
   }
-  size_t o = (size_t)k * ndst + d;
-  if (row_sum) row_sum[o] = (asum > 0) ? acc : 0.0;          // conserve_interp.c:815-819
+  if (row_sum) row_sum[d] = (asum > 0) ? acc : 0.0;           // conserve_interp.c:815-819
   double r;                                                   // :831-839
   if (asum > 0) r = acc / asum;
   else if (touched) r = 0.0;
   else r = missing;
-  out[o] = r;
+  out[d] = r;
+}
+
+// NB levels at once, fields interleaved [cell][NB]: every CSR entry is read once for NB levels and
+// each gather is NB*8 contiguous bytes (a full 64-byte sector for NB = 8).  No missing values
+// (the reference forbids has_missing with nz > 1, conserve_interp.c:544).
+template <int ORDER, int NB>
+__global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const double *f, const double *px, const double *py,
+                                                   double missing, double *out, double *row_sum)
+{
+  int d = d_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  if (d >= ndst) return;
+  int b = csr.row_ptr[d], e = csr.row_ptr[d + 1];
+  double acc[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) acc[k] = 0.0;
+  double asum = 0.0;
+  for (int q = b; q < e; q++) {
+    if (ORDER == 2) {
+      const FgCsrEntry2 E = csr.e2[q];
+      const double *fv = f + (size_t)E.idx_f * NB, *gxv = px + (size_t)E.idx_g * NB, *gyv = py + (size_t)E.idx_g * NB;
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        double v = (fv[k] + gxv[k] * E.di + gyv[k] * E.dj);
+        acc[k] += v * E.area;
+      }
+      asum += E.area;
+    } else {
+      const FgCsrEntry1 E = csr.e1[q];
+      const double *fv = f + (size_t)E.idx_f * NB;
+#pragma unroll
+      for (int k = 0; k < NB; k++) acc[k] += fv[k] * E.area;
+      asum += E.area;
+    }
+  }
+  const bool touched = e > b;
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    if (row_sum) row_sum[(size_t)d * NB + k] = (asum > 0) ? acc[k] : 0.0;
+    double r;
+    if (asum > 0) r = acc[k] / asum;
+    else if (touched) r = 0.0;
+    else r = missing;
+    out[(size_t)d * NB + k] = r;
+  }
+}
+
+// [nb][n] (level-major, row stride ld) <-> [n][NB] interleaved
+template <int NB>
+__global__ __launch_bounds__(256) void k_interleave(long n, const double *in, long ld, int nb, double *out)
+{
+  long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double v[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) v[k] = (k < nb) ? in[(size_t)k * ld + c] : 0.0;
+#pragma unroll
+  for (int k = 0; k < NB; k++) out[(size_t)c * NB + k] = v[k];
+}
+template <int NB>
+__global__ __launch_bounds__(256) void k_deinterleave(long n, const double *in, long ld, int nb, double *out)
+{
+  long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double v[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) v[k] = in[(size_t)c * NB + k];
+#pragma unroll
+  for (int k = 0; k < NB; k++) if (k < nb) out[(size_t)k * ld + c] = v[k];
 }
 
 // interp.c:262-305 (conserve_interp): weights are xarea / (sum of xarea in the destination cell)
@@ -115,10 +196,10 @@ __global__ __launch_bounds__(256) void k_apply_frac(int ndst, FgCsr csr, const d
   if (d >= ndst) return;
   int b = csr.row_ptr[d], e = csr.row_ptr[d + 1];
   double asum = 0.0, acc = 0.0;
-  for (int q = b; q < e; q++) asum += csr.area[q];
+  for (int q = b; q < e; q++) asum += csr.e1[q].area;
   for (int q = b; q < e; q++) {
-    double frac = csr.area[q] / asum;
-    acc += data[csr.idx_f[q]] * frac;
+    double frac = csr.e1[q].area / asum;
+    acc += data[csr.e1[q].idx_f] * frac;
   }
   out[d] = acc;
 }
@@ -170,19 +251,51 @@ void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsr
 {
   if (nsrc > 0) k_src_field_index<<<nblk(nsrc, 256), 256, 0, st>>>(order, tiles_dev, ntiles, nsrc, src_idx_f);
 }
-void fgd_apply(int order, int ndst, FgCsr csr, const double *data, const double *gx, const double *gy,
-               const int *gmask, int has_missing, double missing, int nz, long f_stride, long g_stride,
-               double *out, double *row_sum, hipStream_t st)
+void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, const int *gmask,
+                int has_missing, double missing, double *out, double *row_sum, hipStream_t st)
 {
-  if (ndst <= 0 || nz <= 0) return;
-  dim3 grid(nblk(ndst, 256), nz);
+  if (ndst <= 0) return;
+  int grid = nblk(ndst, 256);
   if (order == 2) {
-    if (has_missing) k_apply<2, true><<<grid, 256, 0, st>>>(ndst, csr, data, gx, gy, gmask, missing, f_stride, g_stride, out, row_sum);
-    else             k_apply<2, false><<<grid, 256, 0, st>>>(ndst, csr, data, gx, gy, gmask, missing, f_stride, g_stride, out, row_sum);
+    if (has_missing) k_apply1<2, true><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, gmask, missing, out, row_sum);
+    else             k_apply1<2, false><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, gmask, missing, out, row_sum);
   } else {
-    if (has_missing) k_apply<1, true><<<grid, 256, 0, st>>>(ndst, csr, data, gx, gy, gmask, missing, f_stride, g_stride, out, row_sum);
-    else             k_apply<1, false><<<grid, 256, 0, st>>>(ndst, csr, data, gx, gy, gmask, missing, f_stride, g_stride, out, row_sum);
+    if (has_missing) k_apply1<1, true><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, gmask, missing, out, row_sum);
+    else             k_apply1<1, false><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, gmask, missing, out, row_sum);
   }
+}
+
+template <int NB>
+static void apply_il_nb(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
+                        double *out, double *row_sum, hipStream_t st)
+{
+  int grid = nblk(ndst, 256);
+  if (order == 2) k_apply_il<2, NB><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum);
+  else            k_apply_il<1, NB><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum);
+}
+// nb in {2, 4, 8}: interleaved fields [cell][nb]
+void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
+                  double *out, double *row_sum, hipStream_t st)
+{
+  if (ndst <= 0) return;
+  if (nb == 8) apply_il_nb<8>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st);
+  else if (nb == 4) apply_il_nb<4>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st);
+  else apply_il_nb<2>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st);
+}
+// level-major [nb_valid][n] (row stride ld) -> interleaved [n][nb_pad] (zero padded), and back
+void fgd_interleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st)
+{
+  if (n <= 0) return;
+  if (nb_pad == 8) k_interleave<8><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+  else if (nb_pad == 4) k_interleave<4><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+  else k_interleave<2><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+}
+void fgd_deinterleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st)
+{
+  if (n <= 0) return;
+  if (nb_pad == 8) k_deinterleave<8><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+  else if (nb_pad == 4) k_deinterleave<4><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+  else k_deinterleave<2><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
 }
 void fgd_apply_frac(int ndst, FgCsr csr, const double *data, double *out, hipStream_t st)
 {

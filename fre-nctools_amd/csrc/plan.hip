@@ -162,6 +162,7 @@ struct fg_plan {
   int *src_idx_f = nullptr;
   double *row_sum = nullptr, *red_partial = nullptr, *red_result = nullptr;
   long row_sum_cap = 0;
+  double *il_f = nullptr, *il_gx = nullptr, *il_gy = nullptr, *il_out = nullptr, *il_rs = nullptr;   // [cell][8] scratch
   long stats[FG_NSTATS] = {0};
 
   template <typename T> T *alloc(size_t count)
@@ -587,11 +588,10 @@ static int build_csr(fg_plan *pl)
   unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(ndst + 1));
   unsigned long long *total_dev = pl->alloc<unsigned long long>(4);
   pl->csr.row_ptr = pl->alloc<int>(ndst + 1);
-  pl->csr.idx_f = pl->alloc<int>(nx + 1); pl->csr.idx_g = pl->alloc<int>(nx + 1);
-  pl->csr.area = pl->alloc<double>(nx + 1);
-  if (pl->order == 2) { pl->csr.di = pl->alloc<double>(nx + 1); pl->csr.dj = pl->alloc<double>(nx + 1); }
-  if (!row_cnt || !perm || !scan_ws || !total_dev || !pl->csr.row_ptr || !pl->csr.idx_f || !pl->csr.idx_g || !pl->csr.area ||
-      (pl->order == 2 && (!pl->csr.di || !pl->csr.dj))) return fail(FG_ERR_HIP, "out of device memory");
+  if (pl->order == 2) pl->csr.e2 = pl->alloc<FgCsrEntry2>(nx + 1);
+  else pl->csr.e1 = pl->alloc<FgCsrEntry1>(nx + 1);
+  if (!row_cnt || !perm || !scan_ws || !total_dev || !pl->csr.row_ptr || (!pl->csr.e1 && !pl->csr.e2))
+    return fail(FG_ERR_HIP, "out of device memory");
   HIPCHK(hipMemsetAsync(row_cnt, 0, (ndst + 1) * sizeof(int), st));
   fgd_csr_count(nx, pl->x_dst, row_cnt, st);
   fgd_exclusive_scan(row_cnt, ndst + 1, pl->csr.row_ptr, scan_ws, total_dev, st);
@@ -602,7 +602,7 @@ static int build_csr(fg_plan *pl)
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
   pl->release(row_cnt); pl->release(perm); pl->release(scan_ws); pl->release(total_dev);
-  if (!pl->red_partial) { pl->red_partial = pl->alloc<double>(1024); pl->red_result = pl->alloc<double>(4); }
+  if (!pl->red_partial) { pl->red_partial = pl->alloc<double>(1024); pl->red_result = pl->alloc<double>(260); }
   if (!pl->red_partial || !pl->red_result) return fail(FG_ERR_HIP, "out of device memory");
   return 0;
 }
@@ -767,6 +767,21 @@ extern "C" int fg_plan_set_xgrid(fg_plan *pl, long nxgrid, const int *t_in, cons
   return 0;
 }
 
+static int ensure_il_scratch(fg_plan *pl, bool want_rs)
+{
+  if (!pl->il_f) {
+    pl->il_f = pl->alloc<double>((size_t)pl->f_stride * 8);
+    pl->il_out = pl->alloc<double>((size_t)pl->ndst * 8);
+    if (pl->order == 2) { pl->il_gx = pl->alloc<double>((size_t)pl->nsrc * 8); pl->il_gy = pl->alloc<double>((size_t)pl->nsrc * 8); }
+    if (!pl->il_f || !pl->il_out || (pl->order == 2 && (!pl->il_gx || !pl->il_gy))) return fail(FG_ERR_HIP, "out of device memory");
+  }
+  if (want_rs && !pl->il_rs) {
+    pl->il_rs = pl->alloc<double>((size_t)pl->ndst * 8);
+    if (!pl->il_rs) return fail(FG_ERR_HIP, "out of device memory");
+  }
+  return 0;
+}
+
 extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad_x, const double *grad_y,
                              const int *grad_mask, int has_missing, double missing, int nz,
                              double *out, double *gsum_out)
@@ -778,26 +793,76 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
   if (pl->order == 2 && (!grad_x || !grad_y)) return fail(FG_ERR_ARG, "order 2 needs grad_x and grad_y");
   if (pl->order == 2 && has_missing && !grad_mask) return fail(FG_ERR_ARG, "order 2 with missing values needs grad_mask");
   HIPCHK(hipSetDevice(pl->device));
-  double miss = has_missing ? missing : -1.e20;                  // conserve_interp.c:541-542
-  double *rs = nullptr;
-  if (gsum_out) {
-    long need = (long)nz * pl->ndst;
-    if (need > pl->row_sum_cap) {
-      pl->release(pl->row_sum);
-      pl->row_sum = pl->alloc<double>(need);
-      if (!pl->row_sum) { pl->row_sum_cap = 0; return fail(FG_ERR_HIP, "out of device memory"); }
-      pl->row_sum_cap = need;
-    }
-    rs = pl->row_sum;
+  hipStream_t st = pl->stream;
+  const double miss = has_missing ? missing : -1.e20;            // conserve_interp.c:541-542
+  const int ndst = pl->ndst;
+  const int nchunk = (nz + 7) / 8;
+  if (nchunk > 256) return fail(FG_ERR_ARG, "nz too large for one call (max 2048 levels)");
+  if (gsum_out && pl->row_sum_cap < ndst) {
+    pl->release(pl->row_sum);
+    pl->row_sum = pl->alloc<double>(ndst);
+    if (!pl->row_sum) { pl->row_sum_cap = 0; return fail(FG_ERR_HIP, "out of device memory"); }
+    pl->row_sum_cap = ndst;
   }
-  pl->apply_pt.start(g_profiling != 0, pl->stream);
+  if (nz > 1) { int rc = ensure_il_scratch(pl, gsum_out != nullptr); if (rc) return rc; }
+  pl->apply_pt.start(g_profiling != 0, st);
   pl->apply_pt.begin(PH_APPLY);
-  fgd_apply(pl->order, pl->ndst, pl->csr, data, grad_x, grad_y, grad_mask, has_missing, miss, nz,
-            pl->f_stride, pl->nsrc, out, rs, pl->stream);
+  int nred = 0;
+  for (int k0 = 0; k0 < nz; k0 += 8) {
+    const int nbv = (nz - k0 < 8) ? nz - k0 : 8;
+    const double *f = data + (size_t)k0 * pl->f_stride;
+    const double *gx = grad_x ? grad_x + (size_t)k0 * pl->nsrc : nullptr;
+    const double *gy = grad_y ? grad_y + (size_t)k0 * pl->nsrc : nullptr;
+    double *o = out + (size_t)k0 * ndst;
+    if (nbv == 1) {
+      fgd_apply1(pl->order, ndst, pl->csr, f, gx, gy, grad_mask, has_missing, miss, o, gsum_out ? pl->row_sum : nullptr, st);
+      if (gsum_out) fgd_reduce_sum(pl->row_sum, ndst, pl->red_partial, pl->red_result + nred++, st);
+    } else {
+      const int nbp = nbv > 4 ? 8 : (nbv > 2 ? 4 : 2);
+      fgd_interleave(nbp, pl->f_stride, f, pl->f_stride, nbv, pl->il_f, st);
+      if (pl->order == 2) {
+        fgd_interleave(nbp, pl->nsrc, gx, pl->nsrc, nbv, pl->il_gx, st);
+        fgd_interleave(nbp, pl->nsrc, gy, pl->nsrc, nbv, pl->il_gy, st);
+      }
+      fgd_apply_il(pl->order, nbp, ndst, pl->csr, pl->il_f, pl->il_gx, pl->il_gy, miss, pl->il_out,
+                   gsum_out ? pl->il_rs : nullptr, st);
+      fgd_deinterleave(nbp, ndst, pl->il_out, ndst, nbv, o, st);
+      if (gsum_out) fgd_reduce_sum(pl->il_rs, (long)ndst * nbp, pl->red_partial, pl->red_result + nred++, st);
+    }
+  }
   pl->apply_pt.end();
   if (pl->apply_pt.on) pl->apply_spans++;
   if (gsum_out) {
-    fgd_reduce_sum(rs, (long)nz * pl->ndst, pl->red_partial, pl->red_result, pl->stream);
+    double parts[256];
+    HIPCHK(hipMemcpyAsync(parts, pl->red_result, nred * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double g = 0;
+    for (int k = 0; k < nred; k++) g += parts[k];
+    *gsum_out = g;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The sweep on fields the caller already keeps interleaved: data_il [F][nb], grad_x_il/grad_y_il [ncells_in][nb],
+// out_il [ndst][nb]; nb in {2, 4, 8}; no missing values.  Skips the two transposes of fg_plan_apply.
+extern "C" int fg_plan_apply_interleaved(fg_plan *pl, int nb, const double *data_il, const double *grad_x_il,
+                                         const double *grad_y_il, double *out_il, double *gsum_out)
+{
+  if (!pl || !data_il || !out_il) return fail(FG_ERR_ARG, "null argument");
+  if (!pl->finalized) return fail(FG_ERR_STATE, "fg_plan_apply_interleaved: call fg_plan_finalize first");
+  if (nb != 2 && nb != 4 && nb != 8) return fail(FG_ERR_ARG, "nb must be 2, 4 or 8");
+  if (pl->order == 2 && (!grad_x_il || !grad_y_il)) return fail(FG_ERR_ARG, "order 2 needs grad_x and grad_y");
+  HIPCHK(hipSetDevice(pl->device));
+  if (gsum_out) { int rc = ensure_il_scratch(pl, true); if (rc) return rc; }
+  pl->apply_pt.start(g_profiling != 0, pl->stream);
+  pl->apply_pt.begin(PH_APPLY);
+  fgd_apply_il(pl->order, nb, pl->ndst, pl->csr, data_il, grad_x_il, grad_y_il, -1.e20, out_il,
+               gsum_out ? pl->il_rs : nullptr, pl->stream);
+  pl->apply_pt.end();
+  if (pl->apply_pt.on) pl->apply_spans++;
+  if (gsum_out) {
+    fgd_reduce_sum(pl->il_rs, (long)pl->ndst * nb, pl->red_partial, pl->red_result, pl->stream);
     HIPCHK(hipMemcpyAsync(gsum_out, pl->red_result, sizeof(double), hipMemcpyDeviceToHost, pl->stream));
     HIPCHK(hipStreamSynchronize(pl->stream));
   }

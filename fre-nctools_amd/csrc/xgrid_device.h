@@ -73,11 +73,14 @@ void fgd_distances(long nx, int nsrc, const int *x_src, const double *x_area, co
 
 // ---- sweep (apply_kernels.hip) ----
 // CSR by destination cell: row_ptr[ndst+1]; per entry: index of the source value in the
-// field array (idx_f), in the gradient arrays (idx_g), area, di, dj.
+// field array (idx_f), in the gradient arrays (idx_g), area, di, dj -- packed per entry.
+// one packed record per entry: a lane reads its row's entries as consecutive 16/32-byte records
+struct FgCsrEntry1 { int idx_f; int pad; double area; };                       // order 1, 16 B
+struct FgCsrEntry2 { int idx_f; int idx_g; double area, di, dj; };            // order 2, 32 B
 struct FgCsr {
   int *row_ptr;
-  int *idx_f, *idx_g;
-  double *area, *di, *dj;
+  FgCsrEntry1 *e1;
+  FgCsrEntry2 *e2;
 };
 void fgd_csr_count(long nx, const int *x_dst, int *row_cnt, hipStream_t st);
 void fgd_csr_fill(long nx, const int *x_dst, const int *row_ptr, int *row_fill, int *perm, hipStream_t st);
@@ -85,9 +88,12 @@ void fgd_csr_sort_rows(int ndst, const int *row_ptr, int *perm, hipStream_t st);
 void fgd_csr_gather(int order, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
                     const double *x_c2, const int *src_idx_f, FgCsr csr, hipStream_t st);
 void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsrc, int *src_idx_f, hipStream_t st);
-void fgd_apply(int order, int ndst, FgCsr csr, const double *data, const double *gx, const double *gy,
-               const int *gmask, int has_missing, double missing, int nz, long f_stride, long g_stride,
-               double *out, double *row_sum, hipStream_t st);
+void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, const int *gmask,
+                int has_missing, double missing, double *out, double *row_sum, hipStream_t st);
+void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
+                  double *out, double *row_sum, hipStream_t st);
+void fgd_interleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st);
+void fgd_deinterleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st);
 void fgd_apply_frac(int ndst, FgCsr csr, const double *data, double *out, hipStream_t st);
 void fgd_reduce_sum(const double *v, long n, double *partial, double *result, hipStream_t st);
 

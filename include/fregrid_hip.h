@@ -201,6 +201,13 @@ int fg_plan_apply(fg_plan *plan, const double *data, const double *grad_x, const
                   const int *grad_mask, int has_missing, double missing, int nz,
                   double *out, double *gsum_out);
 
+/* The sweep on fields the caller keeps INTERLEAVED over nb in {2,4,8} levels/fields/time steps:
+ * data_il [F][nb], grad_x_il/grad_y_il [ncells_in][nb], out_il [ndst][nb] (device pointers).  Every CSR entry
+ * is read once for nb levels and each gather is nb*8 contiguous bytes; this is the layout the sweep
+ * kernel works in -- fg_plan_apply transposes level-major input into it.  No missing values. */
+int fg_plan_apply_interleaved(fg_plan *plan, int nb, const double *data_il, const double *grad_x_il,
+                              const double *grad_y_il, double *out_il, double *gsum_out);
+
 /* HIP stream the plan launches on (hipStream_t as void*), for event timing. */
 void *fg_plan_stream(fg_plan *plan);
 /* wait for everything queued on the plan's stream */

@@ -69,7 +69,8 @@ def test_setup_conserve_interp_vs_oracle(fg, gpu_ok, order, ni, nlon, nlat):
         assert np.max(np.abs(grid_in[t].cell_area - o["cell_area_in"][t]) / o["cell_area_in"][t]) < RTOL
 
 
-@pytest.mark.parametrize("order,nz,has_missing", [(1, 1, False), (1, 3, False), (2, 1, False), (2, 4, False), (1, 1, True), (2, 1, True)])
+@pytest.mark.parametrize("order,nz,has_missing", [(1, 1, False), (1, 3, False), (2, 1, False), (2, 4, False), (1, 1, True), (2, 1, True),
+                                                  (2, 2, False), (2, 8, False), (2, 11, False), (1, 9, False)])
 def test_sweep_bitwise_with_oracle_weights(fg, gpu_ok, order, nz, has_missing):
     """Feed the ORACLE's exchange cells to the device sweep: the CSR row order reproduces the reference's
     summation order, so the remapped field is bit-identical (bar: 1e-6 relative)."""
@@ -108,6 +109,13 @@ def test_sweep_bitwise_with_oracle_weights(fg, gpu_ok, order, nz, has_missing):
                                 gm if order == 2 else None, has_missing, missing, nlon, nlat, nz)
     assert np.array_equal(_bits(out), _bits(ref))
     assert abs(gs - gs_ref) <= 1e-12 * abs(gs_ref)
+    if nz in (2, 4, 8):                          # the interleaved entry point gives the same bits
+        il = lambda t: t.reshape(nz, -1).t().contiguous()
+        out_il = torch.empty(nlon * nlat, nz, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        plan.apply_interleaved(nz, il(d_t), out_il, il(gx_t) if order == 2 else None, il(gy_t) if order == 2 else None)
+        plan.sync()
+        assert np.array_equal(_bits(out_il.t().contiguous().cpu().numpy().ravel()), _bits(ref))
     plan.destroy()
 
 
