@@ -177,7 +177,7 @@ def main():
     dta = time.perf_counter() - ta
     apply_call_ms = p.phase_ms()["apply"]            # device time of one level-major call (2 transposes + sweep)
     # the sweep kernel alone, on fields kept interleaved [cell][nz]
-    nb = 8 if nz >= 8 else (4 if nz >= 4 else 2)
+    nb = 16 if nz >= 16 else (8 if nz >= 8 else (4 if nz >= 4 else 2))
     il = lambda t, n: t[:nb].reshape(nb, n).t().contiguous()
     data_il, gx_il, gy_il = il(data_t, data_t.shape[1]), il(gx_t, ncell_in), il(gy_t, ncell_in)
     out_il = torch.empty(ny_band * nlon, nb, dtype=torch.float64, device=dev)

@@ -11,6 +11,7 @@
 // HBM-bound: per level the kernel streams the CSR entries (32 B each for order 2) and
 // gathers 8..24 B per entry from the source fields (L2/Infinity-Cache resident).
 #include "xgrid_device.h"
+#include <type_traits>
 
 static inline int nblk(long n, int t) { return (int)((n + t - 1) / t); }
 
@@ -75,15 +76,11 @@ __global__ __launch_bounds__(256) void k_src_field_index(int order, const FgTile
   src_idx_f[s] = foff + (j + 1) * (tiles[t].nx + 2) + i + 1;
 }
 
-// Blocks are dealt round-robin to the 8 XCDs (block b and b+8 share an L2).  Remap so that each XCD
-// sweeps one contiguous band of destination rows: neighbouring destination cells share source cells,
-// and this keeps those gathers inside one XCD's L2 (speed only; any placement is correct).
-__device__ __forceinline__ int d_xcd_block(int b, int nb)
-{
-  int per = nb >> 3;
-  if (per == 0 || b >= (per << 3)) return b;
-  return (b & 7) * per + (b >> 3);
-}
+// Block -> destination-row mapping is the identity.  An XCD-banded remap (each XCD sweeping one
+// contiguous band of rows, cdna_hip_programming.md T1) was measured 14-19 % SLOWER here (C384 -> 0.25 deg,
+// 8/16 levels): HBM traffic already equals the algorithmic bytes (profiles/), so there is no L2 reuse to
+// win, and eight far-apart streams cost DRAM locality.
+__device__ __forceinline__ int d_xcd_block(int b, int nb) { (void)nb; return b; }
 
 // Single level, level-major fields (also the has_missing path): one thread per destination cell.
 template <int ORDER, bool MISSING>
@@ -122,47 +119,78 @@ __global__ __launch_bounds__(256) void k_apply1(int ndst, FgCsr csr, const doubl
 }
 
 // NB levels at once, fields interleaved [cell][NB]: every CSR entry is read once for NB levels and
-// each gather is NB*8 contiguous bytes (a full 64-byte sector for NB = 8).  No missing values
-// (the reference forbids has_missing with nz > 1, conserve_interp.c:544).
-template <int ORDER, int NB>
+// each gather is NB*8 contiguous bytes (a full 64-byte sector for NB = 8).  A row is served by NB/V
+// adjacent lanes, each owning V consecutive levels (V = 2: one 16-byte load per field and entry):
+// the lanes of a row read one CSR record (same address, one request) and then one contiguous
+// NB*8-byte segment per field, so a wave instruction touches 64*V/NB full segments instead of 64
+// scattered lines.  Every (row, level) sum adds in ascending exchange-cell order, exactly the
+// reference's order.  No missing values (has_missing requires nz == 1, conserve_interp.c:544).
+template <int V> struct VecD;
+template <> struct VecD<1> { double v[1]; };
+template <> struct __attribute__((aligned(16))) VecD<2> { double v[2]; };
+template <> struct __attribute__((aligned(16))) VecD<4> { double v[4]; };
+
+
+template <int ORDER, int NB, int V>
 __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const double *f, const double *px, const double *py,
                                                    double missing, double *out, double *row_sum)
 {
-  int d = d_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  constexpr int LPR = NB / V;                        // lanes per row
+  constexpr int ROWS = 256 / LPR;                    // rows per block
+  constexpr int APPLY_STAGE = ROWS * 6;              // CSR records staged in LDS (mean row has ~4)
+  typedef typename std::conditional<ORDER == 2, FgCsrEntry2, FgCsrEntry1>::type Entry;
+  __shared__ Entry sh_e[APPLY_STAGE];
+  const int lev = (threadIdx.x % LPR) * V;
+  const int d0 = d_xcd_block(blockIdx.x, gridDim.x) * ROWS;
+  const int d = d0 + threadIdx.x / LPR;
+  // the block's rows own one contiguous run of CSR records: stage it with coalesced 16-byte loads
+  const int dl = min(d0 + ROWS, ndst);
+  const int q0 = csr.row_ptr[d0], q1 = csr.row_ptr[dl];
+  {
+    const Entry *src = (ORDER == 2) ? (const Entry *)csr.e2 : (const Entry *)csr.e1;
+    const int nstage = min(q1 - q0, APPLY_STAGE);
+    constexpr int W = sizeof(Entry) / 16;            // 16-byte words per record
+    const uint4 *g = reinterpret_cast<const uint4 *>(src + q0);
+    uint4 *l = reinterpret_cast<uint4 *>(sh_e);
+    for (int i = threadIdx.x; i < nstage * W; i += 256) l[i] = g[i];
+  }
+  __syncthreads();
   if (d >= ndst) return;
-  int b = csr.row_ptr[d], e = csr.row_ptr[d + 1];
-  double acc[NB];
+  const int b = csr.row_ptr[d], e = csr.row_ptr[d + 1];
+  double acc[V], asum = 0.0;
 #pragma unroll
-  for (int k = 0; k < NB; k++) acc[k] = 0.0;
-  double asum = 0.0;
+  for (int k = 0; k < V; k++) acc[k] = 0.0;
   for (int q = b; q < e; q++) {
+    const int ql = q - q0;
     if (ORDER == 2) {
-      const FgCsrEntry2 E = csr.e2[q];
-      const double *fv = f + (size_t)E.idx_f * NB, *gxv = px + (size_t)E.idx_g * NB, *gyv = py + (size_t)E.idx_g * NB;
+      const FgCsrEntry2 E = (ql < APPLY_STAGE) ? ((const FgCsrEntry2 *)sh_e)[ql] : csr.e2[q];
+      const VecD<V> fv = *reinterpret_cast<const VecD<V> *>(f + (size_t)E.idx_f * NB + lev);
+      const VecD<V> gxv = *reinterpret_cast<const VecD<V> *>(px + (size_t)E.idx_g * NB + lev);
+      const VecD<V> gyv = *reinterpret_cast<const VecD<V> *>(py + (size_t)E.idx_g * NB + lev);
 #pragma unroll
-      for (int k = 0; k < NB; k++) {
-        double v = (fv[k] + gxv[k] * E.di + gyv[k] * E.dj);
+      for (int k = 0; k < V; k++) {
+        double v = (fv.v[k] + gxv.v[k] * E.di + gyv.v[k] * E.dj);
         acc[k] += v * E.area;
       }
       asum += E.area;
     } else {
-      const FgCsrEntry1 E = csr.e1[q];
-      const double *fv = f + (size_t)E.idx_f * NB;
+      const FgCsrEntry1 E = (ql < APPLY_STAGE) ? ((const FgCsrEntry1 *)sh_e)[ql] : csr.e1[q];
+      const VecD<V> fv = *reinterpret_cast<const VecD<V> *>(f + (size_t)E.idx_f * NB + lev);
 #pragma unroll
-      for (int k = 0; k < NB; k++) acc[k] += fv[k] * E.area;
+      for (int k = 0; k < V; k++) acc[k] += fv.v[k] * E.area;
       asum += E.area;
     }
   }
-  const bool touched = e > b;
+  VecD<V> r, rs;
 #pragma unroll
-  for (int k = 0; k < NB; k++) {
-    if (row_sum) row_sum[(size_t)d * NB + k] = (asum > 0) ? acc[k] : 0.0;
-    double r;
-    if (asum > 0) r = acc[k] / asum;
-    else if (touched) r = 0.0;
-    else r = missing;
-    out[(size_t)d * NB + k] = r;
+  for (int k = 0; k < V; k++) {
+    rs.v[k] = (asum > 0) ? acc[k] : 0.0;
+    if (asum > 0) r.v[k] = acc[k] / asum;
+    else if (e > b) r.v[k] = 0.0;
+    else r.v[k] = missing;
   }
+  if (row_sum) *reinterpret_cast<VecD<V> *>(row_sum + (size_t)d * NB + lev) = rs;
+  *reinterpret_cast<VecD<V> *>(out + (size_t)d * NB + lev) = r;
 }
 
 // [nb][n] (level-major, row stride ld) <-> [n][NB] interleaved
@@ -265,35 +293,44 @@ void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *g
   }
 }
 
-template <int NB>
+template <int NB, int V>
 static void apply_il_nb(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
                         double *out, double *row_sum, hipStream_t st)
 {
-  int grid = nblk(ndst, 256);
-  if (order == 2) k_apply_il<2, NB><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum);
-  else            k_apply_il<1, NB><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum);
+  int grid = nblk(ndst, 256 / (NB / V));
+  if (order == 2) k_apply_il<2, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum);
+  else            k_apply_il<1, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum);
 }
-// nb in {2, 4, 8}: interleaved fields [cell][nb]
+// nb in {2, 4, 8, 16}: interleaved fields [cell][nb]
+int g_apply_vec = 0;   // levels per lane: 0 = auto (4 for nb = 16, else 2; measured best on MI355X), or force 1 / 2 / 4
 void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
                   double *out, double *row_sum, hipStream_t st)
 {
   if (ndst <= 0) return;
-  if (nb == 8) apply_il_nb<8>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st);
-  else if (nb == 4) apply_il_nb<4>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st);
-  else apply_il_nb<2>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st);
+  const int v = g_apply_vec ? g_apply_vec : (nb >= 16 ? 4 : 2);
+#define AP(NB_) do { if (v >= 4 && NB_ >= 4) apply_il_nb<NB_, (NB_ >= 4 ? 4 : 2)>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st); \
+                     else if (v >= 2) apply_il_nb<NB_, 2>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st); \
+                     else apply_il_nb<NB_, 1>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st); } while (0)
+  if (nb == 16) AP(16);
+  else if (nb == 8) AP(8);
+  else if (nb == 4) AP(4);
+  else AP(2);
+#undef AP
 }
 // level-major [nb_valid][n] (row stride ld) -> interleaved [n][nb_pad] (zero padded), and back
 void fgd_interleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st)
 {
   if (n <= 0) return;
-  if (nb_pad == 8) k_interleave<8><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+  if (nb_pad == 16) k_interleave<16><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+  else if (nb_pad == 8) k_interleave<8><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
   else if (nb_pad == 4) k_interleave<4><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
   else k_interleave<2><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
 }
 void fgd_deinterleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st)
 {
   if (n <= 0) return;
-  if (nb_pad == 8) k_deinterleave<8><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+  if (nb_pad == 16) k_deinterleave<16><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+  else if (nb_pad == 8) k_deinterleave<8><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
   else if (nb_pad == 4) k_deinterleave<4><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
   else k_deinterleave<2><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
 }

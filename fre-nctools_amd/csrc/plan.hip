@@ -767,6 +767,10 @@ extern "C" int fg_plan_set_xgrid(fg_plan *pl, long nxgrid, const int *t_in, cons
   return 0;
 }
 
+extern int g_apply_vec;
+
+extern "C" void fg_set_apply_vec(int v) { g_apply_vec = (v >= 4) ? 4 : (v >= 2 ? 2 : (v == 1 ? 1 : 0)); }   // tuning hook (scripts/)
+
 static int ensure_il_scratch(fg_plan *pl, bool want_rs)
 {
   if (!pl->il_f) {
@@ -776,7 +780,7 @@ static int ensure_il_scratch(fg_plan *pl, bool want_rs)
     if (!pl->il_f || !pl->il_out || (pl->order == 2 && (!pl->il_gx || !pl->il_gy))) return fail(FG_ERR_HIP, "out of device memory");
   }
   if (want_rs && !pl->il_rs) {
-    pl->il_rs = pl->alloc<double>((size_t)pl->ndst * 8);
+    pl->il_rs = pl->alloc<double>((size_t)pl->ndst * 16);
     if (!pl->il_rs) return fail(FG_ERR_HIP, "out of device memory");
   }
   return 0;
@@ -851,7 +855,7 @@ extern "C" int fg_plan_apply_interleaved(fg_plan *pl, int nb, const double *data
 {
   if (!pl || !data_il || !out_il) return fail(FG_ERR_ARG, "null argument");
   if (!pl->finalized) return fail(FG_ERR_STATE, "fg_plan_apply_interleaved: call fg_plan_finalize first");
-  if (nb != 2 && nb != 4 && nb != 8) return fail(FG_ERR_ARG, "nb must be 2, 4 or 8");
+  if (nb != 2 && nb != 4 && nb != 8 && nb != 16) return fail(FG_ERR_ARG, "nb must be 2, 4, 8 or 16");
   if (pl->order == 2 && (!grad_x_il || !grad_y_il)) return fail(FG_ERR_ARG, "order 2 needs grad_x and grad_y");
   HIPCHK(hipSetDevice(pl->device));
   if (gsum_out) { int rc = ensure_il_scratch(pl, true); if (rc) return rc; }
