@@ -30,14 +30,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def band_rows(nlat, nranks, r):
-    """Contiguous latitude bands, sizes as mpp_compute_extent (mpp_domain.c:101-158): nearly equal."""
-    base, extra = divmod(nlat, nranks)
-    sizes = [base + (1 if k < extra else 0) for k in range(nranks)]
-    j0 = sum(sizes[:r])
-    return j0, j0 + sizes[r]
-
-
 def synth_fields(fg, lon, lat, ni, nz):
     """Deterministic smooth fields on the source tiles: f = 2 + sin(lon_c)cos(lat_c) (level-scaled),
     halo'd [nz][6*(ni+2)^2]; analytic d/dlon, d/dlat stand in for grad_c2l output."""
@@ -114,7 +106,7 @@ def main():
     ni, nlon, nlat, nz = args.ni, args.nlon, args.nlat, args.nz
     lon, lat = fg.gnomonic_ed_corners(ni)
     lo, la = fg.latlon_corners(nlon, nlat)
-    j0, j1 = band_rows(nlat, world, rank)
+    j0, j1 = fg.band_rows(nlat, world, rank)
     ny_band = j1 - j0
     lon_t = [torch.from_numpy(lon[t]).to(dev) for t in range(6)]
     lat_t = [torch.from_numpy(lat[t]).to(dev) for t in range(6)]
@@ -142,7 +134,7 @@ def main():
                                     mean_dlat, mean_dlon, device=local_rank, stream=stream)
         if world > 1:
             p.copy_cell_sums(total_sums)
-            dist.all_reduce(total_sums)
+            fg.allreduce_cell_sums(total_sums)
             p.finalize(total_sums.data_ptr())
         else:
             p.finalize(None)

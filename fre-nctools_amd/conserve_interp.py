@@ -307,9 +307,8 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
             part = torch.empty_like(total)
             p.copy_cell_sums(part)
             total += part
-        dist = torch.distributed
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(total)              # the one exchange step of the path
+        from .parallel import allreduce_cell_sums
+        allreduce_cell_sums(total)              # the one exchange step of the path
         torch.cuda.synchronize(device)
         for p in plans:
             p.finalize(total.data_ptr())
@@ -384,11 +383,8 @@ def do_scalar_conserve_interp(interp, varid, ntiles_in, grid_in, ntiles_out, gri
             d = d[:, halo:halo + ny1, halo:halo + nx1]
             ca = np.asarray(grid_in[n].cell_area).reshape(ny1, nx1)
             gsum_in += float(np.sum(np.where(d != missing, d * ca[None], 0.0)))
-        dist = torch.distributed
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            t = torch.tensor([gsum_out], dtype=torch.float64, device=dev)
-            dist.all_reduce(t)                                         # mpp_sum_double, :902
-            gsum_out = float(t.item())
+        from .parallel import allreduce_scalar_sum
+        gsum_out = allreduce_scalar_sum(gsum_out, dev)                 # mpp_sum_double, :902
         print("the flux(data*area) sum of %s: input = %g, output = %g, diff = %g. "
               % (var.name, gsum_in, gsum_out, gsum_out - gsum_in))
         return gsum_in, gsum_out

@@ -1,0 +1,35 @@
+"""Multi-GPU decomposition of the regrid job (host logic, no device code).
+
+The path shards by destination latitude band, one band per rank, exactly like the reference's
+fregrid_parallel (layout 1 x npes: tools/fregrid/fregrid_util.c:592-597; extents from
+mpp_compute_extent, tools/libfrencutils/mpp_domain.c:101-158).  The only data-path collective is the sum of
+the per-source-cell (area, clon, clat) partial sums over ranks (conserve_interp.c:203-221); torch.distributed
+provides it (backend "nccl" == RCCL over xGMI on the GPUs, "gloo" in the CPU tests).
+"""
+
+
+def band_rows(nlat, nranks, rank):
+    """Rows [j0, j1) of the destination grid owned by `rank` (nearly equal contiguous bands)."""
+    base, extra = divmod(nlat, nranks)
+    sizes = [base + (1 if k < extra else 0) for k in range(nranks)]
+    j0 = sum(sizes[:rank])
+    return j0, j0 + sizes[rank]
+
+
+def allreduce_cell_sums(total):
+    """In-place sum over ranks of the [3*ncells_in] tensor; no-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(total)
+    return total
+
+
+def allreduce_scalar_sum(value, device="cpu"):
+    """mpp_sum_double of one scalar (the global conservation sum, conserve_interp.c:902)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        return float(t.item())
+    return float(value)

@@ -1,0 +1,82 @@
+"""world_size-2 rehearsal of the N > 1 path on CPU (gloo): the destination grid is split into latitude bands
+(fre-nctools_amd/parallel.py), every rank searches its band against all source tiles -- here with the CPU oracle
+standing in for the device search -- the per-source-cell sums are all-reduced through the SAME helper the GPU
+path uses, and the finalized exchange cells of the two ranks, concatenated, must equal the single-rank result."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, initfile, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import load_package
+    import orc
+    fg = load_package()
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    ni, nlon, nlat = 12, 36, 18
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    j0, j1 = fg.band_rows(nlat, world, rank)
+    blo, bla = lo[j0:j1 + 1], la[j0:j1 + 1]
+    ncell = 6 * ni * ni
+    sums = np.zeros((3, ncell))
+    cells = []
+    for t in range(6):
+        x = orc.orc_create_xgrid(2, ni, ni, nlon, j1 - j0, lon[t], lat[t], blo, bla)
+        s = t * ni * ni + x["j_in"] * ni + x["i_in"]
+        for k, key in enumerate(("area", "clon", "clat")):
+            np.add.at(sums[k], s, x[key])
+        cells.append((s, x["j_out"] + j0, x["i_out"], x["area"], x["clon"], x["clat"]))
+    total = torch.from_numpy(sums.reshape(-1).copy())
+    fg.allreduce_cell_sums(total)                                    # the exchange step under test
+    total = total.numpy().reshape(3, ncell)
+    # centroid pass (conserve_interp.c:327-357) with the reduced sums
+    cell_area = np.concatenate([orc.orc_get_grid_area(ni, ni, lon[t], lat[t]) for t in range(6)])
+    ok = total[0] > 0
+    assert np.all(np.abs(total[0][ok] - cell_area[ok]) / cell_area[ok] < 1e-3)   # full coverage here
+    cen_lon = np.where(ok, total[1] / np.where(ok, total[0], 1), 0)
+    cen_lat = np.where(ok, total[2] / np.where(ok, total[0], 1), 0)
+    s = np.concatenate([c[0] for c in cells]); jo = np.concatenate([c[1] for c in cells]); io = np.concatenate([c[2] for c in cells])
+    area = np.concatenate([c[3] for c in cells]); cl = np.concatenate([c[4] for c in cells]); ct = np.concatenate([c[5] for c in cells])
+    di = cl / area - cen_lon[s]
+    dj = ct / area - cen_lat[s]
+    gsum = fg.allreduce_scalar_sum(float(np.sum(area)))
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), s=s, jo=jo, io=io, area=area, di=di, dj=dj, gsum=gsum, band=[j0, j1])
+    dist.destroy_process_group()
+
+
+def test_two_rank_band_decomposition_matches_single_rank(fg):
+    import torch.multiprocessing as mp
+    import orc
+    assert [fg.band_rows(720, 8, r) for r in (0, 7)] == [(0, 90), (630, 720)]
+    assert [fg.band_rows(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]      # mpp_compute_extent style
+    world = 2
+    with tempfile.TemporaryDirectory() as td:
+        initfile = os.path.join(td, "init")
+        mp.spawn(_worker, args=(world, initfile, td), nprocs=world, join=True)
+        parts = [np.load(os.path.join(td, f"rank{r}.npz")) for r in range(world)]
+    assert list(parts[0]["band"]) == [0, 9] and list(parts[1]["band"]) == [9, 18]
+    ni, nlon, nlat = 12, 36, 18
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    o = orc.orc_setup(2, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
+    key_ref = (o["t_in"].astype(np.int64) * ni * ni + o["j_in"] * ni + o["i_in"]) * nlon * nlat + o["j_out"] * nlon + o["i_out"]
+    s = np.concatenate([p["s"] for p in parts]); jo = np.concatenate([p["jo"] for p in parts]); io = np.concatenate([p["io"] for p in parts])
+    key = s.astype(np.int64) * nlon * nlat + jo * nlon + io
+    order = np.argsort(key, kind="stable")
+    assert np.array_equal(key[order], key_ref)                        # same exchange-cell set, no loss at band seams
+    area = np.concatenate([p["area"] for p in parts])[order]
+    assert np.array_equal(area.view(np.uint64), o["area"].view(np.uint64))
+    for k in ("di", "dj"):
+        v = np.concatenate([p[k] for p in parts])[order]
+        assert np.max(np.abs(v - o[k])) < 1e-12 * max(1.0, np.max(np.abs(o[k])))
+    assert abs(float(parts[0]["gsum"]) - float(np.sum(o["area"]))) < 1e-6 * np.sum(o["area"]) * 1e-6
+    assert float(parts[0]["gsum"]) == float(parts[1]["gsum"])

@@ -277,3 +277,61 @@ def test_polygon_known_answers_on_device(fg, gpu_ok):
     for f_dev, f_orc, args in ((L.poly_ctrlon, O.orc_poly_ctrlon, (cl,)), (L.poly_ctrlat, O.orc_poly_ctrlat, ())):
         a, b = f_dev(P(x), P(y), n, *args), f_orc(P(xa), P(ya), n, *args)
         assert abs(a - b) <= 1e-10 * max(abs(b), 1e6)
+
+
+def test_full_size_properties_c384(fg, gpu_ok):
+    """BASELINE.json's headline configuration (C384 -> 1440x720, order 2) at full size, checked through
+    size-independent properties (the brute-force oracle would need ~15 CPU-minutes here): the reference's
+    own counts, canonical order, area closure, partition of unity, linearity and
+    constant preservation of the sweep, and conservation."""
+    import torch
+    ni, nlon, nlat = 384, 1440, 720
+    counts = json.load(open(os.path.join(GOLD, "counts.json")))["C384->1440x720 o2"]
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    plan = fg.XgridPlan.create(2, grids, fg.GridConfig(nlon, nlat, lo, la))
+    assert plan.nxgrid == counts["total"] == 4160000
+    st = plan.stats()
+    assert st["borderline"] == 0                      # no pair within 1e-9 (relative) of the 1e-6 area threshold
+    plan.finalize()
+    x = plan.get_xgrid()
+    per_tile = np.bincount(x["t_in"], minlength=6)
+    assert list(per_tile) == [counts["tiles_1245"], counts["tiles_1245"], counts["tiles_36"], counts["tiles_1245"],
+                              counts["tiles_1245"], counts["tiles_36"]]
+    assert [int(x[k][0]) for k in ("i_in", "j_in", "i_out", "j_out")] == counts["first_xcell_tile1"]
+    assert abs(x["area"][0] - counts["first_area_tile1"]) < 1e-10 * counts["first_area_tile1"]
+    s = x["t_in"].astype(np.int64) * ni * ni + x["j_in"].astype(np.int64) * ni + x["i_in"]
+    d = x["j_out"].astype(np.int64) * nlon + x["i_out"]
+    assert np.all(np.diff(s * (nlon * nlat) + d) > 0)  # canonical order, no duplicates
+    earth = 4 * np.pi * 6371000.0 ** 2
+    assert abs(np.sum(x["area"]) / earth - 0.999999999040900) < 1e-12          # BASELINE.md §2, reference closure
+    a_in, a_out = plan.get_cell_area(nlon * nlat)
+    cov = np.bincount(d, weights=x["area"], minlength=nlon * nlat)
+    assert np.max(np.abs(cov - a_out) / a_out) < 1e-4                          # --check_conserve bound, conserve_interp.c:479
+    for arr in (x["c1"], x["c2"]):                                             # centroid distances balance per source cell
+        tot = np.bincount(s, weights=arr * x["area"], minlength=6 * ni * ni)
+        assert np.max(np.abs(tot)) < 1e-6 * np.max(a_in) * 1e-3
+    dev = "cuda:0"
+    F, ncell = 6 * (ni + 2) ** 2, 6 * ni * ni
+    g = torch.Generator(device="cpu").manual_seed(1)
+    f1 = torch.randn(F, dtype=torch.float64, generator=g); f2 = torch.randn(F, dtype=torch.float64, generator=g)
+    gx = torch.randn(ncell, dtype=torch.float64, generator=g); gy = torch.randn(ncell, dtype=torch.float64, generator=g)
+    data = torch.stack([f1, f2, 2.0 * f1 - 3.0 * f2, torch.full((F,), 7.5, dtype=torch.float64)]).to(dev)
+    gxs = torch.stack([gx, gy, 2.0 * gx - 3.0 * gy, torch.zeros(ncell, dtype=torch.float64)]).to(dev)
+    gys = torch.stack([gy, gx, 2.0 * gy - 3.0 * gx, torch.zeros(ncell, dtype=torch.float64)]).to(dev)
+    out = torch.empty(4, nlon * nlat, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    plan.apply(data, out, nz=4, grad_x_t=gxs, grad_y_t=gys)
+    plan.sync()
+    o = out.cpu().numpy()
+    assert np.max(np.abs(o[2] - (2.0 * o[0] - 3.0 * o[1]))) < 1e-11           # linearity
+    assert np.max(np.abs(o[3] - 7.5)) < 1e-14                                 # constants are preserved
+    # conservation with a positive field and zero gradient: sum(out*covered area) == sum(f*xarea)
+    pos = torch.full((1, F), 1.0, dtype=torch.float64, device=dev)
+    z = torch.zeros(1, ncell, dtype=torch.float64, device=dev)
+    o1 = torch.empty(nlon * nlat, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    gs = plan.apply(pos, o1, nz=1, grad_x_t=z, grad_y_t=z, want_gsum=True)
+    assert abs(gs - np.sum(x["area"])) < 1e-12 * gs
+    plan.destroy()
