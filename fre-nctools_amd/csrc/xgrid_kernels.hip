@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void k_cell_struct(const FgTile *tiles, int nt
 #pragma unroll
   for (int k = 1; k < 4; k++) { if (y[k] < lmin) lmin = y[k]; if (y[k] > lmax) lmax = y[k]; }
   c.lat_min[s] = lmin; c.lat_max[s] = lmax;
+  if (!(lmin >= -G_HPI - 1.e-6) || !(lmax <= G_HPI + 1.e-6)) atomicOr(err, G_ERRBIT_BADLAT);   // also catches NaN
   int n = d_fix_lon(x, y, 4, G_PI);
   if (n < 0 || n > G_MAXV) {
     atomicOr(err, G_ERRBIT_MAXV);
@@ -421,7 +422,7 @@ __device__ __forceinline__ void d_finish_pair(const double *px, const double *py
 
 #define CLIP_THREADS 256
 
-// Quad x quad fast path.  LDS: polygon [8][256] double2 (32 KiB) + cutter [4][256] double2 (16 KiB).
+// Quad x quad fast path.  LDS: polygon [8][256] double2 (32 KiB); the cutting quad lives in registers.
 template <int ORDER>
 __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const int *pair_src, const int *pair_dst,
                                                             FgCells S, const double *mask, FgCells D,
@@ -430,7 +431,6 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const in
                                                             unsigned long long *stats, unsigned *err)
 {
   __shared__ double2 sh_poly[8][CLIP_THREADS];
-  __shared__ double2 sh_cut[4][CLIP_THREADS];
   const int tid = threadIdx.x;
   int p = blockIdx.x * CLIP_THREADS + tid;
   if (p >= npairs) return;
@@ -459,15 +459,24 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const in
     for (int k = 0; k < 4; k++) { x1[k] = d_pimod1(x1[k]); x2[k] = d_pimod1(x2[k]); }
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    sh_poly[k][tid] = make_double2(x1[k], y1[k]);
-    sh_cut[k][tid] = make_double2(x2[k], y2[k]);
-  }
+  for (int k = 0; k < 4; k++) sh_poly[k][tid] = make_double2(x1[k], y1[k]);
+  // the cutting quad stays in registers; its vertex e is picked with selects (n2 <= 4)
+  // vertex e of the cutting quad, picked with bit masks (a ?: chain on e is turned into a scratch-memory
+  // table by the optimizer)
+  const long long b0x = __double_as_longlong(x2[0]), b1x = __double_as_longlong(x2[1]);
+  const long long b2x = __double_as_longlong(x2[2]), b3x = __double_as_longlong(x2[3]);
+  const long long b0y = __double_as_longlong(y2[0]), b1y = __double_as_longlong(y2[1]);
+  const long long b2y = __double_as_longlong(y2[2]), b3y = __double_as_longlong(y2[3]);
+  auto cut = [=](int e) -> double2 {
+    const long long m0 = -(long long)(e == 0), m1 = -(long long)(e == 1), m2 = -(long long)(e == 2), m3 = -(long long)(e == 3);
+    return make_double2(__longlong_as_double((b0x & m0) | (b1x & m1) | (b2x & m2) | (b3x & m3)),
+                        __longlong_as_double((b0y & m0) | (b1y & m1) | (b2y & m2) | (b3y & m3)));
+  };
   int n_cur = n1;
   bool overflow = false, parallel = false;
-  double2 e0 = sh_cut[n2 - 1][tid];
+  double2 e0 = cut(n2 - 1);
   for (int e = 0; e < n2 && n_cur > 0; e++) {
-    double2 e1 = sh_cut[e][tid];
+    double2 e1 = cut(e);
     const double x2_0 = e0.x, y2_0 = e0.y, x2_1 = e1.x, y2_1 = e1.y;
     double2 c[8];
 #pragma unroll
