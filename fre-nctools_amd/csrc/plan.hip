@@ -302,7 +302,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   const long nslots = nbins + bins.nblat;             // regular bins + one wide list per bin row
   int *bin_cnt = pl->alloc<int>(nslots + 1);
   int *bin_start = pl->alloc<int>(nslots + 1);
-  long scan_n = (nslots + 1 > (long)nsrc + 1) ? nslots + 1 : (long)nsrc + 1;
+  long scan_n = (nslots + 1 > (long)nsrc * fgd_cand_group() + 1) ? nslots + 1 : (long)nsrc * fgd_cand_group() + 1;
   if (scan_n < ndst + 1) scan_n = ndst + 1;
   unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(scan_n));
   if (!bin_cnt || !bin_start || !scan_ws) return fail(FG_ERR_HIP, "out of device memory");
@@ -323,16 +323,17 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pt.end();
 
   // --- candidate pairs
-  int *cand_cnt = pl->alloc<int>(nsrc + 1);
-  int *cand_off = pl->alloc<int>(nsrc + 1);
+  const long ncand = (long)nsrc * fgd_cand_group();      // one counter per (source cell, scan lane)
+  int *cand_cnt = pl->alloc<int>(ncand + 1);
+  int *cand_off = pl->alloc<int>(ncand + 1);
   int *heavy_list = pl->alloc<int>(nsrc + 1);
   int *heavy_cnt = pl->alloc<int>(4);
   if (!cand_cnt || !cand_off || !heavy_list || !heavy_cnt) return fail(FG_ERR_HIP, "out of device memory");
   HIPCHK(hipMemsetAsync(heavy_cnt, 0, 4 * sizeof(int), st));
   pt.begin(PH_CANDIDATES);
-  HIPCHK(hipMemsetAsync(cand_cnt + nsrc, 0, sizeof(int), st));
+  HIPCHK(hipMemsetAsync(cand_cnt + ncand, 0, sizeof(int), st));
   fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, heavy_cnt, st);
-  fgd_exclusive_scan(cand_cnt, nsrc + 1, cand_off, scan_ws, total_dev, st);
+  fgd_exclusive_scan(cand_cnt, ncand + 1, cand_off, scan_ws, total_dev, st);
   pt.end();
   unsigned long long npairs64 = 0;
   unsigned errh[4] = {0, 0, 0, 0};
@@ -358,19 +359,18 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pt.end();
 
   // --- clip, area, centroid integrals
+  HIPCHK(hipMemsetAsync(pl->nacc, 0, ((size_t)nsrc + 1) * sizeof(int), st));
   pt.begin(PH_CLIP_QUAD);
   fgd_clip_quad(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-                defer_list, defer_cnt, stats_dev, err_dev, st);
+                pl->nacc, defer_list, defer_cnt, stats_dev, err_dev, st);
   pt.end();
   pt.begin(PH_CLIP_GENERAL);
   fgd_clip_general(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-                   defer_list, defer_cnt, stats_dev, err_dev, st);
+                   pl->nacc, defer_list, defer_cnt, stats_dev, err_dev, st);
   pt.end();
 
   // --- compaction into canonical order
   pt.begin(PH_COMPACT);
-  HIPCHK(hipMemsetAsync(pl->nacc + nsrc, 0, sizeof(int), st));
-  fgd_count_accepted(nsrc, cand_off, cand_cnt, tmp_area, pl->nacc, stats_dev, st);
   fgd_exclusive_scan(pl->nacc, nsrc + 1, pl->xoff, scan_ws, total_dev, st);
   pt.end();
   unsigned long long nx64 = 0, statsh[FG_NSTATS];
@@ -390,7 +390,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   if (order == 2) { pl->x_c1 = pl->alloc<double>(pl->nx + 1); pl->x_c2 = pl->alloc<double>(pl->nx + 1); }
   if (!pl->x_src || !pl->x_dst || !pl->x_area || (order == 2 && (!pl->x_c1 || !pl->x_c2))) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_COMPACT);
-  fgd_scatter_xcells(order, npairs, pair_src, pair_dst, cand_off, cand_cnt, pl->xoff, tmp_area, tmp_clon, tmp_clat,
+  fgd_scatter_xcells(order, npairs, pair_src, pair_dst, cand_off, pl->xoff, tmp_area, tmp_clon, tmp_clat,
                      pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, st);
   pt.end();
   if (order == 2) {
@@ -406,7 +406,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms);
 
   pl->stats[FG_STAT_PAIRS] = npairs;
-  pl->stats[FG_STAT_NONEMPTY] = (long)statsh[FG_STAT_NONEMPTY];
+  pl->stats[FG_STAT_NONEMPTY] = (long)(nx64 + statsh[FG_STAT_BELOW]);
   pl->stats[FG_STAT_NXGRID] = pl->nx;
   pl->stats[FG_STAT_BORDERLINE] = (long)statsh[FG_STAT_BORDERLINE];
   pl->stats[FG_STAT_BINS] = nbins;

@@ -34,14 +34,15 @@ struct FgBinEntry {
 
 enum {
   FG_STAT_PAIRS = 0,      // candidate pairs after the bounding-box tests
-  FG_STAT_NONEMPTY = 1,   // pairs whose clip is non-empty
+  FG_STAT_NONEMPTY = 1,   // pairs whose clip is non-empty (= nxgrid + FG_STAT_BELOW)
   FG_STAT_NXGRID = 2,
   FG_STAT_BORDERLINE = 3, // |xarea/min_area - 1e-6| < 1e-15
   FG_STAT_BINS = 4,
   FG_STAT_BIN_ENTRIES = 5,
   FG_STAT_DEFERRED = 6,   // pairs handled by the general (non quad x quad) kernel
   FG_STAT_HEAVY = 7,      // source cells whose candidate scan got a whole wave
-  FG_NSTATS = 8
+  FG_STAT_BELOW = 8,      // non-empty clips rejected by the 1e-6 area ratio
+  FG_NSTATS = 10
 };
 
 int  fgd_exclusive_scan(const int *in, long n, int *out, unsigned long long *bsum_ws,
@@ -53,16 +54,15 @@ void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, co
 void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start,
                     const FgBinEntry *entries, int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
                     int *heavy_list, int *heavy_cnt, hipStream_t st);
-void fgd_clip_general(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
-              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+void fgd_clip_general(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
+              double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);
-void fgd_clip_quad(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
-              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+void fgd_clip_quad(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
+              double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);
-void fgd_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt, const double *tmp_area, int *nacc,
-                        unsigned long long *stats, hipStream_t st);
+int  fgd_cand_group(void);   // lanes per source cell in the candidate scan: cand_cnt/cand_off hold nsrc*group (+1) entries
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
-                        const int *cand_cnt, const int *xoff, const double *tmp_area, const double *tmp_clon,
+                        const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
                         hipStream_t st);
 void fgd_cell_sums(int nsrc, const int *xoff, const int *nacc, const double *x_area, const double *x_c1,

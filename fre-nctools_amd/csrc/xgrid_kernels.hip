@@ -294,17 +294,22 @@ __device__ __forceinline__ bool d_box_pass(const FgBinEntry &E, double lat_in_mi
 }
 
 #define HEAVY_ENTRIES 96
+#define CAND_G 4          // lanes per source cell in the candidate scan (one bin row each)
 
-// One lane per source cell.  FILL == false: cand_cnt[s] = number of destination cells passing the
-// rejects; cells whose query touches more than HEAVY_ENTRIES table entries are appended to
-// heavy_list instead (k_candidates_heavy gives them a whole wave).  FILL == true: write pairs.
+// CAND_G lanes per source cell, each scanning every CAND_G-th bin row of the cell's query.  Counts and
+// offsets are kept per lane (index s*CAND_G + sub) so the fill pass needs no second counting sweep:
+//   FILL == false: cand_cnt[s*G+sub] = number of destination cells passing the rejects in this lane's rows;
+//                  cells whose query touches more than HEAVY_ENTRIES table entries are appended to
+//                  heavy_list instead (k_candidates_heavy gives them a whole wave and writes cand_cnt[s*G]).
+//   FILL == true:  write the pairs at cand_off[s*G+sub]...
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const double *mask, FgBins b,
                                                      const int *slot_start, const FgBinEntry *entries,
                                                      int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
                                                      int *heavy_list, int *heavy_cnt)
 {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = (int)(t / CAND_G), sub = (int)(t % CAND_G);
   if (s >= nsrc) return;
   int cnt = 0;
   bool active = S.nv[s] > 0;
@@ -314,17 +319,20 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
     const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
     SrcQuery q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
     if (d_query_size(q, b, slot_start) > HEAVY_ENTRIES) {
-      if (!FILL) { int h = atomicAdd(heavy_cnt, 1); heavy_list[h] = s; }
-      return;                                          // cand_cnt[s] comes from the heavy kernel
+      if (!FILL) {
+        if (sub == 0) { int h = atomicAdd(heavy_cnt, 1); heavy_list[h] = s; }
+        else cand_cnt[t] = 0;                          // cand_cnt[s*G] comes from the heavy kernel
+      }
+      return;
     }
-    const int wbase = FILL ? cand_off[s] : 0;
+    const int wbase = FILL ? cand_off[t] : 0;
     const int nbins = b.nblat * b.nblon;
-    for (int r = q.ra; r <= q.rb; r++) {
+    for (int r = q.ra + sub; r <= q.rb; r += CAND_G) {
       int base = r * b.nblon;
       for (int seg = 0; seg < 2; seg++) {
+        if (seg && !q.n1) break;
         int e0 = seg ? slot_start[base] : slot_start[base + q.c_start];
         int e1 = seg ? slot_start[base + q.n1] : slot_start[base + q.c_start + q.n0];
-        if (seg && !q.n1) break;
         for (int e = e0; e < e1; e++) {
           const FgBinEntry E = entries[e];
           if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
         }
       }
     }
-    for (int r = q.r0; r <= q.r1; r++) {
+    for (int r = q.r0 + sub; r <= q.r1; r += CAND_G) {
       int e0 = slot_start[nbins + r], e1 = slot_start[nbins + r + 1];
       for (int e = e0; e < e1; e++) {
         const FgBinEntry E = entries[e];
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
       }
     }
   }
-  if (!FILL) cand_cnt[s] = cnt;
+  if (!FILL) cand_cnt[t] = cnt;
 }
 
 // One wave per heavy source cell (pole caps of the source grid: their longitude range covers
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(64) void k_candidates_heavy(FgCells S, FgBins b, co
     const double lat_in_min = S.lat_min[s], lat_in_max = S.lat_max[s];
     const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
     SrcQuery q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
-    const int wbase = FILL ? cand_off[s] : 0;
+    const int wbase = FILL ? cand_off[s * CAND_G] : 0;
     int cnt = 0;
     const int nrows_reg = q.rb - q.ra + 1, nrows_wide = q.r1 - q.r0 + 1;
     for (int it = 0; it < 2 * nrows_reg + nrows_wide; it++) {
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(64) void k_candidates_heavy(FgCells S, FgBins b, co
         cnt += __popcll(m);
       }
     }
-    if (!FILL && lane == 0) cand_cnt[s] = cnt;
+    if (!FILL && lane == 0) cand_cnt[s * CAND_G] = cnt;
   }
 }
 
@@ -423,20 +431,15 @@ __device__ __forceinline__ void d_finish_pair(const double *px, const double *py
 #define CLIP_THREADS 256
 
 // Quad x quad fast path.  LDS: polygon [8][256] double2 (32 KiB); the cutting quad lives in registers.
+// Returns false if the pair must go to the general kernel (more than 4 vertices on a side, or more than 8
+// in an intermediate polygon); otherwise *o holds the result (area >= 0 accepted, -1 empty, -2 below threshold).
 template <int ORDER>
-__global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const int *pair_src, const int *pair_dst,
-                                                            FgCells S, const double *mask, FgCells D,
-                                                            double *tmp_area, double *tmp_clon, double *tmp_clat,
-                                                            int *defer_list, int *defer_cnt,
-                                                            unsigned long long *stats, unsigned *err)
+__device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS], const int tid, const int s, const int d,
+                                                 const FgCells &S, const double *mask, const FgCells &D,
+                                                 ClipOut *o_out, unsigned long long *stats, unsigned *err)
 {
-  __shared__ double2 sh_poly[8][CLIP_THREADS];
-  const int tid = threadIdx.x;
-  int p = blockIdx.x * CLIP_THREADS + tid;
-  if (p >= npairs) return;
-  const int s = pair_src[p], d = pair_dst[p];
   const int n1 = S.nv[s], n2 = D.nv[d];
-  if (n1 > 4 || n2 > 4) { int q = atomicAdd(defer_cnt, 1); defer_list[q] = p; return; }
+  if (n1 > 4 || n2 > 4) return false;
 
   const double *sv = S.verts + (size_t)s * 16, *dv = D.verts + (size_t)d * 16;
   const double lon_in_avg = S.lon_avg[s];
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const in
     if (overflow) break;
     e0 = e1;
   }
-  if (overflow) { int q = atomicAdd(defer_cnt, 1); defer_list[q] = p; return; }
+  if (overflow) return false;
   if (parallel) atomicOr(err, G_ERRBIT_PARALLEL);
   ClipOut o; o.area = -1.0; o.clon = 0; o.clat = 0;
   if (n_cur > 0) {
@@ -524,8 +527,51 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const in
     d_finish_pair<ORDER, 2 * CLIP_THREADS>(px, px + 1, n_cur, mask ? mask[s] : 1.0, S.area[s], D.area[d],
                                             lon_in_avg, &o, stats);
   }
-  tmp_area[p] = o.area;
-  if (ORDER == 2 && o.area >= 0) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
+  *o_out = o;
+  return true;
+}
+
+// Result encoding shared by the clip kernels and the compaction: an accepted pair keeps pair_dst[p] = d and
+// gets tmp_area/clon/clat[p]; a rejected pair gets pair_dst[p] = -1.  nacc[s] counts the accepted pairs of
+// source cell s: lanes are pair-ordered, so one atomic per (wave, source cell) run does it.
+template <int ORDER>
+__global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const int *pair_src, int *pair_dst,
+                                                            FgCells S, const double *mask, FgCells D,
+                                                            double *tmp_area, double *tmp_clon, double *tmp_clat,
+                                                            int *nacc, int *defer_list, int *defer_cnt,
+                                                            unsigned long long *stats, unsigned *err)
+{
+  __shared__ double2 sh_poly[8][CLIP_THREADS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int p = blockIdx.x * CLIP_THREADS + tid;
+  int s = -1;
+  bool acc = false;
+  if (p < npairs) {
+    s = pair_src[p];
+    const int d = pair_dst[p];
+    ClipOut o;
+    if (!d_clip_quad_pair<ORDER>(sh_poly, tid, s, d, S, mask, D, &o, stats, err)) {
+      int q = atomicAdd(defer_cnt, 1); defer_list[q] = p;      // rare; the general kernel finishes this pair
+    } else if (o.area >= 0) {
+      acc = true;
+      tmp_area[p] = o.area;
+      if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
+    } else {
+      pair_dst[p] = -1;
+      if (o.area == -2.0) atomicAdd(&stats[FG_STAT_BELOW], 1ull);   // rare (slivers below the 1e-6 ratio)
+    }
+  }
+  // segmented count of accepted lanes per run of equal s inside the wave
+  const int s_prev = __shfl_up(s, 1, 64);
+  const bool head = (lane == 0) || (s != s_prev);
+  const unsigned long long hm = __ballot(head), am = __ballot(acc);
+  if (head && s >= 0) {
+    const unsigned long long above = (lane == 63) ? 0ull : (hm >> (lane + 1)) << (lane + 1);
+    const int end = above ? (__ffsll((long long)above) - 1) : 64;
+    const unsigned long long upto = (end == 64) ? ~0ull : ((1ull << end) - 1ull);
+    const int cnt = __popcll(am & upto & ~((1ull << lane) - 1ull));
+    if (cnt) atomicAdd(&nacc[s], cnt);
+  }
 }
 
 // General path: up to 8 x 8 vertices, intermediate polygons up to 16.  One wave per block,
@@ -534,9 +580,9 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const in
 #define GEN_CAP 16
 template <int ORDER>
 __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_list, const int *defer_cnt,
-                                                              const int *pair_src, const int *pair_dst,
+                                                              const int *pair_src, int *pair_dst,
                                                               FgCells S, const double *mask, FgCells D,
-                                                              double *tmp_area, double *tmp_clon, double *tmp_clat,
+                                                              double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
                                                               unsigned long long *stats, unsigned *err)
 {
   __shared__ double2 sh_a[GEN_CAP][GEN_THREADS];
@@ -606,7 +652,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
       double2 (*t)[GEN_THREADS] = cur; cur = nxt; nxt = t;
       e0 = e1;
     }
-    if (overflow) { atomicOr(err, G_ERRBIT_OVERFLOW); tmp_area[p] = -1.0; continue; }
+    if (overflow) { atomicOr(err, G_ERRBIT_OVERFLOW); pair_dst[p] = -1; continue; }
     if (parallel) atomicOr(err, G_ERRBIT_PARALLEL);
     ClipOut o; o.area = -1.0; o.clon = 0; o.clat = 0;
     if (n_cur > 0) {
@@ -614,50 +660,36 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
       d_finish_pair<ORDER, 2 * GEN_THREADS>(px, px + 1, n_cur, mask ? mask[s] : 1.0, S.area[s], D.area[d],
                                             lon_in_avg, &o, stats);
     }
-    tmp_area[p] = o.area;
-    if (ORDER == 2 && o.area >= 0) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
+    if (o.area >= 0) {
+      tmp_area[p] = o.area;
+      if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
+      atomicAdd(&nacc[s], 1);
+    } else {
+      pair_dst[p] = -1;
+      if (o.area == -2.0) atomicAdd(&stats[FG_STAT_BELOW], 1ull);
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // compaction into canonical order
 // ---------------------------------------------------------------------------------------
-// tmp_area[p]: >= 0 accepted exchange cell, -1 empty clip, -2 non-empty clip below the 1e-6 area ratio.
-// One atomic per block for the statistics (a per-wave atomic on one word would serialise at ~12 ns each).
-__global__ __launch_bounds__(256) void k_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt,
-                                                         const double *tmp_area, int *nacc, unsigned long long *stats)
-{
-  __shared__ unsigned sh_cnt;
-  if (threadIdx.x == 0) sh_cnt = 0;
-  __syncthreads();
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  int a = 0, ne = 0;
-  if (s < nsrc) {
-    int o = cand_off[s], c = cand_cnt[s];
-    for (int k = 0; k < c; k++) { double v = tmp_area[o + k]; a += (v >= 0.0) ? 1 : 0; ne += (v != -1.0) ? 1 : 0; }
-    nacc[s] = a;
-  }
-  if (ne) atomicAdd(&sh_cnt, (unsigned)ne);
-  __syncthreads();
-  if (threadIdx.x == 0 && sh_cnt) atomicAdd(&stats[FG_STAT_NONEMPTY], (unsigned long long)sh_cnt);
-}
-
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *pair_src, const int *pair_dst,
-                                                         const int *cand_off, const int *cand_cnt, const int *xoff,
+                                                         const int *cand_off, const int *xoff,
                                                          const double *tmp_area, const double *tmp_clon, const double *tmp_clat,
                                                          int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2)
 {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npairs) return;
-  double a = tmp_area[p];
-  if (!(a >= 0.0)) return;
-  int s = pair_src[p], d = pair_dst[p];
-  int o = cand_off[s], c = cand_cnt[s], rank = 0;
+  const int d = pair_dst[p];                        // -1: rejected by the clip kernels
+  if (d < 0) return;
+  const int s = pair_src[p];
+  int o = cand_off[s * CAND_G], c = cand_off[(s + 1) * CAND_G] - o, rank = 0;
   for (int k = 0; k < c; k++)                       // destination index ascending == the reference's ij loop
-    rank += (tmp_area[o + k] >= 0.0 && pair_dst[o + k] < d) ? 1 : 0;
+    rank += ((unsigned)pair_dst[o + k] < (unsigned)d) ? 1 : 0;    // rejected entries are 0xffffffff
   int pos = xoff[s] + rank;
-  x_src[pos] = s; x_dst[pos] = d; x_area[pos] = a;
+  x_src[pos] = s; x_dst[pos] = d; x_area[pos] = tmp_area[p];
   if (ORDER == 2) { x_c1[pos] = tmp_clon[p]; x_c2[pos] = tmp_clat[p]; }
 }
 
@@ -736,51 +768,47 @@ void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b
   if (nsrc <= 0) return;
   int hgrid = nblk(nsrc, 64); if (hgrid > 2048) hgrid = 2048;
   if (fill) {
-    k_candidates<true><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
+    k_candidates<true><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
     k_candidates_heavy<true><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
   } else {
-    k_candidates<false><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
+    k_candidates<false><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
     k_candidates_heavy<false><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
   }
 }
 
-void fgd_clip_quad(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
-                   double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+void fgd_clip_quad(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
+                   double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
                    unsigned long long *stats, unsigned *err, hipStream_t st)
 {
   if (npairs <= 0) return;
   if (order == 2)
-    k_clip_quad<2><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
+    k_clip_quad<2><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err);
   else
-    k_clip_quad<1><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
+    k_clip_quad<1><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err);
 }
 
-void fgd_clip_general(int order, int npairs, const int *pair_src, const int *pair_dst, FgCells S, const double *mask, FgCells D,
-                      double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+void fgd_clip_general(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
+                      double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
                       unsigned long long *stats, unsigned *err, hipStream_t st)
 {
   if (npairs <= 0) return;
   int grid = nblk(npairs, GEN_THREADS); if (grid > 1024) grid = 1024;
   if (order == 2)
-    k_clip_general<2><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
+    k_clip_general<2><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
   else
-    k_clip_general<1><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
+    k_clip_general<1><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
 }
 
-void fgd_count_accepted(int nsrc, const int *cand_off, const int *cand_cnt, const double *tmp_area, int *nacc,
-                        unsigned long long *stats, hipStream_t st)
-{
-  if (nsrc > 0) k_count_accepted<<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, cand_off, cand_cnt, tmp_area, nacc, stats);
-}
+int fgd_cand_group(void) { return CAND_G; }
 
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
-                        const int *cand_cnt, const int *xoff, const double *tmp_area, const double *tmp_clon,
+                        const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
                         hipStream_t st)
 {
   if (npairs <= 0) return;
-  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, cand_cnt, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2);
-  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, cand_cnt, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2);
+  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2);
+  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2);
 }
 
 void fgd_cell_sums(int nsrc, const int *xoff, const int *nacc, const double *x_area, const double *x_c1,
