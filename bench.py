@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--nlat", type=int, default=720)
     ap.add_argument("--nz", type=int, default=8, help="levels per sweep launch")
     ap.add_argument("--apply-steps", type=int, default=50)
+    ap.add_argument("--no-phase-timing", action="store_true", help="do not record per-phase HIP events in the timed region")
     ap.add_argument("--cpu-rows", type=int, default=32, help="source rows in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -119,7 +120,7 @@ def main():
     total_sums = torch.empty(3 * ncell_in, dtype=torch.float64, device=dev)
     mean_dlat, mean_dlon = np.pi / nlat, 2 * np.pi / nlon
     stream = torch.cuda.current_stream().cuda_stream
-    fg.lib().fg_set_profiling(1)
+    fg.lib().fg_set_profiling(0 if args.no_phase_timing else 1)
 
     def barrier():
         if world > 1:

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -155,7 +156,7 @@ struct fg_plan {
   long nx = 0;
   int *x_src = nullptr, *x_dst = nullptr;
   double *x_area = nullptr, *x_c1 = nullptr, *x_c2 = nullptr;
-  int *xoff = nullptr, *nacc = nullptr;
+  int *xoff = nullptr;
   double *sums = nullptr, *cen = nullptr;
   // sweep
   FgCsr csr{};
@@ -242,6 +243,22 @@ static void choose_bins(const fg_plan *pl, double mean_dlat, double mean_dlon, F
   b->inv_wlon = nblon / (2.0 * PI);
 }
 
+// Device-side counters of one search: one block, zeroed by one memset, read back with one copy into
+// pinned host memory at each of the three points where the host needs a count to size buffers.
+struct DevCounters {
+  unsigned long long total[4];     // [0] bin-table entries  [1] candidate pairs  [2] nxgrid
+  unsigned err[4];
+  int defer_cnt, heavy_cnt, pad0, pad1;
+  unsigned long long stats[FG_NSTATS];
+};
+
+static DevCounters *pinned_counters()
+{
+  static thread_local DevCounters *h = nullptr;
+  if (!h) { if (hipHostMalloc((void **)&h, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) h = nullptr; }
+  return h;
+}
+
 // the search proper; all grid pointers are device pointers
 static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
@@ -249,6 +266,8 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
 {
   hipStream_t st = pl->stream;
   const int nsrc = pl->nsrc, ndst = pl->ndst, order = pl->order;
+  DevCounters *hc = pinned_counters();
+  if (!hc) return fail(FG_ERR_HIP, "hipHostMalloc failed");
 
   // tile descriptors: source tiles + the destination tile as entry [ntiles]
   std::vector<FgTile> th(pl->ntiles + 1);
@@ -257,6 +276,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pl->tiles_dev = pl->alloc<FgTile>(pl->ntiles + 1);
   if (!pl->tiles_dev) return fail(FG_ERR_HIP, "out of device memory");
   HIPCHK(hipMemcpyAsync(pl->tiles_dev, th.data(), sizeof(FgTile) * th.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));          // th lives on this stack frame
 
   bool any_mask = false;
   if (d_mask_in) for (int m = 0; m < pl->ntiles; m++) if (d_mask_in[m]) any_mask = true;
@@ -275,73 +295,67 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
     }
   }
 
+  // --- bins over the destination cells (sizes known up front)
+  FgBins bins;
+  choose_bins(pl, mean_dlat, mean_dlon, &bins);
+  const long nbins = (long)bins.nblat * bins.nblon;
+  const long nslots = nbins + bins.nblat;             // regular bins + one wide list per bin row
+  const long ncand = (long)nsrc * fgd_cand_group();   // one counter per (source cell, scan lane)
+
   if (!alloc_cells(pl, &pl->S, nsrc) || !alloc_cells(pl, &pl->D, ndst)) return fail(FG_ERR_HIP, "out of device memory");
-  unsigned *err_dev = pl->alloc<unsigned>(4);
-  unsigned long long *stats_dev = pl->alloc<unsigned long long>(FG_NSTATS);
-  unsigned long long *total_dev = pl->alloc<unsigned long long>(4);
-  int *defer_cnt = pl->alloc<int>(4);
-  if (!err_dev || !stats_dev || !total_dev || !defer_cnt) return fail(FG_ERR_HIP, "out of device memory");
-  HIPCHK(hipMemsetAsync(err_dev, 0, 4 * sizeof(unsigned), st));
-  HIPCHK(hipMemsetAsync(stats_dev, 0, FG_NSTATS * sizeof(unsigned long long), st));
-  HIPCHK(hipMemsetAsync(defer_cnt, 0, 4 * sizeof(int), st));
+  // one zeroed block: [counters | bin counts | bin fill cursors | accepted-per-source-cell]
+  const size_t zc = (sizeof(DevCounters) + 15) / 16 * 16;
+  const size_t zbytes = zc + ((size_t)(2 * (nslots + 1) + nsrc + 1) * sizeof(int));
+  char *zero_blk = pl->alloc<char>(zbytes);
+  int *bin_start = pl->alloc<int>(nslots + 1);
+  long scan_n = std::max(std::max(nslots, ncand), (long)std::max(nsrc, ndst)) + 1;
+  unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(scan_n));
+  int *cand_cnt = pl->alloc<int>(ncand + 1);
+  int *cand_off = pl->alloc<int>(ncand + 1);
+  int *heavy_list = pl->alloc<int>(nsrc + 1);
+  pl->xoff = pl->alloc<int>(nsrc + 1);
+  if (!zero_blk || !bin_start || !scan_ws || !cand_cnt || !cand_off || !heavy_list || !pl->xoff) return fail(FG_ERR_HIP, "out of device memory");
+  DevCounters *dc = (DevCounters *)zero_blk;
+  int *bin_cnt = (int *)(zero_blk + zc), *bin_fill = bin_cnt + (nslots + 1), *nacc = bin_fill + (nslots + 1);
+  HIPCHK(hipMemsetAsync(zero_blk, 0, zbytes, st));
+  auto readback = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(hc, dc, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  };
 
   PhaseTimer pt, ptot;
   pt.start(g_profiling != 0, st); ptot.start(g_profiling != 0, st);
   for (int k = 0; k < PH_COUNT; k++) pl->phase_ms[k] = 0;
   ptot.begin(PH_SEARCH_TOTAL);
   pt.begin(PH_CELL_STRUCT);
-  fgd_cell_struct(pl->tiles_dev, pl->ntiles, nsrc, pl->S, err_dev, st);
-  fgd_cell_struct(pl->tiles_dev + pl->ntiles, 1, ndst, pl->D, err_dev, st);
+  fgd_cell_struct(pl->tiles_dev, pl->ntiles, nsrc, pl->S, dc->err, st);
+  fgd_cell_struct(pl->tiles_dev + pl->ntiles, 1, ndst, pl->D, dc->err, st);
   pt.end();
   pl->have_geom = true;
 
-  // --- bins over the destination cells
-  FgBins bins;
-  choose_bins(pl, mean_dlat, mean_dlon, &bins);
-  const long nbins = (long)bins.nblat * bins.nblon;
-  const long nslots = nbins + bins.nblat;             // regular bins + one wide list per bin row
-  int *bin_cnt = pl->alloc<int>(nslots + 1);
-  int *bin_start = pl->alloc<int>(nslots + 1);
-  long scan_n = (nslots + 1 > (long)nsrc * fgd_cand_group() + 1) ? nslots + 1 : (long)nsrc * fgd_cand_group() + 1;
-  if (scan_n < ndst + 1) scan_n = ndst + 1;
-  unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(scan_n));
-  if (!bin_cnt || !bin_start || !scan_ws) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_BINS);
-  HIPCHK(hipMemsetAsync(bin_cnt, 0, (nslots + 1) * sizeof(int), st));
   fgd_bin_build(false, ndst, pl->D, bins, bin_cnt, nullptr, nullptr, st);
-  fgd_exclusive_scan(bin_cnt, nslots + 1, bin_start, scan_ws, total_dev, st);
+  fgd_exclusive_scan(bin_cnt, nslots, bin_start, scan_ws, &dc->total[0], st);
   pt.end();
-  unsigned long long nentries = 0;
-  HIPCHK(hipMemcpyAsync(&nentries, total_dev, sizeof nentries, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  if (readback()) return FG_ERR_HIP;
+  if (hc->err[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
+  if (hc->err[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
+  const unsigned long long nentries = hc->total[0];
   if (nentries > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
   FgBinEntry *bin_entries = pl->alloc<FgBinEntry>(nentries ? nentries : 1);
   if (!bin_entries) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_BINS);
-  HIPCHK(hipMemsetAsync(bin_cnt, 0, (nslots + 1) * sizeof(int), st));      // reused as fill cursor
-  fgd_bin_build(true, ndst, pl->D, bins, bin_cnt, bin_start, bin_entries, st);
+  fgd_bin_build(true, ndst, pl->D, bins, bin_fill, bin_start, bin_entries, st);
   pt.end();
 
   // --- candidate pairs
-  const long ncand = (long)nsrc * fgd_cand_group();      // one counter per (source cell, scan lane)
-  int *cand_cnt = pl->alloc<int>(ncand + 1);
-  int *cand_off = pl->alloc<int>(ncand + 1);
-  int *heavy_list = pl->alloc<int>(nsrc + 1);
-  int *heavy_cnt = pl->alloc<int>(4);
-  if (!cand_cnt || !cand_off || !heavy_list || !heavy_cnt) return fail(FG_ERR_HIP, "out of device memory");
-  HIPCHK(hipMemsetAsync(heavy_cnt, 0, 4 * sizeof(int), st));
   pt.begin(PH_CANDIDATES);
-  HIPCHK(hipMemsetAsync(cand_cnt + ncand, 0, sizeof(int), st));
-  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, heavy_cnt, st);
-  fgd_exclusive_scan(cand_cnt, ncand + 1, cand_off, scan_ws, total_dev, st);
+  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, &dc->heavy_cnt, st);
+  fgd_exclusive_scan(cand_cnt, ncand, cand_off, scan_ws, &dc->total[1], st);
   pt.end();
-  unsigned long long npairs64 = 0;
-  unsigned errh[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(&npairs64, total_dev, sizeof npairs64, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(errh, err_dev, sizeof errh, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (errh[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
-  if (errh[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
+  if (readback()) return FG_ERR_HIP;
+  const unsigned long long npairs64 = hc->total[1];
   if (npairs64 > 2000000000ull) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
   const int npairs = (int)npairs64;
 
@@ -350,41 +364,39 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   double *tmp_clon = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
   double *tmp_clat = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
   int *defer_list = pl->alloc<int>(npairs + 1);
-  pl->nacc = pl->alloc<int>(nsrc + 1);
-  pl->xoff = pl->alloc<int>(nsrc + 1);
-  if (!pair_src || !pair_dst || !tmp_area || !defer_list || !pl->nacc || !pl->xoff ||
-      (order == 2 && (!tmp_clon || !tmp_clat))) return fail(FG_ERR_HIP, "out of device memory");
+  if (!pair_src || !pair_dst || !tmp_area || !defer_list || (order == 2 && (!tmp_clon || !tmp_clat)))
+    return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_CANDIDATES);
-  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, st);
+  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, &dc->heavy_cnt, st);
   pt.end();
 
-  // --- clip, area, centroid integrals
-  HIPCHK(hipMemsetAsync(pl->nacc, 0, ((size_t)nsrc + 1) * sizeof(int), st));
+  // --- clip, area, centroid integrals (+ accepted count per source cell)
   pt.begin(PH_CLIP_QUAD);
   fgd_clip_quad(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-                pl->nacc, defer_list, defer_cnt, stats_dev, err_dev, st);
+                nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
   pt.end();
   pt.begin(PH_CLIP_GENERAL);
   fgd_clip_general(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-                   pl->nacc, defer_list, defer_cnt, stats_dev, err_dev, st);
+                   nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
   pt.end();
 
   // --- compaction into canonical order
   pt.begin(PH_COMPACT);
-  fgd_exclusive_scan(pl->nacc, nsrc + 1, pl->xoff, scan_ws, total_dev, st);
+  fgd_exclusive_scan(nacc, nsrc, pl->xoff, scan_ws, &dc->total[2], st);
   pt.end();
-  unsigned long long nx64 = 0, statsh[FG_NSTATS];
-  int deferh = 0, heavyh = 0;
-  HIPCHK(hipMemcpyAsync(&heavyh, heavy_cnt, sizeof heavyh, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&nx64, total_dev, sizeof nx64, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(errh, err_dev, sizeof errh, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(statsh, stats_dev, sizeof statsh, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&deferh, defer_cnt, sizeof deferh, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (errh[0] & 2u) return fail(FG_ERR_PARALLEL, "the line between <x1_0,y1_0> and  <x1_1,y1_1> should not parallel to "
-                                                 "the line between <x2_0,y2_0> and  <x2_1,y2_1>");
-  if (errh[0] & 4u) return fail(FG_ERR_MAXV, "clipped polygon exceeds 16 vertices");
-  pl->nx = (long)nx64;
+  if (readback()) return FG_ERR_HIP;
+  if (hc->err[0] & 2u) return fail(FG_ERR_PARALLEL, "the line between <x1_0,y1_0> and  <x1_1,y1_1> should not parallel to "
+                                                    "the line between <x2_0,y2_0> and  <x2_1,y2_1>");
+  if (hc->err[0] & 4u) return fail(FG_ERR_MAXV, "clipped polygon exceeds 16 vertices");
+  pl->nx = (long)hc->total[2];
+  pl->stats[FG_STAT_PAIRS] = npairs;
+  pl->stats[FG_STAT_NONEMPTY] = (long)(hc->total[2] + hc->stats[FG_STAT_BELOW]);
+  pl->stats[FG_STAT_NXGRID] = pl->nx;
+  pl->stats[FG_STAT_BORDERLINE] = (long)hc->stats[FG_STAT_BORDERLINE];
+  pl->stats[FG_STAT_BINS] = nbins;
+  pl->stats[FG_STAT_BIN_ENTRIES] = (long)nentries;
+  pl->stats[FG_STAT_DEFERRED] = hc->defer_cnt;
+  pl->stats[FG_STAT_HEAVY] = hc->heavy_cnt;
   pl->x_src = pl->alloc<int>(pl->nx + 1); pl->x_dst = pl->alloc<int>(pl->nx + 1);
   pl->x_area = pl->alloc<double>(pl->nx + 1);
   if (order == 2) { pl->x_c1 = pl->alloc<double>(pl->nx + 1); pl->x_c2 = pl->alloc<double>(pl->nx + 1); }
@@ -397,7 +409,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
     pl->sums = pl->alloc<double>(3 * (size_t)nsrc);
     if (!pl->sums) return fail(FG_ERR_HIP, "out of device memory");
     pt.begin(PH_CELL_SUMS);
-    fgd_cell_sums(nsrc, pl->xoff, pl->nacc, pl->x_area, pl->x_c1, pl->x_c2, pl->sums, st);
+    fgd_cell_sums(nsrc, pl->xoff, pl->x_area, pl->x_c1, pl->x_c2, pl->sums, st);
     pt.end();
   }
   ptot.end();
@@ -405,18 +417,9 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   HIPCHK(hipGetLastError());
   pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms);
 
-  pl->stats[FG_STAT_PAIRS] = npairs;
-  pl->stats[FG_STAT_NONEMPTY] = (long)(nx64 + statsh[FG_STAT_BELOW]);
-  pl->stats[FG_STAT_NXGRID] = pl->nx;
-  pl->stats[FG_STAT_BORDERLINE] = (long)statsh[FG_STAT_BORDERLINE];
-  pl->stats[FG_STAT_BINS] = nbins;
-  pl->stats[FG_STAT_BIN_ENTRIES] = (long)nentries;
-  pl->stats[FG_STAT_DEFERRED] = deferh;
-  pl->stats[FG_STAT_HEAVY] = heavyh;
-
   // scratch no longer needed
-  void *scratch[] = {bin_cnt, bin_start, scan_ws, bin_entries, heavy_list, heavy_cnt, cand_cnt, cand_off, pair_src, pair_dst,
-                     tmp_area, tmp_clon, tmp_clat, defer_list, err_dev, stats_dev, total_dev, defer_cnt};
+  void *scratch[] = {zero_blk, bin_start, scan_ws, bin_entries, heavy_list, cand_cnt, cand_off, pair_src, pair_dst,
+                     tmp_area, tmp_clon, tmp_clat, defer_list};
   for (void *p : scratch) pl->release(p);
   pl->searched = true;
   return pl->nx;
@@ -584,7 +587,7 @@ static int build_csr(fg_plan *pl)
     if (!pl->src_idx_f) return fail(FG_ERR_HIP, "out of device memory");
     fgd_src_field_index(pl->order, pl->tiles_dev, pl->ntiles, pl->nsrc, pl->src_idx_f, st);
   }
-  int *row_cnt = pl->alloc<int>(ndst + 1);
+  int *row_cnt = pl->alloc<int>(2 * ((size_t)ndst + 1));   // counts | fill cursors, one memset
   int *perm = pl->alloc<int>(nx + 1);
   unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(ndst + 1));
   unsigned long long *total_dev = pl->alloc<unsigned long long>(4);
@@ -593,11 +596,10 @@ static int build_csr(fg_plan *pl)
   else pl->csr.e1 = pl->alloc<FgCsrEntry1>(nx + 1);
   if (!row_cnt || !perm || !scan_ws || !total_dev || !pl->csr.row_ptr || (!pl->csr.e1 && !pl->csr.e2))
     return fail(FG_ERR_HIP, "out of device memory");
-  HIPCHK(hipMemsetAsync(row_cnt, 0, (ndst + 1) * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(row_cnt, 0, 2 * ((size_t)ndst + 1) * sizeof(int), st));
   fgd_csr_count(nx, pl->x_dst, row_cnt, st);
-  fgd_exclusive_scan(row_cnt, ndst + 1, pl->csr.row_ptr, scan_ws, total_dev, st);
-  HIPCHK(hipMemsetAsync(row_cnt, 0, (ndst + 1) * sizeof(int), st));
-  fgd_csr_fill(nx, pl->x_dst, pl->csr.row_ptr, row_cnt, perm, st);
+  fgd_exclusive_scan(row_cnt, ndst, pl->csr.row_ptr, scan_ws, total_dev, st);
+  fgd_csr_fill(nx, pl->x_dst, pl->csr.row_ptr, row_cnt + ndst + 1, perm, st);
   fgd_csr_sort_rows(ndst, pl->csr.row_ptr, perm, st);
   fgd_csr_gather(pl->order, nx, perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, pl->csr, st);
   HIPCHK(hipStreamSynchronize(st));

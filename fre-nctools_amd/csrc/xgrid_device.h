@@ -45,6 +45,7 @@ enum {
   FG_NSTATS = 10
 };
 
+// n inputs -> n+1 exclusive prefixes (out[n] = total, also stored 64-bit in *total_dev)
 int  fgd_exclusive_scan(const int *in, long n, int *out, unsigned long long *bsum_ws,
                         unsigned long long *total_dev, hipStream_t st);
 long fgd_scan_ws_elems(long n);
@@ -65,7 +66,7 @@ void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *p
                         const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
                         hipStream_t st);
-void fgd_cell_sums(int nsrc, const int *xoff, const int *nacc, const double *x_area, const double *x_c1,
+void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
                    const double *x_c2, double *sums, hipStream_t st);
 void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st);
 void fgd_distances(long nx, int nsrc, const int *x_src, const double *x_area, const double *cen, double *x_c1,

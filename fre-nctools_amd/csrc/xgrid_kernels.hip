@@ -100,7 +100,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_top(unsigned long long *b
   if (threadIdx.x == 0) *total_out = carry;
 }
 
-// out[i] = exclusive prefix (32-bit; the host checks the 64-bit total fits)
+// out[i] = exclusive prefix for i in [0, n] (n inputs, n+1 outputs; 32-bit, the host checks the 64-bit total fits)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int *in, long n, const unsigned long long *bsum, int *out)
 {
   __shared__ unsigned tile[SCAN_CHUNK];
@@ -128,22 +128,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int *in, long
   for (int k = 0; k < SCAN_ITEMS; k++) {
     int li = k * SCAN_THREADS + threadIdx.x;
     long idx = base + li;
-    if (idx < n) out[idx] = (int)tile[li];
+    if (idx <= n) out[idx] = (int)tile[li];
   }
 }
 
 int fgd_exclusive_scan(const int *in, long n, int *out, unsigned long long *bsum_ws,
                        unsigned long long *total_dev, hipStream_t st)
 {
-  if (n <= 0) { hipMemsetAsync(total_dev, 0, sizeof(unsigned long long), st); return 0; }
-  int nb = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  // n inputs -> n+1 outputs (out[n] = total); blocks cover n+1 positions, inputs beyond n read as 0
+  if (n < 0) n = 0;
+  int nb = (int)((n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK);
   k_scan_block_sums<<<nb, SCAN_THREADS, 0, st>>>(in, n, bsum_ws);
   k_scan_top<<<1, SCAN_THREADS, 0, st>>>(bsum_ws, nb, total_dev);
   k_scan_apply<<<nb, SCAN_THREADS, 0, st>>>(in, n, bsum_ws, out);
   return 0;
 }
 
-long fgd_scan_ws_elems(long n) { return (n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1; }
+long fgd_scan_ws_elems(long n) { return (n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK + 1; }
 
 // ---------------------------------------------------------------------------------------
 // per-cell records
@@ -697,13 +698,13 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
 // order-2 centroid pass
 // ---------------------------------------------------------------------------------------
 // sums[0..2][nsrc] over this plan's exchange cells, in exchange-cell order (conserve_interp.c:216-221)
-__global__ __launch_bounds__(256) void k_cell_sums(int nsrc, const int *xoff, const int *nacc, const double *x_area,
+__global__ __launch_bounds__(256) void k_cell_sums(int nsrc, const int *xoff, const double *x_area,
                                                     const double *x_c1, const double *x_c2, double *sums)
 {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsrc) return;
   double a = 0, l = 0, t = 0;
-  int o = xoff[s], c = nacc[s];
+  int o = xoff[s], c = xoff[s + 1] - o;
   for (int k = 0; k < c; k++) { a += x_area[o + k]; l += x_c1[o + k]; t += x_c2[o + k]; }
   sums[s] = a; sums[nsrc + s] = l; sums[2 * (size_t)nsrc + s] = t;
 }
@@ -811,10 +812,10 @@ void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *p
   else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2);
 }
 
-void fgd_cell_sums(int nsrc, const int *xoff, const int *nacc, const double *x_area, const double *x_c1,
+void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
                    const double *x_c2, double *sums, hipStream_t st)
 {
-  if (nsrc > 0) k_cell_sums<<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, xoff, nacc, x_area, x_c1, x_c2, sums);
+  if (nsrc > 0) k_cell_sums<<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, xoff, x_area, x_c1, x_c2, sums);
 }
 
 void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st)
