@@ -143,6 +143,7 @@ struct fg_plan {
   bool own_stream = true;
   int ntiles = 0;
   std::vector<int> nx_in, ny_in, cell_off;
+  std::vector<FgTile> tiles_host;   // staging for the async descriptor upload
   int nsrc = 0;                 // flattened source cells
   int nx_out = 0, ny_out = 0, ndst = 0;
   long f_stride = 0;            // elements in one level of the source field array
@@ -157,6 +158,7 @@ struct fg_plan {
   int *x_src = nullptr, *x_dst = nullptr;
   double *x_area = nullptr, *x_c1 = nullptr, *x_c2 = nullptr;
   int *xoff = nullptr;
+  int *row_cnt = nullptr;        // exchange cells per destination cell, counted while scattering (2*(ndst+1): counts | cursors)
   double *sums = nullptr, *cen = nullptr;
   // sweep
   FgCsr csr{};
@@ -270,13 +272,13 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   if (!hc) return fail(FG_ERR_HIP, "hipHostMalloc failed");
 
   // tile descriptors: source tiles + the destination tile as entry [ntiles]
-  std::vector<FgTile> th(pl->ntiles + 1);
+  std::vector<FgTile> &th = pl->tiles_host;  // owned by the plan: the upload below needs no sync
+  th.resize(pl->ntiles + 1);
   for (int m = 0; m < pl->ntiles; m++) th[m] = FgTile{d_lon_in[m], d_lat_in[m], pl->nx_in[m], pl->ny_in[m], pl->cell_off[m]};
   th[pl->ntiles] = FgTile{d_lon_out, d_lat_out, pl->nx_out, pl->ny_out, 0};
   pl->tiles_dev = pl->alloc<FgTile>(pl->ntiles + 1);
   if (!pl->tiles_dev) return fail(FG_ERR_HIP, "out of device memory");
   HIPCHK(hipMemcpyAsync(pl->tiles_dev, th.data(), sizeof(FgTile) * th.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));          // th lives on this stack frame
 
   bool any_mask = false;
   if (d_mask_in) for (int m = 0; m < pl->ntiles; m++) if (d_mask_in[m]) any_mask = true;
@@ -401,9 +403,12 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pl->x_area = pl->alloc<double>(pl->nx + 1);
   if (order == 2) { pl->x_c1 = pl->alloc<double>(pl->nx + 1); pl->x_c2 = pl->alloc<double>(pl->nx + 1); }
   if (!pl->x_src || !pl->x_dst || !pl->x_area || (order == 2 && (!pl->x_c1 || !pl->x_c2))) return fail(FG_ERR_HIP, "out of device memory");
+  pl->row_cnt = pl->alloc<int>(2 * ((size_t)ndst + 1));
+  if (!pl->row_cnt) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_COMPACT);
+  HIPCHK(hipMemsetAsync(pl->row_cnt, 0, 2 * ((size_t)ndst + 1) * sizeof(int), st));
   fgd_scatter_xcells(order, npairs, pair_src, pair_dst, cand_off, pl->xoff, tmp_area, tmp_clon, tmp_clat,
-                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, st);
+                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, pl->row_cnt, st);
   pt.end();
   if (order == 2) {
     pl->sums = pl->alloc<double>(3 * (size_t)nsrc);
@@ -587,7 +592,9 @@ static int build_csr(fg_plan *pl)
     if (!pl->src_idx_f) return fail(FG_ERR_HIP, "out of device memory");
     fgd_src_field_index(pl->order, pl->tiles_dev, pl->ntiles, pl->nsrc, pl->src_idx_f, st);
   }
-  int *row_cnt = pl->alloc<int>(2 * ((size_t)ndst + 1));   // counts | fill cursors, one memset
+  int *row_cnt = pl->row_cnt;
+  const bool counted = row_cnt != nullptr;                  // the search's scatter kernel already counted the rows
+  if (!counted) row_cnt = pl->alloc<int>(2 * ((size_t)ndst + 1));   // counts | fill cursors, one memset
   int *perm = pl->alloc<int>(nx + 1);
   unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(ndst + 1));
   unsigned long long *total_dev = pl->alloc<unsigned long long>(4);
@@ -596,15 +603,17 @@ static int build_csr(fg_plan *pl)
   else pl->csr.e1 = pl->alloc<FgCsrEntry1>(nx + 1);
   if (!row_cnt || !perm || !scan_ws || !total_dev || !pl->csr.row_ptr || (!pl->csr.e1 && !pl->csr.e2))
     return fail(FG_ERR_HIP, "out of device memory");
-  HIPCHK(hipMemsetAsync(row_cnt, 0, 2 * ((size_t)ndst + 1) * sizeof(int), st));
-  fgd_csr_count(nx, pl->x_dst, row_cnt, st);
+  if (!counted) {
+    HIPCHK(hipMemsetAsync(row_cnt, 0, 2 * ((size_t)ndst + 1) * sizeof(int), st));
+    fgd_csr_count(nx, pl->x_dst, row_cnt, st);
+  }
   fgd_exclusive_scan(row_cnt, ndst, pl->csr.row_ptr, scan_ws, total_dev, st);
   fgd_csr_fill(nx, pl->x_dst, pl->csr.row_ptr, row_cnt + ndst + 1, perm, st);
   fgd_csr_sort_rows(ndst, pl->csr.row_ptr, perm, st);
   fgd_csr_gather(pl->order, nx, perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, pl->csr, st);
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
-  pl->release(row_cnt); pl->release(perm); pl->release(scan_ws); pl->release(total_dev);
+  pl->release(row_cnt); pl->row_cnt = nullptr; pl->release(perm); pl->release(scan_ws); pl->release(total_dev);
   if (!pl->red_partial) { pl->red_partial = pl->alloc<double>(1024); pl->red_result = pl->alloc<double>(260); }
   if (!pl->red_partial || !pl->red_result) return fail(FG_ERR_HIP, "out of device memory");
   return 0;

@@ -267,18 +267,12 @@ __device__ __forceinline__ SrcQuery d_src_query(double lat_min, double lat_max, 
   return q;
 }
 
-// number of table entries the query touches
+// size of the query: bins scanned (a bin holds ~2 cells: bins are 1.5x the mean cell) plus the entries of
+// the wide lists of its rows (two table loads).  Only used to route huge queries to the wave-per-cell kernel.
 __device__ __forceinline__ int d_query_size(const SrcQuery &q, FgBins b, const int *slot_start)
 {
-  int t = 0;
-  for (int r = q.ra; r <= q.rb; r++) {
-    int base = r * b.nblon;
-    t += slot_start[base + q.c_start + q.n0] - slot_start[base + q.c_start];
-    if (q.n1) t += slot_start[base + q.n1] - slot_start[base];
-  }
   const int nbins = b.nblat * b.nblon;
-  t += slot_start[nbins + q.r1 + 1] - slot_start[nbins + q.r0];
-  return t;
+  return (q.rb - q.ra + 1) * (q.n0 + q.n1) + (slot_start[nbins + q.r1 + 1] - slot_start[nbins + q.r0]);
 }
 
 // the reference's two bounding-box rejects, create_xgrid.c:1055 and :1062-1079
@@ -294,7 +288,7 @@ __device__ __forceinline__ bool d_box_pass(const FgBinEntry &E, double lat_in_mi
   return true;
 }
 
-#define HEAVY_ENTRIES 96
+#define HEAVY_ENTRIES 64      // scanned bins + wide entries above which a source cell gets a whole wave
 #define CAND_G 4          // lanes per source cell in the candidate scan (one bin row each)
 
 // CAND_G lanes per source cell, each scanning every CAND_G-th bin row of the cell's query.  Counts and
@@ -679,7 +673,8 @@ template <int ORDER>
 __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *pair_src, const int *pair_dst,
                                                          const int *cand_off, const int *xoff,
                                                          const double *tmp_area, const double *tmp_clon, const double *tmp_clat,
-                                                         int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2)
+                                                         int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
+                                                         int *row_cnt)
 {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npairs) return;
@@ -691,6 +686,7 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
     rank += ((unsigned)pair_dst[o + k] < (unsigned)d) ? 1 : 0;    // rejected entries are 0xffffffff
   int pos = xoff[s] + rank;
   x_src[pos] = s; x_dst[pos] = d; x_area[pos] = tmp_area[p];
+  atomicAdd(&row_cnt[d], 1);                         // destination-row sizes for the CSR build (fg_plan_finalize)
   if (ORDER == 2) { x_c1[pos] = tmp_clon[p]; x_c2[pos] = tmp_clat[p]; }
 }
 
@@ -805,11 +801,11 @@ int fgd_cand_group(void) { return CAND_G; }
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
                         const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                        hipStream_t st)
+                        int *row_cnt, hipStream_t st)
 {
   if (npairs <= 0) return;
-  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2);
-  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2);
+  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt);
+  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt);
 }
 
 void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
