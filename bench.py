@@ -98,11 +98,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # FG_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks sharing one GPU (development only;
+    # the driver's multi-GPU runs use one rank per GPU over RCCL == backend "nccl")
+    backend = os.environ.get("FG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     ni, nlon, nlat, nz = args.ni, args.nlon, args.nlat, args.nz
     lon, lat = fg.gnomonic_ed_corners(ni)

@@ -18,6 +18,10 @@ def load_package():
     if "fre_nctools_amd" in sys.modules:
         return sys.modules["fre_nctools_amd"]
     pkg_dir = os.path.join(ROOT, "fre-nctools_amd")
+    if not os.path.exists(os.path.join(pkg_dir, "libfregrid_hip.so")):
+        # fresh checkout: build artefacts are git-ignored.  hipcc cross-compiles gfx950 without a GPU.
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(pkg_dir, "csrc"), "-j4"], stdout=subprocess.DEVNULL)
     spec = importlib.util.spec_from_file_location("fre_nctools_amd", os.path.join(pkg_dir, "__init__.py"),
                                                   submodule_search_locations=[pkg_dir])
     mod = importlib.util.module_from_spec(spec)
