@@ -30,6 +30,9 @@ EXPORTS = [
     "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
     "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
     "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_stream", "fg_plan_sync",
+    "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
+    "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
+    "fg_gnomonic_ed_grid",
     "fg_plan_stats", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
 
@@ -129,6 +132,33 @@ def lib():
     L.fg_set_profiling.restype = None
     L.fg_plan_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.fg_plan_phase_ms.restype = C.c_int
+    lp = C.POINTER(C.c_long)
+    L.fg_c2l_create.argtypes = [C.c_int, ip, ip, dpp, dpp, dpp, dpp, C.c_int] + [ip] * 10 + [C.c_int, C.POINTER(vp)]
+    L.fg_c2l_create.restype = C.c_int
+    L.fg_c2l_destroy.argtypes = [vp]
+    L.fg_c2l_destroy.restype = None
+    L.fg_c2l_ncells.argtypes = [vp]
+    L.fg_c2l_ncells.restype = C.c_long
+    L.fg_c2l_halo_size.argtypes = [vp]
+    L.fg_c2l_halo_size.restype = C.c_long
+    L.fg_c2l_set_stream.argtypes = [vp, vp]
+    L.fg_c2l_set_stream.restype = C.c_int
+    L.fg_c2l_sync.argtypes = [vp]
+    L.fg_c2l_sync.restype = C.c_int
+    L.fg_c2l_get_centres.argtypes = [vp, dp, dp]
+    L.fg_c2l_get_centres.restype = C.c_int
+    L.fg_c2l_fill_halo.argtypes = [vp, vp, vp, C.c_int]
+    L.fg_c2l_fill_halo.restype = C.c_int
+    L.fg_c2l_gradient.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp]
+    L.fg_c2l_gradient.restype = C.c_int
+    L.fg_c2l_grid_info.argtypes = [C.c_int, C.c_int] + [dp] * 15
+    L.fg_c2l_grid_info.restype = C.c_int
+    L.fg_find_contacts.argtypes = [C.c_int, ip, ip, dpp, dpp, C.c_int] + [ip] * 10
+    L.fg_find_contacts.restype = C.c_int
+    L.fg_halo_map.argtypes = [C.c_int, ip, ip, C.c_int] + [ip] * 10 + [lp, ip]
+    L.fg_halo_map.restype = C.c_int
+    L.fg_gnomonic_ed_grid.argtypes = [C.c_int, C.c_double, C.c_int, dp, dp, dp, dp]
+    L.fg_gnomonic_ed_grid.restype = C.c_int
     L.fg_gnomonic_ed_corners.argtypes = [C.c_int, C.c_double, C.c_int, dp, dp]
     L.fg_gnomonic_ed_corners.restype = C.c_int
     L.fg_latlon_corners.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp]

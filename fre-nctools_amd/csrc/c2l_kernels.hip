@@ -1,0 +1,166 @@
+// c2l_kernels.hip -- order-2 input preparation on the device: halo fill across tile contacts,
+// the cubed-sphere gradient grad_c2l and the missing-value gradient mask.
+//
+//   k_pack_interior   copy [nz][ncells] fields into the halo'd layout [nz][F]   (fregrid_util.c:2137-2145)
+//   k_halo_gather     update_halo for every tile at once through the gather map built by fg_halo_map
+//                     (fregrid_util.c:2168-2182, :2614-2658)
+//   k_grad_c2l        a2b_ord2 + Green's-theorem gradient + projection, fused: one thread per cell evaluates the
+//                     four B-grid corner values it needs (gradient_c2l.c:58-118, :124-195).  Pure add/mul/div in
+//                     the reference's order => bit-identical to the CPU reference (compiled -ffp-contract=off).
+//   k_grad_mask       3x3 missing-value stencil (fregrid_util.c:2203-2216)
+#include "xgrid_device.h"
+
+struct C2lTile {
+  int nx, ny;
+  long cell_off;      // first cell of the tile in [ncells] arrays
+  long f_off;         // first element of the tile in halo'd [F] arrays
+  long dx_off, dy_off;  // offsets into dx / en_n ([ny+1][nx]) and dy / en_e ([ny][nx+1]) concatenations
+  long ew_off, es_off;  // offsets into edge_w/e ([ny+1]) and edge_s/n ([nx+1]) concatenations
+};
+
+struct C2lGeom {
+  const double *dx, *dy, *area, *edge_w, *edge_e, *edge_s, *edge_n, *en_n, *en_e, *vlon, *vlat;
+};
+
+__device__ __forceinline__ int d_find_tile(const C2lTile *tiles, int ntiles, long cell)
+{
+  int t = 0;
+  while (t + 1 < ntiles && cell >= tiles[t + 1].cell_off) t++;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void k_pack_interior(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
+                                                        const double *src, double *dst)
+{
+  long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (c >= ncells) return;
+  const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
+  long loc = c - T.cell_off;
+  int i = (int)(loc % T.nx), j = (int)(loc / T.nx);
+  dst[(size_t)k * F + T.f_off + (long)(j + 1) * (T.nx + 2) + i + 1] = src[(size_t)k * ncells + c];
+}
+
+__global__ __launch_bounds__(256) void k_halo_gather(long F, int nz, const int *map, double *data)
+{
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (e >= F) return;
+  int src = map[e];
+  if (src >= 0) data[(size_t)k * F + e] = data[(size_t)k * F + src];   // sources are interior cells: no read/write overlap
+}
+
+// B-grid value at corner (i, j) of a tile, all four tile edges treated as cubed-sphere edges (gradient_c2l.c:124-195)
+__device__ __forceinline__ double d_a2b(const double *q, int nx, int ny, int i, int j,
+                                        const double *edge_w, const double *edge_e, const double *edge_s, const double *edge_n)
+{
+  const int w = nx + 2;
+  const double r3 = 1. / 3.;
+  const int nxp = nx + 1, nyp = ny + 1;
+  if (i == 0 && j == 0)   return r3 * (q[1 * w + 1] + q[1 * w] + q[1]);
+  if (i == nx && j == 0)  return r3 * (q[1 * w + nx] + q[nx] + q[1 * w + nxp]);
+  if (i == nx && j == ny) return r3 * (q[ny * w + nx] + q[ny * w + nxp] + q[nyp * w + nx]);
+  if (i == 0 && j == ny)  return r3 * (q[ny * w + 1] + q[ny * w] + q[nyp * w + 1]);
+  if (i == 0) {
+    double a = 0.5 * (q[j * w] + q[j * w + 1]), b = 0.5 * (q[(j + 1) * w] + q[(j + 1) * w + 1]);
+    return edge_w[j] * a + (1 - edge_w[j]) * b;
+  }
+  if (i == nx) {
+    double a = 0.5 * (q[j * w + nx] + q[j * w + nxp]), b = 0.5 * (q[(j + 1) * w + nx] + q[(j + 1) * w + nxp]);
+    return edge_e[j] * a + (1 - edge_e[j]) * b;
+  }
+  if (j == 0) {
+    double a = 0.5 * (q[i] + q[w + i]), b = 0.5 * (q[i + 1] + q[w + i + 1]);
+    return edge_s[i] * a + (1 - edge_s[i]) * b;
+  }
+  if (j == ny) {
+    double a = 0.5 * (q[ny * w + i] + q[nyp * w + i]), b = 0.5 * (q[ny * w + i + 1] + q[nyp * w + i + 1]);
+    return edge_n[i] * a + (1 - edge_n[i]) * b;
+  }
+  return 0.25 * (q[j * w + i] + q[j * w + i + 1] + q[(j + 1) * w + i] + q[(j + 1) * w + i + 1]);
+}
+
+__global__ __launch_bounds__(256) void k_grad_c2l(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
+                                                   const double *data, C2lGeom g, double *grad_x, double *grad_y)
+{
+  long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (c >= ncells) return;
+  const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
+  const int nx = T.nx, ny = T.ny, nxp = nx + 1;
+  long loc = c - T.cell_off;
+  const int i = (int)(loc % nx), j = (int)(loc / nx);
+  const double *q = data + (size_t)k * F + T.f_off;
+  const double *ew = g.edge_w + T.ew_off, *ee = g.edge_e + T.ew_off, *es = g.edge_s + T.es_off, *en = g.edge_n + T.es_off;
+  const double b00 = d_a2b(q, nx, ny, i, j, ew, ee, es, en), b10 = d_a2b(q, nx, ny, i + 1, j, ew, ee, es, en);
+  const double b01 = d_a2b(q, nx, ny, i, j + 1, ew, ee, es, en), b11 = d_a2b(q, nx, ny, i + 1, j + 1, ew, ee, es, en);
+  const double *dx = g.dx + T.dx_off, *dy = g.dy + T.dy_off;
+  const double *enn = g.en_n + 3 * T.dx_off, *ene = g.en_e + 3 * T.dy_off;
+  const long ms = (long)j * nx + i, mn = (long)(j + 1) * nx + i;       // south / north edges of the cell
+  const long mw = (long)j * nxp + i, me = mw + 1;                       // west / east edges
+  double g3[3];
+#pragma unroll
+  for (int n = 0; n < 3; n++) {
+    double pdx_s = 0.5 * (b00 + b10) * dx[ms] * enn[3 * ms + n];
+    double pdx_n = 0.5 * (b01 + b11) * dx[mn] * enn[3 * mn + n];
+    double pdy_w = 0.5 * (b00 + b01) * dy[mw] * ene[3 * mw + n];
+    double pdy_e = 0.5 * (b10 + b11) * dy[me] * ene[3 * me + n];
+    g3[n] = pdx_n - pdx_s - pdy_w + pdy_e;
+  }
+  const double *vlon = g.vlon + 3 * c, *vlat = g.vlat + 3 * c;
+  const double area = g.area[c];
+  double gx = (vlon[0] * g3[0] + vlon[1] * g3[1] + vlon[2] * g3[2]) / area;
+  gx *= 6371000.;
+  double gy = (vlat[0] * g3[0] + vlat[1] * g3[1] + vlat[2] * g3[2]) / area;
+  gy *= 6371000.;
+  grad_x[(size_t)k * ncells + c] = gx;
+  grad_y[(size_t)k * ncells + c] = gy;
+}
+
+__global__ __launch_bounds__(256) void k_grad_mask(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
+                                                    const double *data, double missing, int *mask)
+{
+  long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (c >= ncells) return;
+  const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
+  const int w = T.nx + 2;
+  long loc = c - T.cell_off;
+  const int ii = (int)(loc % T.nx) + 1, jj = (int)(loc / T.nx) + 1;
+  const double *q = data + (size_t)k * F + T.f_off;
+  int m = 0;
+  for (int dj = -1; dj <= 1; dj++)
+    for (int di = -1; di <= 1; di++) {
+      if (di == 0 && dj == 0) continue;
+      if (q[(jj + dj) * w + ii + di] == missing) m = 1;
+    }
+  mask[(size_t)k * ncells + c] = m;
+}
+
+static inline int nblk(long n, int t) { return (int)((n + t - 1) / t); }
+
+void fgd_pack_interior(const void *tiles, int ntiles, long ncells, long F, int nz, const double *src, double *dst, hipStream_t st)
+{
+  if (ncells > 0 && nz > 0) k_pack_interior<<<dim3(nblk(ncells, 256), nz), 256, 0, st>>>((const C2lTile *)tiles, ntiles, ncells, F, nz, src, dst);
+}
+void fgd_halo_gather(long F, int nz, const int *map, double *data, hipStream_t st)
+{
+  if (F > 0 && nz > 0) k_halo_gather<<<dim3(nblk(F, 256), nz), 256, 0, st>>>(F, nz, map, data);
+}
+void fgd_grad_c2l(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, const double *const *geom,
+                  double *grad_x, double *grad_y, hipStream_t st)
+{
+  if (ncells <= 0 || nz <= 0) return;
+  C2lGeom g{geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9], geom[10]};
+  k_grad_c2l<<<dim3(nblk(ncells, 256), nz), 256, 0, st>>>((const C2lTile *)tiles, ntiles, ncells, F, nz, data, g, grad_x, grad_y);
+}
+void fgd_grad_mask(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, double missing, int *mask, hipStream_t st)
+{
+  if (ncells > 0 && nz > 0) k_grad_mask<<<dim3(nblk(ncells, 256), nz), 256, 0, st>>>((const C2lTile *)tiles, ntiles, ncells, F, nz, data, missing, mask);
+}
+size_t fgd_c2l_tile_size(void) { return sizeof(C2lTile); }
+void fgd_c2l_tile_fill(void *dst, int idx, int nx, int ny, long cell_off, long f_off, long dx_off, long dy_off, long ew_off, long es_off)
+{
+  C2lTile *t = (C2lTile *)dst + idx;
+  t->nx = nx; t->ny = ny; t->cell_off = cell_off; t->f_off = f_off; t->dx_off = dx_off; t->dy_off = dy_off; t->ew_off = ew_off; t->es_off = es_off;
+}

@@ -27,11 +27,16 @@
 #define FG_D2R (FG_PI / 180)
 #define FG_RADIUS 6371000.0
 
+/* The reference's latlon2xyz (mosaic_util.c:212-222) compiles to five separate libm calls -- its output pointers
+ * may alias its inputs, so gcc cannot fuse sin/cos into sincos -- and glibc's sincos can differ from sin/cos in
+ * the last bit.  Keep the calls separate here too (noinline wrappers defeat the sincos fusion). */
+static double __attribute__((noinline)) sin_sep(double x) { return sin(x); }
+static double __attribute__((noinline)) cos_sep(double x) { return cos(x); }
 static void ll2xyz(double lon, double lat, double *p)
 {
-  p[0] = cos(lat) * cos(lon);
-  p[1] = cos(lat) * sin(lon);
-  p[2] = sin(lat);
+  p[0] = cos_sep(lat) * cos_sep(lon);
+  p[1] = cos_sep(lat) * sin_sep(lon);
+  p[2] = sin_sep(lat);
 }
 
 /* mosaic_util.c:228-252 */
@@ -237,7 +242,39 @@ static void six_tiles(int ni, double *x, double *y)
       }
 }
 
+/* T-cell centres: normalised sum of the four corner unit vectors (create_gnomonic_cubic_grid.c:2008-2048) */
+static void cell_centres(int ni, const double *lonc, const double *latc, double *lont, double *latt)
+{
+  int nip = ni + 1;
+  size_t np = (size_t)nip * nip;
+  double *xc = (double *)malloc(np * sizeof(double)), *yc = (double *)malloc(np * sizeof(double)), *zc = (double *)malloc(np * sizeof(double));
+  for (size_t k = 0; k < np; k++) { double p[3]; ll2xyz(lonc[k], latc[k], p); xc[k] = p[0]; yc[k] = p[1]; zc[k] = p[2]; }
+  for (int j = 0; j < ni; j++)
+    for (int i = 0; i < ni; i++) {
+      int p1 = j * nip + i, p2 = p1 + 1, p3 = (j + 1) * nip + i + 1, p4 = (j + 1) * nip + i;
+      double xt = xc[p1] + xc[p2] + xc[p3] + xc[p4];
+      double yt = yc[p1] + yc[p2] + yc[p3] + yc[p4];
+      double zt = zc[p1] + zc[p2] + zc[p3] + zc[p4];
+      double dd = sqrt(pow(xt, 2) + pow(yt, 2) + pow(zt, 2));
+      xt /= dd; yt /= dd; zt /= dd;
+      xyz2ll(xt, yt, zt, &lont[j * ni + i], &latt[j * ni + i]);
+    }
+  free(xc); free(yc); free(zc);
+}
+
+static int gnomonic_ed_grid(int ni, double shift_fac, int via_degrees, double *lonc, double *latc, double *lont, double *latt);
+
 int fg_gnomonic_ed_corners(int ni, double shift_fac, int via_degrees, double *lonc, double *latc)
+{
+  return gnomonic_ed_grid(ni, shift_fac, via_degrees, lonc, latc, NULL, NULL);
+}
+
+int fg_gnomonic_ed_grid(int ni, double shift_fac, int via_degrees, double *lonc, double *latc, double *lont, double *latt)
+{
+  return gnomonic_ed_grid(ni, shift_fac, via_degrees, lonc, latc, lont, latt);
+}
+
+static int gnomonic_ed_grid(int ni, double shift_fac, int via_degrees, double *lonc, double *latc, double *lont, double *latt)
 {
   if (ni < 2) return -1;
   int nip = ni + 1;
@@ -281,14 +318,22 @@ int fg_gnomonic_ed_corners(int ni, double shift_fac, int via_degrees, double *lo
   for (int j = 0; j < nip; j++) {
     xc[5 * T + j * nip] = xc[4 * T + j * nip + ni];         yc[5 * T + j * nip] = yc[4 * T + j * nip + ni];
   }
+  if (lont && latt)                                  /* centres come from the radian corners (:493) */
+    for (int t = 0; t < 6; t++) cell_centres(ni, xc + t * np, yc + t * np, lont + (size_t)t * ni * ni, latt + (size_t)t * ni * ni);
   if (via_degrees) {
     /* grid files hold degrees (create_gnomonic_cubic_grid.c:717-720); fregrid converts back
-       (fregrid_util.c:230-231) */
+       (fregrid_util.c:230-231,241-242) */
     for (size_t n = 0; n < 6 * np; n++) {
       double xd = xc[n] * FG_R2D, yd = yc[n] * FG_R2D;
       xc[n] = xd * FG_D2R;
       yc[n] = yd * FG_D2R;
     }
+    if (lont && latt)
+      for (size_t n = 0; n < (size_t)6 * ni * ni; n++) {
+        double xd = lont[n] * FG_R2D, yd = latt[n] * FG_R2D;
+        lont[n] = xd * FG_D2R;
+        latt[n] = yd * FG_D2R;
+      }
   }
   return 0;
 }

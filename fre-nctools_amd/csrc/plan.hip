@@ -1099,3 +1099,160 @@ extern "C" void pimod(double x[], int nn)
   const double PI = 3.14159265358979323846;
   for (int i = 0; i < nn; i++) { if (x[i] < -PI) x[i] += 2.0 * PI; else if (x[i] > PI) x[i] -= 2.0 * PI; }
 }
+
+// ----------------------------------------------------------------------------- order-2 input preparation
+// fg_c2l: per-mosaic state for get_input_data's order-2 branch on the device (fregrid_util.c:2137-2216):
+// halo fill across tile contacts, grad_c2l, gradient mask.  Geometry (calc_c2l_grid_info) is computed once on
+// the host in the reference's operation order (c2l_host.c) and kept in HBM.
+extern "C" int fg_c2l_grid_info(int nx, int ny, const double *xt, const double *yt, const double *xc, const double *yc,
+                                double *dx, double *dy, double *area, double *edge_w, double *edge_e, double *edge_s,
+                                double *edge_n, double *en_n, double *en_e, double *vlon, double *vlat);
+extern "C" int fg_halo_map(int ntiles, const int *nx, const int *ny, int ncontacts, const int *tile1, const int *tile2,
+                           const int *istart1, const int *iend1, const int *jstart1, const int *jend1,
+                           const int *istart2, const int *iend2, const int *jstart2, const int *jend2,
+                           long *map_off, int *map);
+
+struct fg_c2l {
+  int device = 0, ntiles = 0;
+  hipStream_t stream = nullptr;
+  long ncells = 0, F = 0;
+  std::vector<int> nx, ny;
+  std::vector<void *> owned;
+  void *tiles_dev = nullptr;
+  int *map_dev = nullptr;
+  double *geom_dev[11] = {nullptr};
+  std::vector<double> lont_halo, latt_halo;       // host copies (tests / inspection)
+  template <typename T> T *alloc(size_t n) { void *p = g_pool.get(device, n * sizeof(T)); if (p) owned.push_back(p); return (T *)p; }
+};
+
+extern "C" void fg_c2l_destroy(fg_c2l *h)
+{
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (void *p : h->owned) g_pool.put(p);
+  delete h;
+}
+
+extern "C" int fg_c2l_create(int ntiles, const int *nx, const int *ny, const double *const *lonc, const double *const *latc,
+                             const double *const *lont, const double *const *latt,
+                             int ncontacts, const int *tile1, const int *tile2,
+                             const int *istart1, const int *iend1, const int *jstart1, const int *jend1,
+                             const int *istart2, const int *iend2, const int *jstart2, const int *jend2,
+                             int device, fg_c2l **out)
+{
+  if (ntiles < 1 || !nx || !ny || !lonc || !latc || !lont || !latt || !out) return fail(FG_ERR_ARG, "null argument");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(FG_ERR_HIP, "no HIP device visible: libfregrid_hip needs an MI355X-class GPU");
+  if (device < 0 || device >= ndev) return fail(FG_ERR_ARG, "device out of range");
+  HIPCHK(hipSetDevice(device));
+  fg_c2l *h = new fg_c2l();
+  h->device = device; h->ntiles = ntiles;
+  std::vector<long> cell_off(ntiles + 1), f_off(ntiles + 1), dx_off(ntiles + 1), dy_off(ntiles + 1), ew_off(ntiles + 1), es_off(ntiles + 1);
+  long co = 0, fo = 0, xo = 0, yo = 0, wo = 0, so = 0;
+  for (int t = 0; t < ntiles; t++) {
+    if (nx[t] < 2 || ny[t] < 2) { delete h; return fail(FG_ERR_ARG, "tiles need at least 2x2 cells for the gradient"); }
+    h->nx.push_back(nx[t]); h->ny.push_back(ny[t]);
+    cell_off[t] = co; f_off[t] = fo; dx_off[t] = xo; dy_off[t] = yo; ew_off[t] = wo; es_off[t] = so;
+    co += (long)nx[t] * ny[t]; fo += (long)(nx[t] + 2) * (ny[t] + 2);
+    xo += (long)nx[t] * (ny[t] + 1); yo += (long)(nx[t] + 1) * ny[t]; wo += ny[t] + 1; so += nx[t] + 1;
+  }
+  h->ncells = co; h->F = fo;
+  // halo map (setup_boundary + update_halo semantics)
+  std::vector<long> map_off(ntiles + 1);
+  std::vector<int> map(fo);
+  int rc = fg_halo_map(ntiles, nx, ny, ncontacts, tile1, tile2, istart1, iend1, jstart1, jend1, istart2, iend2, jstart2, jend2,
+                       map_off.data(), map.data());
+  if (rc) { delete h; return fail(rc, "fregrid_util: inconsistent contact description (size mismatch between the boundary)"); }
+  // halo'd cell centres: interior copy, zero halo (init_halo), then the same halo update as the data
+  h->lont_halo.assign(fo, 0.0); h->latt_halo.assign(fo, 0.0);
+  for (int t = 0; t < ntiles; t++)
+    for (int j = 0; j < ny[t]; j++) for (int i = 0; i < nx[t]; i++) {
+      h->lont_halo[f_off[t] + (long)(j + 1) * (nx[t] + 2) + i + 1] = lont[t][(long)j * nx[t] + i];
+      h->latt_halo[f_off[t] + (long)(j + 1) * (nx[t] + 2) + i + 1] = latt[t][(long)j * nx[t] + i];
+    }
+  for (long e = 0; e < fo; e++) if (map[e] >= 0) { h->lont_halo[e] = h->lont_halo[map[e]]; h->latt_halo[e] = h->latt_halo[map[e]]; }
+  // geometry per tile
+  std::vector<double> dx(xo), dy(yo), area(co), ew(wo), ee(wo), es(so), en(so), enn(3 * xo), ene(3 * yo), vlon(3 * co), vlat(3 * co);
+  for (int t = 0; t < ntiles; t++) {
+    rc = fg_c2l_grid_info(nx[t], ny[t], h->lont_halo.data() + f_off[t], h->latt_halo.data() + f_off[t], lonc[t], latc[t],
+                          dx.data() + dx_off[t], dy.data() + dy_off[t], area.data() + cell_off[t], ew.data() + ew_off[t],
+                          ee.data() + ew_off[t], es.data() + es_off[t], en.data() + es_off[t], enn.data() + 3 * dx_off[t],
+                          ene.data() + 3 * dy_off[t], vlon.data() + 3 * cell_off[t], vlat.data() + 3 * cell_off[t]);
+    if (rc) { delete h; return fail(rc, "fg_c2l_grid_info failed"); }
+  }
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return fail(FG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  std::vector<char> th(fgd_c2l_tile_size() * ntiles);
+  for (int t = 0; t < ntiles; t++) fgd_c2l_tile_fill(th.data(), t, nx[t], ny[t], cell_off[t], f_off[t], dx_off[t], dy_off[t], ew_off[t], es_off[t]);
+  const std::vector<double> *src[11] = {&dx, &dy, &area, &ew, &ee, &es, &en, &enn, &ene, &vlon, &vlat};
+  bool ok = true;
+  h->tiles_dev = h->alloc<char>(th.size()); h->map_dev = h->alloc<int>(fo);
+  ok = ok && h->tiles_dev && h->map_dev;
+  for (int k = 0; k < 11 && ok; k++) { h->geom_dev[k] = h->alloc<double>(src[k]->size()); ok = ok && h->geom_dev[k]; }
+  if (!ok) { fg_c2l_destroy(h); return fail(FG_ERR_HIP, "out of device memory"); }
+  ok = ok && hipMemcpy(h->tiles_dev, th.data(), th.size(), hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(h->map_dev, map.data(), fo * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+  for (int k = 0; k < 11 && ok; k++) ok = hipMemcpy(h->geom_dev[k], src[k]->data(), src[k]->size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { fg_c2l_destroy(h); return fail(FG_ERR_HIP, "upload of the gradient geometry failed"); }
+  *out = h;
+  return 0;
+}
+
+extern "C" long fg_c2l_ncells(const fg_c2l *h) { return h ? h->ncells : FG_ERR_ARG; }
+extern "C" long fg_c2l_halo_size(const fg_c2l *h) { return h ? h->F : FG_ERR_ARG; }
+extern "C" int fg_c2l_set_stream(fg_c2l *h, void *stream)
+{
+  if (!h) return fail(FG_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipStreamDestroy(h->stream);
+  h->stream = (hipStream_t)stream;
+  return 0;
+}
+extern "C" int fg_c2l_sync(fg_c2l *h)
+{
+  if (!h) return fail(FG_ERR_ARG, "null handle");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+// host copies of the halo'd cell-centre arrays [F] (for tests)
+extern "C" int fg_c2l_get_centres(const fg_c2l *h, double *lont_halo, double *latt_halo)
+{
+  if (!h) return fail(FG_ERR_ARG, "null handle");
+  if (lont_halo) memcpy(lont_halo, h->lont_halo.data(), h->F * sizeof(double));
+  if (latt_halo) memcpy(latt_halo, h->latt_halo.data(), h->F * sizeof(double));
+  return 0;
+}
+
+// src [nz][ncells] (tiles back to back, no halo) -> halo_data [nz][F] with the halo filled from the neighbours.
+// src == NULL: halo_data already holds the interiors, only the halo is filled.  Device pointers.
+extern "C" int fg_c2l_fill_halo(fg_c2l *h, const double *src, double *halo_data, int nz)
+{
+  if (!h || !halo_data || nz < 1) return fail(FG_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (src) {
+    HIPCHK(hipMemsetAsync(halo_data, 0, (size_t)nz * h->F * sizeof(double), h->stream));   // init_halo (corners stay 0)
+    fgd_pack_interior(h->tiles_dev, h->ntiles, h->ncells, h->F, nz, src, halo_data, h->stream);
+  }
+  fgd_halo_gather(h->F, nz, h->map_dev, halo_data, h->stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// grad_c2l for every tile and level: halo_data [nz][F] -> grad_x, grad_y [nz][ncells]; grad_mask (int [nz][ncells],
+// may be NULL) is filled when has_missing (fregrid_util.c:2203-2216), zeroed otherwise.  Device pointers.
+extern "C" int fg_c2l_gradient(fg_c2l *h, const double *halo_data, int nz, int has_missing, double missing,
+                               double *grad_x, double *grad_y, int *grad_mask)
+{
+  if (!h || !halo_data || !grad_x || !grad_y || nz < 1) return fail(FG_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  fgd_grad_c2l(h->tiles_dev, h->ntiles, h->ncells, h->F, nz, halo_data, (const double *const *)h->geom_dev, grad_x, grad_y, h->stream);
+  if (grad_mask) {
+    if (has_missing) fgd_grad_mask(h->tiles_dev, h->ntiles, h->ncells, h->F, nz, halo_data, missing, grad_mask, h->stream);
+    else HIPCHK(hipMemsetAsync(grad_mask, 0, (size_t)nz * h->ncells * sizeof(int), h->stream));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}

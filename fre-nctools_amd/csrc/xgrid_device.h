@@ -103,3 +103,12 @@ void fgd_reduce_sum(const double *v, long n, double *partial, double *result, hi
 void fgd_poly_clip(int npoly, const double *lon1, const double *lat1, const int *n1, const double *lon2, const double *lat2,
                    const int *n2, double *lon_out, double *lat_out, int *n_out, hipStream_t st);
 void fgd_poly_op(int op, int npoly, double *lon, double *lat, int *n, const double *clon, double *result, hipStream_t st);
+
+// ---- order-2 input preparation (c2l_kernels.hip)
+void fgd_pack_interior(const void *tiles, int ntiles, long ncells, long F, int nz, const double *src, double *dst, hipStream_t st);
+void fgd_halo_gather(long F, int nz, const int *map, double *data, hipStream_t st);
+void fgd_grad_c2l(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, const double *const *geom,
+                  double *grad_x, double *grad_y, hipStream_t st);
+void fgd_grad_mask(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, double missing, int *mask, hipStream_t st);
+size_t fgd_c2l_tile_size(void);
+void fgd_c2l_tile_fill(void *dst, int idx, int nx, int ny, long cell_off, long f_off, long dx_off, long dy_off, long ew_off, long es_off);

@@ -34,3 +34,15 @@ def latlon_corners(nlon, nlat, lonbegin=0.0, lonend=360.0, latbegin=-90.0, laten
     if rc:
         raise ValueError(f"fg_latlon_corners failed: {rc}")
     return lon, lat
+
+
+def gnomonic_ed_grid(ni, shift_fac=18.0, via_degrees=True):
+    """C<ni> cubed sphere corners and T-cell centres: (lonc, latc [6, ni+1, ni+1], lont, latt [6, ni, ni])."""
+    lon = np.empty((6, ni + 1, ni + 1), dtype=np.float64)
+    lat = np.empty_like(lon)
+    lont = np.empty((6, ni, ni), dtype=np.float64)
+    latt = np.empty_like(lont)
+    rc = lib().fg_gnomonic_ed_grid(ni, float(shift_fac), 1 if via_degrees else 0, _dp(lon), _dp(lat), _dp(lont), _dp(latt))
+    if rc:
+        raise ValueError(f"fg_gnomonic_ed_grid({ni}) failed: {rc}")
+    return lon, lat, lont, latt

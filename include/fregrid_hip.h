@@ -236,11 +236,54 @@ int fg_clip_2dx2d_batch(int npoly, const double *lon1, const double *lat1, const
                         double *lon_out, double *lat_out, int *n_out);
 int fg_poly_op_batch(int op, int npoly, double *lon, double *lat, int *n, const double *clon, double *result);
 
+/* ------------------------------------------------- order-2 input preparation ---- */
+/* What get_input_data does for conserve_order2 before the sweep (tools/fregrid/fregrid_util.c:2137-2216):
+ * copy each level into a halo'd array, fill the halo from the neighbouring tiles (update_halo :2614), run
+ * grad_c2l (tools/libfrencutils/gradient_c2l.c:58) and build the missing-value gradient mask.  On the device. */
+typedef struct fg_c2l fg_c2l;
+
+/* Host, once per mosaic.  lonc/latc: corners [(ny+1)][(nx+1)], lont/latt: T-cell centres [ny][nx] (radians, host).
+ * Contacts in the convention read_mosaic_contact hands to fregrid (read_mosaic.c:655-777): tile numbers 1-based,
+ * 0-based model indices, istart == iend for a west/east edge (0 / nx-1), jstart == jend for south/north.
+ * Computes calc_c2l_grid_info (gradient_c2l.c:368) per tile on the host and keeps it in HBM. */
+int  fg_c2l_create(int ntiles, const int *nx, const int *ny, const double *const *lonc, const double *const *latc,
+                   const double *const *lont, const double *const *latt,
+                   int ncontacts, const int *tile1, const int *tile2,
+                   const int *istart1, const int *iend1, const int *jstart1, const int *jend1,
+                   const int *istart2, const int *iend2, const int *jstart2, const int *jend2,
+                   int device, fg_c2l **out);
+void fg_c2l_destroy(fg_c2l *h);
+long fg_c2l_ncells(const fg_c2l *h);        /* sum of nx*ny                   */
+long fg_c2l_halo_size(const fg_c2l *h);     /* F = sum of (nx+2)*(ny+2)       */
+int  fg_c2l_set_stream(fg_c2l *h, void *stream);
+int  fg_c2l_sync(fg_c2l *h);
+int  fg_c2l_get_centres(const fg_c2l *h, double *lont_halo, double *latt_halo);   /* host copies [F] */
+/* src [nz][ncells] (tiles back to back) -> halo_data [nz][F] with the halo filled (src == NULL: interiors are
+ * already in halo_data).  Device pointers. */
+int  fg_c2l_fill_halo(fg_c2l *h, const double *src, double *halo_data, int nz);
+/* halo_data [nz][F] -> grad_x, grad_y [nz][ncells]; grad_mask int [nz][ncells] or NULL.  Device pointers. */
+int  fg_c2l_gradient(fg_c2l *h, const double *halo_data, int nz, int has_missing, double missing,
+                     double *grad_x, double *grad_y, int *grad_mask);
+
+/* Host helpers behind fg_c2l_create, exported for tests and for callers without a mosaic file. */
+int fg_c2l_grid_info(int nx, int ny, const double *xt, const double *yt, const double *xc, const double *yc,
+                     double *dx, double *dy, double *area, double *edge_w, double *edge_e, double *edge_s,
+                     double *edge_n, double *en_n, double *en_e, double *vlon, double *vlat);
+int fg_find_contacts(int ntiles, const int *nx, const int *ny, const double *const *lonc, const double *const *latc,
+                     int max_contacts, int *tile1, int *tile2, int *istart1, int *iend1, int *jstart1, int *jend1,
+                     int *istart2, int *iend2, int *jstart2, int *jend2);
+int fg_halo_map(int ntiles, const int *nx, const int *ny, int ncontacts, const int *tile1, const int *tile2,
+                const int *istart1, const int *iend1, const int *jstart1, const int *jend1,
+                const int *istart2, const int *iend2, const int *jstart2, const int *jend2,
+                long *map_off, int *map);
+
 /* ---------------------------------------------------------------- (G) ----- */
 /* Equal-distance gnomonic cubed sphere ("gnomonic_ed"), C<ni>: cell corners of the six
  * tiles, lonc/latc[6*(ni+1)*(ni+1)] radians.  shift_fac as make_hgrid (default 18).
  * via_degrees != 0 reproduces the radians->degrees->radians round trip of the grid file. */
 int fg_gnomonic_ed_corners(int ni, double shift_fac, int via_degrees, double *lonc, double *latc);
+/* same, plus the T-cell centres lont/latt[6*ni*ni] (cell_center, create_gnomonic_cubic_grid.c:2008) */
+int fg_gnomonic_ed_grid(int ni, double shift_fac, int via_degrees, double *lonc, double *latc, double *lont, double *latt);
 /* Regular lat-lon grid of get_output_grid_by_size (degrees in, radians out),
  * lonc/latc[(nlat+1)*(nlon+1)]. */
 int fg_latlon_corners(int nlon, int nlat, double lonbegin, double lonend, double latbegin,

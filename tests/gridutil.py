@@ -9,7 +9,7 @@ D2R = np.pi / 180
 R2D = 180 / np.pi
 
 
-def ref_gnomonic_corners(ni):
+def ref_gnomonic_corners(ni, centres=False, supergrid=False):
     """C<ni> corners from the REFERENCE generator (create_gnomonic_cubic_grid.c:101 compiled in oracle/_ref),
     with fregrid's read-back (every 2nd supergrid point, degrees * D2R; fregrid_util.c:227-232).
     The generator chats on stderr; that is the reference's behaviour."""
@@ -35,9 +35,14 @@ def ref_gnomonic_corners(ni):
     P = lambda a: a.ctypes.data_as(dp)
     f(b"gnomonic_ed", nlon, nlat, P(x), P(y), P(dx), P(dy), P(area), P(adx), P(ady),
       18.0, 0, 0, 1.0, 0.0, 0.0, 0, nest, nest, nest, nest, nest, nest, 0, 0)
-    x = x.reshape(6, nxp, nxp)[:, ::2, ::2] * D2R
-    y = y.reshape(6, nxp, nxp)[:, ::2, ::2] * D2R
-    return np.ascontiguousarray(x), np.ascontiguousarray(y)
+    x = x.reshape(6, nxp, nxp)
+    y = y.reshape(6, nxp, nxp)
+    if supergrid:
+        return x, y                                  # degrees, as make_hgrid writes them
+    if centres:                                      # T-cell centres: odd supergrid points (fregrid_util.c:238-243)
+        return (np.ascontiguousarray(x[:, ::2, ::2] * D2R), np.ascontiguousarray(y[:, ::2, ::2] * D2R),
+                np.ascontiguousarray(x[:, 1::2, 1::2] * D2R), np.ascontiguousarray(y[:, 1::2, 1::2] * D2R))
+    return np.ascontiguousarray(x[:, ::2, ::2] * D2R), np.ascontiguousarray(y[:, ::2, ::2] * D2R)
 
 
 def analytic_field(lon_c, lat_c):
