@@ -84,37 +84,45 @@ __global__ __launch_bounds__(256) void k_grad_c2l(const C2lTile *tiles, int ntil
                                                    const double *data, C2lGeom g, double *grad_x, double *grad_y)
 {
   long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  int k = blockIdx.y;
   if (c >= ncells) return;
   const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
   const int nx = T.nx, ny = T.ny, nxp = nx + 1;
   long loc = c - T.cell_off;
   const int i = (int)(loc % nx), j = (int)(loc / nx);
-  const double *q = data + (size_t)k * F + T.f_off;
   const double *ew = g.edge_w + T.ew_off, *ee = g.edge_e + T.ew_off, *es = g.edge_s + T.es_off, *en = g.edge_n + T.es_off;
-  const double b00 = d_a2b(q, nx, ny, i, j, ew, ee, es, en), b10 = d_a2b(q, nx, ny, i + 1, j, ew, ee, es, en);
-  const double b01 = d_a2b(q, nx, ny, i, j + 1, ew, ee, es, en), b11 = d_a2b(q, nx, ny, i + 1, j + 1, ew, ee, es, en);
   const double *dx = g.dx + T.dx_off, *dy = g.dy + T.dy_off;
   const double *enn = g.en_n + 3 * T.dx_off, *ene = g.en_e + 3 * T.dy_off;
   const long ms = (long)j * nx + i, mn = (long)(j + 1) * nx + i;       // south / north edges of the cell
   const long mw = (long)j * nxp + i, me = mw + 1;                       // west / east edges
-  double g3[3];
+  // the geometry of the cell is level-independent: load it once, then sweep the levels
+  const double dxs = dx[ms], dxn = dx[mn], dyw = dy[mw], dye = dy[me];
+  double ens[3], enn3[3], enw[3], ene3[3], vlo[3], vla[3];
 #pragma unroll
   for (int n = 0; n < 3; n++) {
-    double pdx_s = 0.5 * (b00 + b10) * dx[ms] * enn[3 * ms + n];
-    double pdx_n = 0.5 * (b01 + b11) * dx[mn] * enn[3 * mn + n];
-    double pdy_w = 0.5 * (b00 + b01) * dy[mw] * ene[3 * mw + n];
-    double pdy_e = 0.5 * (b10 + b11) * dy[me] * ene[3 * me + n];
-    g3[n] = pdx_n - pdx_s - pdy_w + pdy_e;
+    ens[n] = enn[3 * ms + n]; enn3[n] = enn[3 * mn + n]; enw[n] = ene[3 * mw + n]; ene3[n] = ene[3 * me + n];
+    vlo[n] = g.vlon[3 * c + n]; vla[n] = g.vlat[3 * c + n];
   }
-  const double *vlon = g.vlon + 3 * c, *vlat = g.vlat + 3 * c;
   const double area = g.area[c];
-  double gx = (vlon[0] * g3[0] + vlon[1] * g3[1] + vlon[2] * g3[2]) / area;
-  gx *= 6371000.;
-  double gy = (vlat[0] * g3[0] + vlat[1] * g3[1] + vlat[2] * g3[2]) / area;
-  gy *= 6371000.;
-  grad_x[(size_t)k * ncells + c] = gx;
-  grad_y[(size_t)k * ncells + c] = gy;
+  for (int k = 0; k < nz; k++) {
+    const double *q = data + (size_t)k * F + T.f_off;
+    const double b00 = d_a2b(q, nx, ny, i, j, ew, ee, es, en), b10 = d_a2b(q, nx, ny, i + 1, j, ew, ee, es, en);
+    const double b01 = d_a2b(q, nx, ny, i, j + 1, ew, ee, es, en), b11 = d_a2b(q, nx, ny, i + 1, j + 1, ew, ee, es, en);
+    double g3[3];
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
+      double pdx_s = 0.5 * (b00 + b10) * dxs * ens[n];
+      double pdx_n = 0.5 * (b01 + b11) * dxn * enn3[n];
+      double pdy_w = 0.5 * (b00 + b01) * dyw * enw[n];
+      double pdy_e = 0.5 * (b10 + b11) * dye * ene3[n];
+      g3[n] = pdx_n - pdx_s - pdy_w + pdy_e;
+    }
+    double gx = (vlo[0] * g3[0] + vlo[1] * g3[1] + vlo[2] * g3[2]) / area;
+    gx *= 6371000.;
+    double gy = (vla[0] * g3[0] + vla[1] * g3[1] + vla[2] * g3[2]) / area;
+    gy *= 6371000.;
+    grad_x[(size_t)k * ncells + c] = gx;
+    grad_y[(size_t)k * ncells + c] = gy;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_grad_mask(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
@@ -152,7 +160,7 @@ void fgd_grad_c2l(const void *tiles, int ntiles, long ncells, long F, int nz, co
 {
   if (ncells <= 0 || nz <= 0) return;
   C2lGeom g{geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9], geom[10]};
-  k_grad_c2l<<<dim3(nblk(ncells, 256), nz), 256, 0, st>>>((const C2lTile *)tiles, ntiles, ncells, F, nz, data, g, grad_x, grad_y);
+  k_grad_c2l<<<nblk(ncells, 256), 256, 0, st>>>((const C2lTile *)tiles, ntiles, ncells, F, nz, data, g, grad_x, grad_y);
 }
 void fgd_grad_mask(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, double missing, int *mask, hipStream_t st)
 {
