@@ -32,7 +32,7 @@ EXPORTS = [
     "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_stream", "fg_plan_sync",
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
     "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
-    "fg_gnomonic_ed_grid",
+    "fg_gnomonic_ed_grid", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
     "fg_plan_stats", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
 
@@ -159,6 +159,15 @@ def lib():
     L.fg_halo_map.restype = C.c_int
     L.fg_gnomonic_ed_grid.argtypes = [C.c_int, C.c_double, C.c_int, dp, dp, dp, dp]
     L.fg_gnomonic_ed_grid.restype = C.c_int
+    L.fg_remap_write.argtypes = [C.c_char_p, C.c_int, C.c_long, ip, ip, ip, dp, dp]
+    L.fg_remap_write.restype = C.c_int
+    L.fg_remap_write_interp.argtypes = [C.c_char_p, C.c_int, C.c_long] + [ip] * 5 + [dp] * 3 + [C.c_int, C.c_int]
+    L.fg_remap_write_interp.restype = C.c_int
+    L.fg_remap_read_size.argtypes = [C.c_char_p]
+    L.fg_remap_read_size.restype = C.c_long
+    L.fg_remap_read.argtypes = [C.c_char_p, C.c_int, C.c_long] + [ip] * 5 + [dp] * 3
+    L.fg_remap_read.restype = C.c_int
+    L.fg_remap_last_error.restype = C.c_char_p
     L.fg_gnomonic_ed_corners.argtypes = [C.c_int, C.c_double, C.c_int, dp, dp]
     L.fg_gnomonic_ed_corners.restype = C.c_int
     L.fg_latlon_corners.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp]

@@ -49,6 +49,8 @@ class GridConfig:
     lonc: np.ndarray
     latc: np.ndarray
     cell_area: Optional[np.ndarray] = None     # filled by setup_conserve_interp (get_grid_area semantics)
+    isc: int = 0                               # start of this rank's compute domain in the whole output tile
+    jsc: int = 0                               # (grid_out[n].isc / jsc, fregrid_util.c:598-603)
 
     @property
     def nxc(self):
@@ -271,6 +273,8 @@ class InterpConfig:
     dj_in: Optional[np.ndarray] = None
     area: Optional[np.ndarray] = None
     plan: Optional[XgridPlan] = None
+    remap_file: Optional[str] = None           # Interp_config.remap_file (globals.h:155); used with READ / WRITE
+    file_exist: int = 0
 
 
 def _torch():
@@ -288,6 +292,29 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
     if not (opcode & (CONSERVE_ORDER1 | CONSERVE_ORDER2)):
         raise ValueError("conserve_interp: interp_method should be CONSERVE_ORDER1 or CONSERVE_ORDER2")
     torch = _torch()
+    if opcode & READ:                                                  # conserve_interp.c:62-126
+        from .remap_file import read_remap_file
+        for n in range(ntiles_out):
+            ic = interp[n]
+            if not ic.file_exist:
+                continue
+            x = read_remap_file(ic.remap_file, order)
+            g = grid_out[n]
+            keep = ((x["i_out"] >= g.isc) & (x["i_out"] <= g.isc + g.nx - 1) &
+                    (x["j_out"] >= g.jsc) & (x["j_out"] <= g.jsc + g.ny - 1))          # :93-97
+            sel = {k: v[keep] for k, v in x.items()}
+            sel["i_out"] = sel["i_out"] - g.isc
+            sel["j_out"] = sel["j_out"] - g.jsc
+            plan = XgridPlan.create_empty(order, [gi.nx for gi in grid_in[:ntiles_in]], [gi.ny for gi in grid_in[:ntiles_in]],
+                                          g.nx, g.ny, device=device)
+            plan.set_xgrid(sel["t_in"], sel["i_in"], sel["j_in"], sel["i_out"], sel["j_out"], sel["area"],
+                           sel.get("di_in"), sel.get("dj_in"))
+            ic.plan, ic.nxgrid = plan, int(keep.sum())
+            ic.t_in, ic.i_in, ic.j_in, ic.i_out, ic.j_out, ic.area = (sel["t_in"], sel["i_in"], sel["j_in"], sel["i_out"],
+                                                                       sel["j_out"], sel["area"])
+            ic.di_in, ic.dj_in = sel.get("di_in"), sel.get("dj_in")
+        print("NOTE: Finish reading index and weight for conservative interpolation from file.")   # :125
+        return interp
     plans = []
     for n in range(ntiles_out):
         plans.append(XgridPlan.create(order, grid_in[:ntiles_in], grid_out[n], device=device))
@@ -325,6 +352,19 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
                                                                        x["j_out"], x["area"])
             if order == 2:
                 ic.di_in, ic.dj_in = x["c1"], x["c2"]
+    if opcode & WRITE:                                                 # conserve_interp.c:368-445 (single rank: no gather)
+        from .remap_file import write_remap_file
+        for n in range(ntiles_out):
+            ic = interp[n]
+            if ic.remap_file and ic.nxgrid > 0:
+                if not fetch:
+                    x = plans[n].get_xgrid()
+                    ic.t_in, ic.i_in, ic.j_in, ic.i_out, ic.j_out, ic.area = (x["t_in"], x["i_in"], x["j_in"], x["i_out"],
+                                                                               x["j_out"], x["area"])
+                    if order == 2:
+                        ic.di_in, ic.dj_in = x["c1"], x["c2"]
+                write_remap_file(ic.remap_file, order, ic.t_in, ic.i_in, ic.j_in, ic.i_out, ic.j_out, ic.area,
+                                 ic.di_in, ic.dj_in, grid_out[n].isc, grid_out[n].jsc)
     print("NOTE: done calculating index and weight for conservative interpolation")   # :446
     return interp
 

@@ -277,6 +277,19 @@ int fg_halo_map(int ntiles, const int *nx, const int *ny, int ncontacts, const i
                 const int *istart2, const int *iend2, const int *jstart2, const int *jend2,
                 long *map_off, int *map);
 
+/* ------------------------------------------------- remap file without libnetcdf -- */
+/* Classic-netCDF writer/reader for fregrid's --remap_file (written at tools/fregrid/conserve_interp.c:368-445, read
+ * through tools/libfrencutils/read_mosaic.c:352-558).  Host functions; see csrc/remap_file.c for the layout. */
+int  fg_remap_write(const char *path, int order, long ncells, const int *tile1, const int *tile1_cell,
+                    const int *tile2_cell, const double *xgrid_area, const double *tile1_distance);  /* file variables as is (1-based) */
+int  fg_remap_write_interp(const char *path, int order, long n, const int *t_in, const int *i_in, const int *j_in,
+                           const int *i_out, const int *j_out, const double *area, const double *di_in,
+                           const double *dj_in, int isc, int jsc);                                    /* from 0-based Interp_config arrays */
+long fg_remap_read_size(const char *path);                                                            /* read_mosaic_xgrid_size */
+int  fg_remap_read(const char *path, int order, long ncells, int *t_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                   double *area, double *di_in, double *dj_in);                                       /* 0-based, reference conversions applied */
+const char *fg_remap_last_error(void);
+
 /* ---------------------------------------------------------------- (G) ----- */
 /* Equal-distance gnomonic cubed sphere ("gnomonic_ed"), C<ni>: cell corners of the six
  * tiles, lonc/latc[6*(ni+1)*(ni+1)] radians.  shift_fac as make_hgrid (default 18).

@@ -339,3 +339,43 @@ def test_full_size_properties_c384(fg, gpu_ok):
     gs = plan.apply(pos, o1, nz=1, grad_x_t=z, grad_y_t=z, want_gsum=True)
     assert abs(gs - np.sum(x["area"])) < 1e-12 * gs
     plan.destroy()
+
+
+def test_remap_file_write_then_read_branch(fg, gpu_ok, tmp_path):
+    """BASELINE configs 4/5: 'write remap_file' then 'read cached remap_file' (set_remap_file semantics,
+    fregrid_util.c:1946-1992): the READ branch must sweep exactly like the plan that computed the weights."""
+    import torch
+    ni, nlon, nlat = 32, 96, 48
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grid_in = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    path = str(tmp_path / "remap.tile1.nc")
+    interp = [fg.InterpConfig(remap_file=path)]
+    fg.setup_conserve_interp(6, grid_in, 1, [fg.GridConfig(nlon, nlat, lo, la)], interp, fg.CONSERVE_ORDER2 | fg.WRITE)
+    assert fg.lib().fg_remap_read_size(path.encode()) == interp[0].nxgrid
+    interp2 = [fg.InterpConfig(remap_file=path, file_exist=1)]
+    fg.setup_conserve_interp(6, grid_in, 1, [fg.GridConfig(nlon, nlat, lo, la)], interp2, fg.CONSERVE_ORDER2 | fg.READ)
+    assert interp2[0].nxgrid == interp[0].nxgrid
+    for k in ("t_in", "i_in", "j_in", "i_out", "j_out", "di_in", "dj_in"):
+        assert np.array_equal(getattr(interp2[0], k), getattr(interp[0], k)), k
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(4)
+    data = torch.randn(1, 6 * (ni + 2) ** 2, dtype=torch.float64, generator=g).to(dev)
+    gx = torch.randn(1, 6 * ni * ni, dtype=torch.float64, generator=g).to(dev)
+    gy = torch.randn(1, 6 * ni * ni, dtype=torch.float64, generator=g).to(dev)
+    o1 = torch.empty(nlon * nlat, dtype=torch.float64, device=dev); o2 = torch.empty_like(o1)
+    torch.cuda.synchronize()
+    interp[0].plan.apply(data, o1, nz=1, grad_x_t=gx, grad_y_t=gy); interp[0].plan.sync()
+    interp2[0].plan.apply(data, o2, nz=1, grad_x_t=gx, grad_y_t=gy); interp2[0].plan.sync()
+    a, b = o1.cpu().numpy(), o2.cpu().numpy()
+    # the file round trip rescales the areas (area/garea*garea, read_mosaic.c:432 + conserve_interp.c:86): last-bit changes only
+    assert np.max(np.abs(a - b)) <= 1e-13 * np.max(np.abs(a))
+    # rank-local read: keep only the cells of a latitude band (conserve_interp.c:93-112)
+    j0, j1 = fg.band_rows(nlat, 2, 1)
+    band = fg.GridConfig(nlon, j1 - j0, lo[j0:j1 + 1], la[j0:j1 + 1], jsc=j0)
+    interp3 = [fg.InterpConfig(remap_file=path, file_exist=1)]
+    fg.setup_conserve_interp(6, grid_in, 1, [band], interp3, fg.CONSERVE_ORDER2 | fg.READ)
+    o3 = torch.empty(nlon * (j1 - j0), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    interp3[0].plan.apply(data, o3, nz=1, grad_x_t=gx, grad_y_t=gy); interp3[0].plan.sync()
+    assert np.array_equal(o3.cpu().numpy(), b.reshape(nlat, nlon)[j0:j1].ravel())
