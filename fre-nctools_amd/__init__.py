@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import FregridHipError, lib, lib_path  # noqa: F401
-from .grids import gnomonic_ed_corners, gnomonic_ed_grid, latlon_corners  # noqa: F401
+from .grids import gnomonic_ed_corners, gnomonic_ed_grid, latlon_corners, tripolar_corners  # noqa: F401
 from .c2l import C2lPrep, find_contacts, c2l_grid_info, halo_map  # noqa: F401
 from .remap_file import write_remap_file, read_remap_file  # noqa: F401
 from .parallel import band_rows, allreduce_cell_sums, allreduce_scalar_sum  # noqa: F401

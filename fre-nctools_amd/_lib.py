@@ -32,7 +32,7 @@ EXPORTS = [
     "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_stream", "fg_plan_sync",
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
     "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
-    "fg_gnomonic_ed_grid", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
+    "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
     "fg_plan_stats", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
 
@@ -157,6 +157,8 @@ def lib():
     L.fg_find_contacts.restype = C.c_int
     L.fg_halo_map.argtypes = [C.c_int, ip, ip, C.c_int] + [ip] * 10 + [lp, ip]
     L.fg_halo_map.restype = C.c_int
+    L.fg_tripolar_corners.argtypes = [C.c_int, C.c_int] + [C.c_double] * 5 + [dp, dp]
+    L.fg_tripolar_corners.restype = C.c_int
     L.fg_gnomonic_ed_grid.argtypes = [C.c_int, C.c_double, C.c_int, dp, dp, dp, dp]
     L.fg_gnomonic_ed_grid.restype = C.c_int
     L.fg_remap_write.argtypes = [C.c_char_p, C.c_int, C.c_long, ip, ip, ip, dp, dp]

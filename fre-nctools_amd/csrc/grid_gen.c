@@ -354,3 +354,98 @@ int fg_latlon_corners(int nlon, int nlat, double lonbegin, double lonend, double
   }
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------- tripolar grid
+ * make_hgrid --grid_type tripolar_grid with two bounds per axis (uniform spacing) and center "none":
+ * tools/make_hgrid/create_lonlat_grid.c:360-447 (grid lines, join latitude, Murray bipolar cap) with
+ * compute_grid_bound / tp_trans / bp_lam / bp_phi / lat_dist / lon_in_range of tools/libfrencutils/tool_util.c:263-365,
+ * :479-536 and the two-point (linear) case of cubic_spline_sp (interp.c:65-69), followed by fregrid's read-back of
+ * every second supergrid point (fregrid_util.c:227-232).
+ * NOT PINNED to the reference generator: tool_util.c includes <netcdf.h>, which this image lacks, so it cannot be
+ * compiled here.  The generator only synthesises test/benchmark inputs; parity of the search on these inputs is
+ * established against the oracle, which does not depend on how the grid was made. */
+static double tp_lat_dist(double x1, double x2)
+{
+  double a = fmod(x1 - x2 + 720, 360.), b = fmod(x2 - x1 + 720, 360.);
+  return a < b ? a : b;
+}
+static double tp_lon_in_range(double lon, double lon_strt)
+{
+  const double SMALL = 1.0e-4;
+  double v = lon, lon_end = lon_strt + 360.;
+  if (fabs(v - lon_strt) < SMALL) v = lon_strt;
+  else if (fabs(v - lon_end) < SMALL) v = lon_strt;
+  else {
+    while (1) {
+      if (v < lon_strt) v = v + 360.;
+      else if (v > lon_end) v = v - 360.;
+      else break;
+    }
+  }
+  return v;
+}
+static void tp_trans1(double *lon, double *lat, double lon_ref, double lon_start, double lam0, double bpeq, double bpsp, double bpnp, double rp)
+{
+  const double SMALL = 1.0e-4;
+  double bp_lam = 2. * atan(tan((0.5 * FG_PI - (*lat) * FG_D2R) / 2) / rp) * FG_R2D;
+  if (tp_lat_dist(*lon, bpeq) < 90.) bp_lam = -bp_lam;
+  double bp_phi = (tp_lat_dist(*lon, bpsp) < 90.) ? (-90 + tp_lat_dist(*lon, bpsp)) : (90 - tp_lat_dist(*lon, bpnp));
+  double lamc = bp_lam * FG_D2R, phic = bp_phi * FG_D2R, chic, phis, lams;
+  if (fabs(*lat - 90.) < SMALL) {
+    if (phic > 0) *lon = tp_lon_in_range(lon_start, lon_ref);
+    else *lon = lon_start + 180.;
+    chic = acos(cos(lamc) * cos(phic));
+    phis = FG_PI * 0.5 - 2 * atan(rp * tan(chic / 2));
+    *lat = phis * FG_R2D;
+    return;
+  }
+  if (fabs(lamc) < SMALL && fabs(phic) < SMALL) { *lat = 90.; *lon = lon_ref; }
+  else {
+    lams = fmod(lam0 + FG_PI + FG_PI / 2 - atan2(sin(lamc), tan(phic)), 2 * FG_PI);
+    chic = acos(cos(lamc) * cos(phic));
+    phis = FG_PI * 0.5 - 2 * atan(rp * tan(chic / 2));
+    *lon = lams * FG_R2D;
+    *lon = tp_lon_in_range(*lon, lon_ref);
+    *lat = phis * FG_R2D;
+  }
+}
+
+/* nlon x nlat model cells; bounds in degrees (e.g. -280, 80, -82, 90 as tests/fregrid/latlon:36-37); lat_join 65.
+ * lonc/latc [(nlat+1)*(nlon+1)] radians. */
+int fg_tripolar_corners(int nlon, int nlat, double xbnd0, double xbnd1, double ybnd0, double ybnd1, double lat_join_in,
+                        double *lonc, double *latc)
+{
+  if (nlon < 2 || nlat < 2) return -1;
+  const int nx = 2 * nlon, ny = 2 * nlat, nxp = nx + 1, nyp = ny + 1;       /* supergrid */
+  double *xb = (double *)malloc(nxp * sizeof(double)), *yb = (double *)malloc(nyp * sizeof(double));
+  double *x = (double *)malloc((size_t)nxp * nyp * sizeof(double)), *y = (double *)malloc((size_t)nxp * nyp * sizeof(double));
+  if (!xb || !yb || !x || !y) { free(xb); free(yb); free(x); free(y); return -2; }
+  double px = (xbnd1 - xbnd0) / ((nx + 1.0) - 1.0), py = (ybnd1 - ybnd0) / ((ny + 1.0) - 1.0);
+  for (int i = 0; i < nxp; i++) xb[i] = px * ((i + 1.0) - 1.0) + xbnd0;
+  for (int j = 0; j < nyp; j++) yb[j] = py * ((j + 1.0) - 1.0) + ybnd0;
+  for (int j = 0; j < nyp; j++) for (int i = 0; i < nxp; i++) { x[(size_t)j * nxp + i] = xb[i]; y[(size_t)j * nxp + i] = yb[j]; }
+  /* nearest_index (mosaic_util.c:81-109) */
+  int j_join;
+  if (lat_join_in < yb[0]) j_join = 0;
+  else if (lat_join_in > yb[nyp - 1]) j_join = nyp - 1;
+  else {
+    int i = 0; j_join = 0;
+    while (i < nyp) { i = i + 1; if (lat_join_in <= yb[i]) { j_join = i; if (yb[i] - lat_join_in > lat_join_in - yb[i - 1]) j_join = i - 1; break; } }
+  }
+  const double lat_join = yb[j_join], lon_start = xbnd0;
+  const double lon_bpeq = lon_start + 90., lon_bpnp = lon_start, lon_bpsp = lon_start + 180.;
+  const double lam0 = fmod(lon_bpeq * FG_D2R + 2 * FG_PI, 2 * FG_PI);
+  const double rp = tan((0.5 * FG_PI - lat_join * FG_D2R) / 2.);
+  for (int j = j_join; j < nyp; j++)
+    for (int i = 0; i < nxp; i++) {
+      double lon_last = x[(size_t)j * nxp + (i - 1 > 0 ? i - 1 : 0)];
+      tp_trans1(&x[(size_t)j * nxp + i], &y[(size_t)j * nxp + i], lon_last, lon_start, lam0, lon_bpeq, lon_bpsp, lon_bpnp, rp);
+    }
+  for (int j = 0; j <= nlat; j++)
+    for (int i = 0; i <= nlon; i++) {
+      lonc[(size_t)j * (nlon + 1) + i] = x[(size_t)(2 * j) * nxp + 2 * i] * FG_D2R;
+      latc[(size_t)j * (nlon + 1) + i] = y[(size_t)(2 * j) * nxp + 2 * i] * FG_D2R;
+    }
+  free(xb); free(yb); free(x); free(y);
+  return 0;
+}

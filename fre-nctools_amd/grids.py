@@ -46,3 +46,13 @@ def gnomonic_ed_grid(ni, shift_fac=18.0, via_degrees=True):
     if rc:
         raise ValueError(f"fg_gnomonic_ed_grid({ni}) failed: {rc}")
     return lon, lat, lont, latt
+
+
+def tripolar_corners(nlon, nlat, xbnd=(-280.0, 80.0), ybnd=(-82.0, 90.0), lat_join=65.0):
+    """Tripolar ocean grid corners (bounds as tests/fregrid/latlon:36-37): (lonc, latc) [nlat+1, nlon+1] radians."""
+    lon = np.empty((nlat + 1, nlon + 1), dtype=np.float64)
+    lat = np.empty_like(lon)
+    rc = lib().fg_tripolar_corners(nlon, nlat, xbnd[0], xbnd[1], ybnd[0], ybnd[1], lat_join, _dp(lon), _dp(lat))
+    if rc:
+        raise ValueError(f"fg_tripolar_corners failed: {rc}")
+    return lon, lat

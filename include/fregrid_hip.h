@@ -302,6 +302,11 @@ int fg_gnomonic_ed_grid(int ni, double shift_fac, int via_degrees, double *lonc,
 int fg_latlon_corners(int nlon, int nlat, double lonbegin, double lonend, double latbegin,
                       double latend, int center_y, double *lonc, double *latc);
 
+/* Tripolar ocean grid (make_hgrid --grid_type tripolar_grid, uniform bounds, Murray bipolar cap north of lat_join):
+ * nlon x nlat model cells, bounds in degrees, lonc/latc[(nlat+1)*(nlon+1)] radians.  Input synthesis only (see grid_gen.c). */
+int fg_tripolar_corners(int nlon, int nlat, double xbnd0, double xbnd1, double ybnd0, double ybnd1, double lat_join,
+                        double *lonc, double *latc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,3 +140,25 @@ def test_oracle_setup_and_apply_conserve(fg):
     assert np.max(np.abs(out - 3.25)) < 1e-14
     earth = 4 * np.pi * 6371000.0 ** 2
     assert abs(gs / 3.25 - earth) / earth < 5e-9
+
+
+def test_tripolar_generator_properties(fg):
+    """fg_tripolar_corners (unpinned restatement of create_tripolar_grid): regular below the join latitude, cap cells
+    close on the spherical cap, the top row is the fold (mirror-symmetric about lon_start+90 / +270)."""
+    nlon, nlat = 72, 43
+    lon, lat = fg.tripolar_corners(nlon, nlat)
+    lonr, latr = fg.latlon_corners(nlon, nlat, -280.0, 80.0, -82.0, 90.0)
+    yb = np.degrees(latr[:, 0])
+    jj = int(np.argmin(np.abs(yb - 65.0)))
+    assert np.array_equal(lon[:jj], lonr[:jj]) or np.max(np.abs(lon[:jj] - lonr[:jj])) < 1e-13
+    assert np.max(np.abs(lat[:jj + 1] - latr[:jj + 1])) < 1e-13
+    assert np.all(lat[jj:] >= lat[jj, 0] - 1e-12) and np.all(lat <= np.pi / 2)
+    area = orc.orc_get_grid_area(nlon, nlat, lon, lat)
+    assert area.min() > 0
+    R = 6371000.0
+    cap = 2 * np.pi * R * R * (1 + np.sin(np.radians(82.0)))
+    assert abs(area.sum() / cap - 1) < 1e-9
+    top_lat = lat[-1]
+    assert np.max(np.abs(top_lat - top_lat[::-1])) < 1e-12          # fold symmetry
+    half = nlon // 2
+    assert np.max(np.abs(top_lat[:half + 1] - top_lat[:half + 1][::-1])) < 1e-12

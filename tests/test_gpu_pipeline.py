@@ -192,6 +192,31 @@ def test_curvilinear_target_with_pole_caps(fg, gpu_ok):
     assert n > 0
 
 
+def test_tripolar_both_directions(fg, gpu_ok):
+    """BASELINE config 5 scaled down: tripolar ocean grid (longitudes -280..80, bipolar Arctic cap with the fold
+    along the top row) <-> cubed-sphere tiles, neither side lat-lon.  The generator is unpinned input synthesis
+    (grid_gen.c); parity of the search on it is against the oracle."""
+    tlon, tlat = fg.tripolar_corners(90, 54)
+    lon, lat = fg.gnomonic_ed_corners(16)
+    tot = 0
+    for t in range(6):                                   # ocean -> atmosphere tile t
+        n, st = _plan_vs_oracle(fg, 2 if t in (2, 4) else 1, [(90, 54, tlon, tlat)], (16, 16, lon[t], lat[t]))
+        tot += n
+    assert tot > 6 * 256
+    # atmosphere (all six tiles) -> ocean, second order
+    n, st = _plan_vs_oracle(fg, 2, [(16, 16, lon[t], lat[t]) for t in range(6)], (90, 54, tlon, tlat))
+    assert n > 90 * 54
+    # exchange-grid area closes on the ocean grid's own area (every ocean cell is fully covered by the sphere)
+    grids = [fg.GridConfig(16, 16, lon[t], lat[t]) for t in range(6)]
+    plan = fg.XgridPlan.create(1, grids, fg.GridConfig(90, 54, tlon, tlat))
+    plan.finalize()
+    x = plan.get_xgrid()
+    plan.destroy()
+    got = np.bincount(x["j_out"].astype(np.int64) * 90 + x["i_out"], weights=x["area"], minlength=90 * 54)
+    area = orc.orc_get_grid_area(90, 54, tlon, tlat)
+    assert np.max(np.abs(got - area) / area) < 2e-3      # poly_area's great-circle-vs-parallel edge model, not a bug
+
+
 def test_coarse_to_fine_and_fine_to_coarse(fg, gpu_ok):
     lon, lat = fg.gnomonic_ed_corners(8)
     lo, la = fg.latlon_corners(240, 120)
