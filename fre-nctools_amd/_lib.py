@@ -29,12 +29,20 @@ EXPORTS = [
     "fg_last_error", "fg_device_count", "fg_plan_create", "fg_plan_create_dev", "fg_plan_create_empty",
     "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
     "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
-    "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_stream", "fg_plan_sync",
+    "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_apply_ex", "fg_plan_mono_begin",
+    "fg_plan_mono_minmax_dev", "fg_plan_mono_copy_minmax", "fg_plan_mono_end", "fg_plan_stream", "fg_plan_sync",
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
     "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
     "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
     "fg_plan_stats", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
+
+
+class ApplyOpts(C.Structure):
+    """fg_apply_opts (include/fregrid_hip.h); pointer members are device addresses."""
+    _fields_ = [("has_missing", C.c_int), ("missing", C.c_double), ("weight", C.c_void_p),
+                ("cell_methods_sum", C.c_int), ("field_area", C.c_void_p), ("area_missing", C.c_double),
+                ("cell_area_in", C.c_void_p), ("cell_area_out", C.c_void_p), ("monotonic", C.c_int)]
 
 
 def lib():
@@ -122,6 +130,17 @@ def lib():
     L.fg_plan_apply.restype = C.c_int
     L.fg_plan_apply_interleaved.argtypes = [vp, C.c_int, vp, vp, vp, vp, dp]
     L.fg_plan_apply_interleaved.restype = C.c_int
+    ao = C.POINTER(ApplyOpts)
+    L.fg_plan_apply_ex.argtypes = [vp, ao, vp, vp, vp, vp, C.c_int, vp, dp]
+    L.fg_plan_apply_ex.restype = C.c_int
+    L.fg_plan_mono_begin.argtypes = [vp, ao, vp, vp, vp, vp]
+    L.fg_plan_mono_begin.restype = C.c_int
+    L.fg_plan_mono_minmax_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.fg_plan_mono_minmax_dev.restype = C.c_int
+    L.fg_plan_mono_copy_minmax.argtypes = [vp, C.c_int, vp, vp]
+    L.fg_plan_mono_copy_minmax.restype = C.c_int
+    L.fg_plan_mono_end.argtypes = [vp, ao, vp, vp, dp]
+    L.fg_plan_mono_end.restype = C.c_int
     L.fg_plan_stream.argtypes = [vp]
     L.fg_plan_stream.restype = vp
     L.fg_plan_sync.argtypes = [vp]

@@ -21,9 +21,13 @@ from ._lib import lib, check
 # option bits, tools/libfrencutils/globals.h:46-61
 CONSERVE_ORDER1 = 1
 CONSERVE_ORDER2 = 2
+TARGET = 16
 READ = 256
 WRITE = 512
 CHECK_CONSERVE = 1024
+MONOTONIC = 16384
+CELL_METHODS_MEAN = 0      # globals.h:64-65
+CELL_METHODS_SUM = 1
 MAXVAL = 1.0e20            # conserve_interp.c:36
 
 
@@ -49,6 +53,8 @@ class GridConfig:
     lonc: np.ndarray
     latc: np.ndarray
     cell_area: Optional[np.ndarray] = None     # filled by setup_conserve_interp (get_grid_area semantics)
+    weight: Optional[np.ndarray] = None        # grid_in[].weight [ny, nx] (--weight_file/--weight_field)
+    weight_exist: int = 0
     isc: int = 0                               # start of this rank's compute domain in the whole output tile
     jsc: int = 0                               # (grid_out[n].isc / jsc, fregrid_util.c:598-603)
 
@@ -68,6 +74,10 @@ class VarConfig:
     interp_method: int = CONSERVE_ORDER1
     has_missing: int = 0
     missing: float = -MAXVAL
+    cell_measures: int = 0                     # the variable carries its own cell area (field_in[].area)
+    cell_methods: int = CELL_METHODS_MEAN
+    area_missing: float = -MAXVAL
+    use_volume: int = 0
 
 
 @dataclass
@@ -78,6 +88,7 @@ class FieldConfig:
     grad_x: Optional[np.ndarray] = None
     grad_y: Optional[np.ndarray] = None
     grad_mask: Optional[np.ndarray] = None
+    area: Optional[np.ndarray] = None          # field_in[].area [ny, nx] of a cell_measures variable
     var: List[VarConfig] = field(default_factory=lambda: [VarConfig()])
 
 
@@ -250,6 +261,32 @@ class XgridPlan:
         return g.value if want_gsum else None
 
 
+    def apply_ex(self, data_t, out_t, nz=1, grad_x_t=None, grad_y_t=None, grad_mask_t=None, has_missing=False,
+                 missing=-MAXVAL, weight_t=None, cell_methods_sum=False, field_area_t=None, area_missing=-MAXVAL,
+                 cell_area_in_t=None, cell_area_out_t=None, monotonic=False, want_gsum=False, minmax_hook=None):
+        """The sweep with every do_scalar_conserve_interp option (fg_plan_apply_ex).  ``minmax_hook(plan)``
+        is called between the two halves of the monotone sweep (all-reduce point, :672-677)."""
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        addr = lambda t: t.data_ptr() if t is not None else None
+        o = _lib.ApplyOpts(1 if has_missing else 0, float(missing), addr(weight_t), 1 if cell_methods_sum else 0,
+                           addr(field_area_t), float(area_missing), addr(cell_area_in_t), addr(cell_area_out_t),
+                           1 if monotonic else 0)
+        g = C.c_double(0.0)
+        gp = C.byref(g) if want_gsum else None
+        L = lib()
+        if monotonic and self.order == 2 and minmax_hook is not None:
+            check(L.fg_plan_mono_begin(self._h, C.byref(o), ptr(data_t), ptr(grad_x_t), ptr(grad_y_t), ptr(grad_mask_t)))
+            minmax_hook(self)
+            check(L.fg_plan_mono_end(self._h, C.byref(o), ptr(data_t), ptr(out_t), gp))
+        else:
+            check(L.fg_plan_apply_ex(self._h, C.byref(o), ptr(data_t), ptr(grad_x_t), ptr(grad_y_t), ptr(grad_mask_t),
+                                     nz, ptr(out_t), gp))
+        return g.value if want_gsum else None
+
+    def mono_copy_minmax(self, to_plan, fmin_t, fmax_t):
+        check(lib().fg_plan_mono_copy_minmax(self._h, 1 if to_plan else 0, C.c_void_p(fmin_t.data_ptr()),
+                                              C.c_void_p(fmax_t.data_ptr())))
+
     def apply_interleaved(self, nb, data_il_t, out_il_t, grad_x_il_t=None, grad_y_il_t=None, want_gsum=False):
         """Sweep on interleaved device tensors: data [F, nb], grads [ncells_in, nb], out [ndst, nb]."""
         g = C.c_double(0.0)
@@ -385,31 +422,73 @@ def pack_field(order, field_in, ntiles_in, nz, key="data"):
 
 def do_scalar_conserve_interp(interp, varid, ntiles_in, grid_in, ntiles_out, grid_out, field_in, field_out,
                               opcode, nz, device=0):
-    """conserve_interp.c:507 -- plain scalar branch (order 1 :561-616, order 2 :743-813, :815-907)."""
+    """conserve_interp.c:507-910.  The plain branch (no weight / cell_measures / cell_methods=sum / monotonic /
+    target_grid) runs the bandwidth kernels (fg_plan_apply); any of those options routes to fg_plan_apply_ex."""
     torch = _torch()
     var = field_in[0].var[varid]
     order = 2 if var.interp_method == CONSERVE_ORDER2 else 1
+    monotonic = bool(opcode & MONOTONIC) if order == 2 else False      # :525-531
     has_missing = int(var.has_missing)
     missing = var.missing if has_missing else -MAXVAL
+    weight_exist = int(grid_in[0].weight_exist)
+    cell_measures, cell_methods = int(var.cell_measures), int(var.cell_methods)
+    target_grid = bool(opcode & TARGET) and not var.use_volume          # :535-536
     if nz > 1 and has_missing:
         raise ValueError("conserve_interp: has_missing should be false when nz > 1")
+    if nz > 1 and cell_measures:
+        raise ValueError("conserve_interp: cell_measures should be false when nz > 1")
+    if nz > 1 and cell_methods == CELL_METHODS_SUM:
+        raise ValueError("conserve_interp: cell_methods should not be sum when nz > 1")
     dev = f"cuda:{device}"
     data = torch.from_numpy(pack_field(order, field_in, ntiles_in, nz, "data").astype(np.float64)).to(dev)
     gx = gy = gm = None
     if order == 2:
         gx = torch.from_numpy(pack_field(order, field_in, ntiles_in, nz, "grad_x").astype(np.float64)).to(dev)
         gy = torch.from_numpy(pack_field(order, field_in, ntiles_in, nz, "grad_y").astype(np.float64)).to(dev)
-        if has_missing:
+        if has_missing or (monotonic and field_in[0].grad_mask is not None):
             gm = torch.from_numpy(np.concatenate([np.asarray(field_in[t].grad_mask, dtype=np.int32).reshape(-1)
                                                   for t in range(ntiles_in)])).to(dev)
+    extended = weight_exist or cell_measures or cell_methods == CELL_METHODS_SUM or target_grid or monotonic
+
+    def flat(get):
+        return torch.from_numpy(np.concatenate([_f64(get(t)).reshape(-1) for t in range(ntiles_in)])).to(dev)
+
+    w_t = fa_t = ca_t = None
+    if extended:
+        if weight_exist:
+            w_t = flat(lambda t: grid_in[t].weight)
+        if cell_measures:
+            fa_t = flat(lambda t: field_in[t].area)
+        if cell_measures or cell_methods == CELL_METHODS_SUM:
+            ca_t = flat(lambda t: grid_in[t].cell_area)
+
+    def minmax_hook(plan):                                             # mpp_min_double / mpp_max_double, :672-677
+        from .parallel import allreduce_minmax, world_size
+        if world_size() > 1:
+            fmin = torch.empty(plan.ncells_in, dtype=torch.float64, device=dev)
+            fmax = torch.empty_like(fmin)
+            plan.mono_copy_minmax(False, fmin, fmax)
+            allreduce_minmax(fmin, fmax)
+            torch.cuda.synchronize(device)
+            plan.mono_copy_minmax(True, fmin, fmax)
+
     gsum_out = 0.0
     for m in range(ntiles_out):
         nx2, ny2 = grid_out[m].nxc, grid_out[m].nyc
         out = torch.empty(nz * nx2 * ny2, dtype=torch.float64, device=dev)
         torch.cuda.synchronize(device)
-        g = interp[m].plan.apply(data, out, nz=nz, grad_x_t=gx, grad_y_t=gy, grad_mask_t=gm,
-                                 has_missing=bool(has_missing), missing=missing,
-                                 want_gsum=bool(opcode & CHECK_CONSERVE))
+        want = bool(opcode & CHECK_CONSERVE)
+        if extended:
+            cao_t = torch.from_numpy(_f64(grid_out[m].cell_area).reshape(-1)).to(dev) if target_grid else None
+            torch.cuda.synchronize(device)
+            g = interp[m].plan.apply_ex(data, out, nz=nz, grad_x_t=gx, grad_y_t=gy, grad_mask_t=gm,
+                                        has_missing=bool(has_missing), missing=missing, weight_t=w_t,
+                                        cell_methods_sum=cell_methods == CELL_METHODS_SUM, field_area_t=fa_t,
+                                        area_missing=var.area_missing, cell_area_in_t=ca_t, cell_area_out_t=cao_t,
+                                        monotonic=monotonic, want_gsum=want, minmax_hook=minmax_hook)
+        else:
+            g = interp[m].plan.apply(data, out, nz=nz, grad_x_t=gx, grad_y_t=gy, grad_mask_t=gm,
+                                     has_missing=bool(has_missing), missing=missing, want_gsum=want)
         interp[m].plan.sync()
         field_out[m].data = out.cpu().numpy().reshape(nz, ny2, nx2)
         if g is not None:
@@ -421,8 +500,14 @@ def do_scalar_conserve_interp(interp, varid, ntiles_in, grid_in, ntiles_out, gri
             nx1, ny1 = grid_in[n].nx, grid_in[n].ny
             d = np.asarray(field_in[n].data, dtype=np.float64).reshape(nz, ny1 + 2 * halo, nx1 + 2 * halo)
             d = d[:, halo:halo + ny1, halo:halo + nx1]
-            ca = np.asarray(grid_in[n].cell_area).reshape(ny1, nx1)
-            gsum_in += float(np.sum(np.where(d != missing, d * ca[None], 0.0)))
+            if cell_measures:
+                fa = np.asarray(field_in[n].area).reshape(ny1, nx1)
+                gsum_in += float(np.sum(np.where(d[0] != missing, d[0] * fa, 0.0)))
+            elif cell_methods == CELL_METHODS_SUM:
+                gsum_in += float(np.sum(np.where(d[0] != missing, d[0], 0.0)))
+            else:
+                ca = np.asarray(grid_in[n].cell_area).reshape(ny1, nx1)
+                gsum_in += float(np.sum(np.where(d != missing, d * ca[None], 0.0)))
         from .parallel import allreduce_scalar_sum
         gsum_out = allreduce_scalar_sum(gsum_out, dev)                 # mpp_sum_double, :902
         print("the flux(data*area) sum of %s: input = %g, output = %g, diff = %g. "

@@ -125,6 +125,145 @@ __global__ __launch_bounds__(256) void k_apply1(int ndst, FgCsr csr, const doubl
 // NB*8-byte segment per field, so a wave instruction touches 64*V/NB full segments instead of 64
 // scattered lines.  Every (row, level) sum adds in ascending exchange-cell order, exactly the
 // reference's order.  No missing values (has_missing requires nz == 1, conserve_interp.c:544).
+// Every option of do_scalar_conserve_interp on one level; the per-entry operation order is the reference's
+// (weight, then the missing test, then sum / cell_measures scaling) so sums are bit-identical.
+// MONO: values come limited from xdata[] (the monotone branch never sets out_miss, :720-739).
+template <int ORDER, bool MONO>
+__global__ __launch_bounds__(256) void k_apply_ex(int ndst, FgCsr csr, const double *f, const double *px, const double *py,
+                                                   FgApplyEx o, double *out, double *row_sum, int *err)
+{
+  int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= ndst) return;
+  int b = csr.row_ptr[d], e = csr.row_ptr[d + 1];
+  double acc = 0.0, asum = 0.0, asum_t = 0.0;
+  int touched = 0;
+  for (int q = b; q < e; q++) {
+    double a, v, di = 0, dj = 0;
+    int s, jf;
+    if (ORDER == 2) { const FgCsrEntry2 E = csr.e2[q]; a = E.area; jf = E.idx_f; s = E.idx_g; di = E.di; dj = E.dj; }
+    else            { const FgCsrEntry1 E = csr.e1[q]; a = E.area; jf = E.idx_f; s = E.idx_f; }
+    if (o.cell_area_out) {                                       // :845-860 (plain exchange-cell area, no weight)
+      if (o.field_area) asum_t += (a * o.field_area[s] / o.cell_area[s]);
+      else asum_t += a;
+    }
+    if (MONO) {
+      v = o.xdata[q];
+      if (v == o.missing) continue;
+      if (o.weight) a *= o.weight[s];
+    } else {
+      if (o.weight) a *= o.weight[s];
+      v = f[jf];
+      if (o.has_missing && v == o.missing) continue;
+    }
+    if (o.sum) a /= o.cell_area[s];
+    else if (o.field_area) {
+      const double fa = o.field_area[s];
+      if (!MONO && o.has_missing && fa == o.area_missing) { atomicOr(err, FG_XERR_AREA_MISSING); continue; }
+      a *= (fa / o.cell_area[s]);
+    }
+    if (ORDER == 2 && !MONO) {
+      bool flat = o.has_missing && o.gmask && o.gmask[s] != 0;
+      if (!flat) v = (v + px[s] * di + py[s] * dj);
+    }
+    acc += v * a;
+    asum += a;
+    if (!MONO) touched = 1;
+  }
+  if (row_sum) row_sum[d] = (asum > 0) ? acc : 0.0;             // :815-819
+  double r = acc;
+  if (o.sum) {                                                  // :821-830
+    if (asum == 0) r = touched ? 0.0 : o.missing;
+  } else {
+    if (asum > 0) r = acc / asum;                               // :832-839
+    else if (touched) r = 0.0;
+    else r = o.missing;
+    if (o.cell_area_out && r != o.missing) r *= (asum_t / o.cell_area_out[d]);
+  }
+  out[d] = r;
+}
+
+__device__ __forceinline__ void d_atomic_max_f64(double *p, double v)
+{
+  unsigned long long *u = (unsigned long long *)p, old = *u;
+  while (__longlong_as_double((long long)old) < v) {
+    unsigned long long seen = atomicCAS(u, old, (unsigned long long)__double_as_longlong(v));
+    if (seen == old) break;
+    old = seen;
+  }
+}
+__device__ __forceinline__ void d_atomic_min_f64(double *p, double v)
+{
+  unsigned long long *u = (unsigned long long *)p, old = *u;
+  while (__longlong_as_double((long long)old) > v) {
+    unsigned long long seen = atomicCAS(u, old, (unsigned long long)__double_as_longlong(v));
+    if (seen == old) break;
+    old = seen;
+  }
+}
+
+// :622-645: bounds of the 3x3 halo'd neighbourhood, ignoring missing values
+__global__ __launch_bounds__(256) void k_mono_bounds(const FgTile *tiles, int ntiles, int nsrc, const int *src_idx_f, const double *f,
+                                                      double missing, double *fbmax, double *fbmin, double *fmax, double *fmin)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsrc) return;
+  int t = 0;
+  while (t + 1 < ntiles && s >= tiles[t + 1].cell_off) t++;
+  const int ld = tiles[t].nx + 2, c = src_idx_f[s];
+  double mx = -1.e20, mn = 1.e20;
+  for (int jj = -1; jj <= 1; jj++)
+    for (int ii = -1; ii <= 1; ii++) {
+      double v = f[c + jj * ld + ii];
+      if (v != missing) { if (v > mx) mx = v; if (v < mn) mn = v; }
+    }
+  fbmax[s] = mx; fbmin[s] = mn; fmax[s] = -1.e20; fmin[s] = 1.e20;
+}
+
+// :647-669: second-order value of every exchange cell (CSR order) and its extremes per source cell
+__global__ __launch_bounds__(256) void k_mono_xdata(long nx, FgCsr csr, const double *f, const double *px, const double *py,
+                                                     const int *gmask, double missing, double *xdata, double *fmax, double *fmin)
+{
+  long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nx) return;
+  const FgCsrEntry2 E = csr.e2[q];
+  double v = f[E.idx_f], x;
+  if (v != missing) {
+    if (gmask && gmask[E.idx_g]) x = v;
+    else x = v + px[E.idx_g] * E.di + py[E.idx_g] * E.dj;
+    d_atomic_max_f64(fmax + E.idx_g, x);
+    d_atomic_min_f64(fmin + E.idx_g, x);
+  } else
+    x = missing;
+  xdata[q] = x;
+}
+
+// :679-716
+__global__ __launch_bounds__(256) void k_mono_limit(long nx, FgCsr csr, const double *f, double missing, const double *fbmax,
+                                                     const double *fbmin, const double *fmax, const double *fmin, double *xdata, int *err)
+{
+  long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nx) return;
+  double x = xdata[q];
+  if (x == missing) return;
+  const FgCsrEntry2 E = csr.e2[q];
+  const int s = E.idx_g;
+  const double f_bar = f[E.idx_f];
+  if (fmax[s] > fbmax[s]) {
+    x = f_bar + ((x - f_bar) / (fmax[s] - f_bar)) * (fbmax[s] - f_bar);
+    if (x > fbmax[s]) {
+      if (x - fbmax[s] < 1.e-10) x = fbmax[s];
+      if (x > fbmax[s]) atomicOr(err, FG_XERR_ABOVE);
+    }
+  } else if (fmin[s] < fbmin[s]) {
+    x = f_bar + ((x - f_bar) / (fmin[s] - f_bar)) * (fbmin[s] - f_bar);
+    if (x < fbmin[s]) {
+      if (fbmin[s] - x < 1.e-10) x = fbmin[s];
+      if (x < fbmin[s]) atomicOr(err, FG_XERR_BELOW);
+    }
+  }
+  xdata[q] = x;
+}
+
 template <int V> struct VecD;
 template <> struct VecD<1> { double v[1]; };
 template <> struct __attribute__((aligned(16))) VecD<2> { double v[2]; };
@@ -334,6 +473,33 @@ void fgd_deinterleave(int nb_pad, long n, const double *in, long ld, int nb_vali
   else if (nb_pad == 4) k_deinterleave<4><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
   else k_deinterleave<2><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
 }
+void fgd_apply_ex(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, FgApplyEx o,
+                  double *out, double *row_sum, int *err, hipStream_t st)
+{
+  if (ndst <= 0) return;
+  int grid = nblk(ndst, 256);
+  if (order == 2) {
+    if (o.xdata) k_apply_ex<2, true><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, o, out, row_sum, err);
+    else         k_apply_ex<2, false><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, o, out, row_sum, err);
+  } else
+    k_apply_ex<1, false><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, o, out, row_sum, err);
+}
+void fgd_mono_bounds(const FgTile *tiles_dev, int ntiles, int nsrc, const int *src_idx_f, const double *f, double missing,
+                     double *fbmax, double *fbmin, double *fmax, double *fmin, hipStream_t st)
+{
+  if (nsrc > 0) k_mono_bounds<<<nblk(nsrc, 256), 256, 0, st>>>(tiles_dev, ntiles, nsrc, src_idx_f, f, missing, fbmax, fbmin, fmax, fmin);
+}
+void fgd_mono_xdata(long nx, FgCsr csr, const double *f, const double *gx, const double *gy, const int *gmask, double missing,
+                    double *xdata, double *fmax, double *fmin, hipStream_t st)
+{
+  if (nx > 0) k_mono_xdata<<<nblk(nx, 256), 256, 0, st>>>(nx, csr, f, gx, gy, gmask, missing, xdata, fmax, fmin);
+}
+void fgd_mono_limit(long nx, FgCsr csr, const double *f, double missing, const double *fbmax, const double *fbmin,
+                    const double *fmax, const double *fmin, double *xdata, int *err, hipStream_t st)
+{
+  if (nx > 0) k_mono_limit<<<nblk(nx, 256), 256, 0, st>>>(nx, csr, f, missing, fbmax, fbmin, fmax, fmin, xdata, err);
+}
+
 void fgd_apply_frac(int ndst, FgCsr csr, const double *data, double *out, hipStream_t st)
 {
   if (ndst > 0) k_apply_frac<<<nblk(ndst, 256), 256, 0, st>>>(ndst, csr, data, out);

@@ -167,6 +167,10 @@ struct fg_plan {
   long row_sum_cap = 0;
   double *il_f = nullptr, *il_gx = nullptr, *il_gy = nullptr, *il_out = nullptr, *il_rs = nullptr;   // [cell][8] scratch
   long stats[FG_NSTATS] = {0};
+  // monotone limiter scratch (fg_plan_mono_*): limited values per CSR entry, per-source-cell bounds, error word
+  double *mono_x = nullptr, *mono_b = nullptr;     // mono_b: [4][nsrc] = f_bar_max | f_bar_min | f_max | f_min
+  int *xerr = nullptr;
+  bool mono_open = false;
 
   template <typename T> T *alloc(size_t count)
   {
@@ -858,6 +862,155 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
   }
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+// ------------------------------------------------------------------- the sweep with every option
+static int ex_check(fg_plan *pl, const fg_apply_opts *o, const double *data, const double *gx, const double *gy, int nz, const char *who)
+{
+  if (!pl || !o || !data) return fail(FG_ERR_ARG, "%s: null argument", who);
+  if (!pl->finalized) return fail(FG_ERR_STATE, "%s: call fg_plan_finalize first", who);
+  if (nz < 1) return fail(FG_ERR_ARG, "nz must be >= 1");
+  if (nz > 1 && o->has_missing) return fail(FG_ERR_ARG, "conserve_interp: has_missing should be false when nz > 1");
+  if (nz > 1 && o->field_area) return fail(FG_ERR_ARG, "conserve_interp: cell_measures should be false when nz > 1");
+  if (nz > 1 && o->cell_methods_sum) return fail(FG_ERR_ARG, "conserve_interp: cell_methods should not be sum when nz > 1");
+  if (pl->order == 2 && (!gx || !gy)) return fail(FG_ERR_ARG, "order 2 needs grad_x and grad_y");
+  if ((o->cell_methods_sum || o->field_area) && !o->cell_area_in && !pl->have_geom)
+    return fail(FG_ERR_ARG, "%s: cell_area_in is required (this plan was loaded from a remap file and holds no cell areas)", who);
+  return 0;
+}
+
+static int ex_error_word(fg_plan *pl)
+{
+  int e = 0;
+  HIPCHK(hipMemcpyAsync(&e, pl->xerr, sizeof(int), hipMemcpyDeviceToHost, pl->stream));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  if (e & FG_XERR_AREA_MISSING) return fail(FG_ERR_DATA, "conserve_interp: data is not missing but area is missing");
+  if (e & FG_XERR_ABOVE) return fail(FG_ERR_DATA, " xdata is greater than f_bar_max ");
+  if (e & FG_XERR_BELOW) return fail(FG_ERR_DATA, " xdata is less than f_bar_min ");
+  return 0;
+}
+
+static int ex_scratch(fg_plan *pl, bool mono)
+{
+  if (!pl->xerr) { pl->xerr = pl->alloc<int>(4); if (!pl->xerr) return fail(FG_ERR_HIP, "out of device memory"); }
+  if (pl->row_sum_cap < pl->ndst) {
+    pl->release(pl->row_sum);
+    pl->row_sum = pl->alloc<double>(pl->ndst);
+    if (!pl->row_sum) { pl->row_sum_cap = 0; return fail(FG_ERR_HIP, "out of device memory"); }
+    pl->row_sum_cap = pl->ndst;
+  }
+  if (mono && !pl->mono_x) {
+    pl->mono_x = pl->alloc<double>(pl->nx > 0 ? pl->nx : 1);
+    pl->mono_b = pl->alloc<double>((size_t)pl->nsrc * 4);
+    if (!pl->mono_x || !pl->mono_b) return fail(FG_ERR_HIP, "out of device memory");
+  }
+  return 0;
+}
+
+static FgApplyEx ex_pack(fg_plan *pl, const fg_apply_opts *o, const int *gmask)
+{
+  FgApplyEx x{};
+  x.weight = o->weight; x.field_area = o->field_area; x.cell_area_out = o->cell_methods_sum ? nullptr : o->cell_area_out;
+  x.cell_area = o->cell_area_in ? o->cell_area_in : (pl->have_geom ? pl->S.area : nullptr);
+  x.gmask = gmask; x.area_missing = o->area_missing;
+  x.has_missing = o->has_missing; x.missing = o->has_missing ? o->missing : -1.e20;   // conserve_interp.c:541-542
+  x.sum = o->cell_methods_sum;
+  return x;
+}
+
+extern "C" int fg_plan_mono_begin(fg_plan *pl, const fg_apply_opts *o, const double *data, const double *grad_x,
+                                  const double *grad_y, const int *grad_mask)
+{
+  int rc = ex_check(pl, o, data, grad_x, grad_y, 1, "fg_plan_mono_begin");
+  if (rc) return rc;
+  if (pl->order != 2) return fail(FG_ERR_ARG, "the monotone limiter belongs to conserve_order2 (conserve_interp.c:527-531)");
+  HIPCHK(hipSetDevice(pl->device));
+  if ((rc = ex_scratch(pl, true))) return rc;
+  const double miss = o->has_missing ? o->missing : -1.e20;
+  double *b = pl->mono_b;
+  const size_t n = pl->nsrc;
+  HIPCHK(hipMemsetAsync(pl->xerr, 0, sizeof(int), pl->stream));
+  fgd_mono_bounds(pl->tiles_dev, pl->ntiles, pl->nsrc, pl->src_idx_f, data, miss, b, b + n, b + 2 * n, b + 3 * n, pl->stream);
+  fgd_mono_xdata(pl->nx, pl->csr, data, grad_x, grad_y, grad_mask, miss, pl->mono_x, b + 2 * n, b + 3 * n, pl->stream);
+  HIPCHK(hipGetLastError());
+  pl->mono_open = true;
+  return 0;
+}
+
+extern "C" int fg_plan_mono_minmax_dev(fg_plan *pl, double **f_min, double **f_max)
+{
+  if (!pl || !pl->mono_open) return fail(FG_ERR_STATE, "fg_plan_mono_minmax_dev: call fg_plan_mono_begin first");
+  if (f_max) *f_max = pl->mono_b + 2 * (size_t)pl->nsrc;
+  if (f_min) *f_min = pl->mono_b + 3 * (size_t)pl->nsrc;
+  return 0;
+}
+
+extern "C" int fg_plan_mono_copy_minmax(fg_plan *pl, int to_plan, double *f_min, double *f_max)
+{
+  if (!pl || !pl->mono_open || !f_min || !f_max) return fail(FG_ERR_STATE, "fg_plan_mono_copy_minmax: call fg_plan_mono_begin first");
+  HIPCHK(hipSetDevice(pl->device));
+  double *mx = pl->mono_b + 2 * (size_t)pl->nsrc, *mn = pl->mono_b + 3 * (size_t)pl->nsrc;
+  const size_t bytes = (size_t)pl->nsrc * sizeof(double);
+  HIPCHK(hipMemcpyAsync(to_plan ? mn : f_min, to_plan ? f_min : mn, bytes, hipMemcpyDeviceToDevice, pl->stream));
+  HIPCHK(hipMemcpyAsync(to_plan ? mx : f_max, to_plan ? f_max : mx, bytes, hipMemcpyDeviceToDevice, pl->stream));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  return 0;
+}
+
+extern "C" int fg_plan_mono_end(fg_plan *pl, const fg_apply_opts *o, const double *data, double *out, double *gsum_out)
+{
+  if (!pl || !o || !data || !out) return fail(FG_ERR_ARG, "null argument");
+  if (!pl->mono_open) return fail(FG_ERR_STATE, "fg_plan_mono_end: call fg_plan_mono_begin first");
+  HIPCHK(hipSetDevice(pl->device));
+  pl->mono_open = false;
+  const double miss = o->has_missing ? o->missing : -1.e20;
+  double *b = pl->mono_b;
+  const size_t n = pl->nsrc;
+  fgd_mono_limit(pl->nx, pl->csr, data, miss, b, b + n, b + 2 * n, b + 3 * n, pl->mono_x, pl->xerr, pl->stream);
+  FgApplyEx x = ex_pack(pl, o, nullptr);
+  x.xdata = pl->mono_x;
+  fgd_apply_ex(2, pl->ndst, pl->csr, data, nullptr, nullptr, x, out, gsum_out ? pl->row_sum : nullptr, pl->xerr, pl->stream);
+  if (gsum_out) {
+    fgd_reduce_sum(pl->row_sum, pl->ndst, pl->red_partial, pl->red_result, pl->stream);
+    HIPCHK(hipMemcpyAsync(gsum_out, pl->red_result, sizeof(double), hipMemcpyDeviceToHost, pl->stream));
+  }
+  HIPCHK(hipGetLastError());
+  return ex_error_word(pl);
+}
+
+extern "C" int fg_plan_apply_ex(fg_plan *pl, const fg_apply_opts *o, const double *data, const double *grad_x,
+                                const double *grad_y, const int *grad_mask, int nz, double *out, double *gsum_out)
+{
+  int rc = ex_check(pl, o, data, grad_x, grad_y, nz, "fg_plan_apply_ex");
+  if (rc) return rc;
+  if (!out) return fail(FG_ERR_ARG, "null argument");
+  if (o->monotonic && pl->order == 2) {
+    if (nz != 1) return fail(FG_ERR_ARG, "the monotone limiter works on one level per call (conserve_interp.c:648-651 index level 0 only)");
+    if ((rc = fg_plan_mono_begin(pl, o, data, grad_x, grad_y, grad_mask))) return rc;
+    return fg_plan_mono_end(pl, o, data, out, gsum_out);
+  }
+  HIPCHK(hipSetDevice(pl->device));
+  if ((rc = ex_scratch(pl, false))) return rc;
+  if (nz > 256) return fail(FG_ERR_ARG, "nz too large for one call (max 256 levels)");
+  hipStream_t st = pl->stream;
+  HIPCHK(hipMemsetAsync(pl->xerr, 0, sizeof(int), st));
+  FgApplyEx x = ex_pack(pl, o, grad_mask);
+  for (int k = 0; k < nz; k++) {
+    fgd_apply_ex(pl->order, pl->ndst, pl->csr, data + (size_t)k * pl->f_stride, grad_x ? grad_x + (size_t)k * pl->nsrc : nullptr,
+                 grad_y ? grad_y + (size_t)k * pl->nsrc : nullptr, x, out + (size_t)k * pl->ndst,
+                 gsum_out ? pl->row_sum : nullptr, pl->xerr, st);
+    if (gsum_out) fgd_reduce_sum(pl->row_sum, pl->ndst, pl->red_partial, pl->red_result + k, st);
+  }
+  HIPCHK(hipGetLastError());
+  if (gsum_out) {
+    double parts[256];
+    HIPCHK(hipMemcpyAsync(parts, pl->red_result, nz * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double g = 0;
+    for (int k = 0; k < nz; k++) g += parts[k];
+    *gsum_out = g;
+  }
+  return ex_error_word(pl);
 }
 
 // The sweep on fields the caller already keeps interleaved: data_il [F][nb], grad_x_il/grad_y_il [ncells_in][nb],

@@ -98,6 +98,31 @@ void fgd_deinterleave(int nb_pad, long n, const double *in, long ld, int nb_vali
 void fgd_apply_frac(int ndst, FgCsr csr, const double *data, double *out, hipStream_t st);
 void fgd_reduce_sum(const double *v, long n, double *partial, double *result, hipStream_t st);
 
+// ---- the sweep with every do_scalar_conserve_interp option (conserve_interp.c:507-910), one level per launch
+struct FgApplyEx {
+  const double *weight;      // [nsrc] grid_in.weight, or null                       (:574 ...)
+  const double *cell_area;   // [nsrc] grid_in.cell_area (sum / cell_measures)
+  const double *field_area;  // [nsrc] field_in.area, or null = no cell_measures     (:582-588)
+  const double *cell_area_out;  // [ndst] grid_out.cell_area, or null = no --target_grid rescale (:842-869)
+  const int *gmask;          // [nsrc] grad_mask or null (= all zero)
+  const double *xdata;       // monotone: limited exchange-cell values in CSR order, or null
+  double area_missing, missing;
+  int has_missing, sum;      // sum = cell_methods == CELL_METHODS_SUM
+};
+#define FG_XERR_AREA_MISSING 1
+#define FG_XERR_ABOVE 2
+#define FG_XERR_BELOW 4
+void fgd_apply_ex(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, FgApplyEx o,
+                  double *out, double *row_sum, int *err, hipStream_t st);
+// monotone limiter (:617-716): per-source-cell neighbourhood bounds, exchange-cell values + their per-cell
+// extremes (atomic min/max: order independent), then the limited values
+void fgd_mono_bounds(const FgTile *tiles_dev, int ntiles, int nsrc, const int *src_idx_f, const double *f, double missing,
+                     double *fbmax, double *fbmin, double *fmax, double *fmin, hipStream_t st);
+void fgd_mono_xdata(long nx, FgCsr csr, const double *f, const double *gx, const double *gy, const int *gmask, double missing,
+                    double *xdata, double *fmax, double *fmin, hipStream_t st);
+void fgd_mono_limit(long nx, FgCsr csr, const double *f, double missing, const double *fbmax, const double *fbmin,
+                    const double *fmax, const double *fmin, double *xdata, int *err, hipStream_t st);
+
 // ---- batched polygon primitives (poly_kernels.hip); polygons are rows of [npoly][FG_POLY_STRIDE]
 #define FG_POLY_STRIDE 24
 void fgd_poly_clip(int npoly, const double *lon1, const double *lat1, const int *n1, const double *lon2, const double *lat2,

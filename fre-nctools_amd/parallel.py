@@ -33,3 +33,18 @@ def allreduce_scalar_sum(value, device="cpu"):
         dist.all_reduce(t)
         return float(t.item())
     return float(value)
+
+
+def world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_minmax(fmin, fmax):
+    """mpp_min_double / mpp_max_double over the per-source-cell extremes of the monotone limiter
+    (conserve_interp.c:672-677); in place."""
+    import torch.distributed as dist
+    if world_size() > 1:
+        dist.all_reduce(fmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(fmax, op=dist.ReduceOp.MAX)
+    return fmin, fmax

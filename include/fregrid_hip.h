@@ -45,6 +45,7 @@ extern "C" {
 #define FG_ERR_PARALLEL   (-4)   /* clip hit parallel edges, |determ| < 1e-30 (create_xgrid.c:1314) */
 #define FG_ERR_CAPACITY   (-5)   /* caller's output arrays too small (reference: MAXXGRID fatal, :1087) */
 #define FG_ERR_STATE      (-6)   /* call made in the wrong plan state                          */
+#define FG_ERR_DATA       (-7)   /* the field data hit one of the reference's fatal checks (conserve_interp.c:584,:697,:709) */
 
 /* option bits, same values as tools/libfrencutils/globals.h:46-61 where they exist */
 #define FG_CONSERVE_ORDER1 1
@@ -207,6 +208,44 @@ int fg_plan_apply(fg_plan *plan, const double *data, const double *grad_x, const
  * kernel works in -- fg_plan_apply transposes level-major input into it.  No missing values. */
 int fg_plan_apply_interleaved(fg_plan *plan, int nb, const double *data_il, const double *grad_x_il,
                               const double *grad_y_il, double *out_il, double *gsum_out);
+
+/* The sweep with every remaining option of do_scalar_conserve_interp (conserve_interp.c:507-910).  All pointers are
+ * DEVICE pointers over the flattened source cells (tiles back to back, [ny][nx], no halo) or destination cells.
+ *   weight          grid_in[].weight (weight_exist, --weight_file/--weight_field), or NULL
+ *   cell_methods_sum  cell_methods == CELL_METHODS_SUM: area /= cell_area; un-normalised output (:821-830)
+ *   field_area      field_in[].area of a cell_measures variable (area *= field_area/cell_area), or NULL;
+ *                   with has_missing a field_area equal to area_missing under valid data is the reference's fatal
+ *                   "data is not missing but area is missing" -> FG_ERR_DATA
+ *   cell_area_in    grid_in[].cell_area; NULL = the plan's own get_grid_area values (search-built plans only)
+ *   cell_area_out   grid_out.cell_area; non-NULL switches the --target_grid rescale on (:842-869; the caller
+ *                   leaves it NULL for use_volume variables, :536)
+ *   monotonic       --monotonic limiter, conserve_order2 only (:617-748): one level per call
+ * nz > 1 is legal only without has_missing / field_area / cell_methods_sum (:544-546).  With every option off
+ * the result equals fg_plan_apply's bit for bit.  Levels are swept one launch each (these are the rarely used
+ * branches; the bandwidth path is fg_plan_apply / fg_plan_apply_interleaved). */
+typedef struct fg_apply_opts {
+  int has_missing;
+  double missing;
+  const double *weight;
+  int cell_methods_sum;
+  const double *field_area;
+  double area_missing;
+  const double *cell_area_in;
+  const double *cell_area_out;
+  int monotonic;
+} fg_apply_opts;
+int fg_plan_apply_ex(fg_plan *plan, const fg_apply_opts *opts, const double *data, const double *grad_x,
+                     const double *grad_y, const int *grad_mask, int nz, double *out, double *gsum_out);
+/* The monotone sweep split at the reference's mpp_min_double/mpp_max_double (:672-677) so that ranks holding bands of
+ * one destination grid can all-reduce the per-source-cell extremes (MIN over f_min, MAX over f_max, ncells_in doubles
+ * each, device pointers) between the two calls.  fg_plan_apply_ex(monotonic=1) is begin + end. */
+int fg_plan_mono_begin(fg_plan *plan, const fg_apply_opts *opts, const double *data, const double *grad_x,
+                       const double *grad_y, const int *grad_mask);
+int fg_plan_mono_minmax_dev(fg_plan *plan, double **f_min, double **f_max);
+/* device-to-device copy of the extremes out of (to_plan = 0) or back into (to_plan = 1) the plan, for callers whose
+ * collective library wants its own buffers (torch.distributed); synchronises the plan's stream */
+int fg_plan_mono_copy_minmax(fg_plan *plan, int to_plan, double *f_min, double *f_max);
+int fg_plan_mono_end(fg_plan *plan, const fg_apply_opts *opts, const double *data, double *out, double *gsum_out);
 
 /* HIP stream the plan launches on (hipStream_t as void*), for event timing. */
 void *fg_plan_stream(fg_plan *plan);

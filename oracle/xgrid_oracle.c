@@ -701,3 +701,244 @@ double orc_gsum_in(int order, int ntiles_in, const int *nx_in, const int *ny_in,
   }
   return g;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * do_scalar_conserve_interp with every branch (conserve_interp.c:507-910): source weight field
+ * (weight_exist, :574,:608,:737,:757,:799), cell_methods = sum (:580,:612,:741,:767,:803, final :821-830),
+ * cell_measures (:582-588,:614,:743,:769-775,:805, area_missing fatal), the monotone limiter (:617-748) and the
+ * --target_grid rescale (:842-869).  Test infrastructure only.  Restated: conserve_interp.c includes mpp_io.h ->
+ * <netcdf.h>, so the reference's own object cannot be built here (parity of these branches is UNPINNED against
+ * compiled reference code; the plain branch is cross-checked by orc_do_scalar_conserve_interp above, which this
+ * function must reproduce bit for bit when all options are off).
+ * weight, field_area, cell_area_in: per tile [ny][nx] (NULL pointer = option off; cell_area_in required for
+ * sum/measures/target with measures).  Returns 0, -1 (illegal nz combination, :544-546), -2 ("data is not missing
+ * but area is missing"), -3 (" xdata is greater than f_bar_max "), -4 (" xdata is less than f_bar_min ").
+ * Monotone: the reference indexes level 0 only and takes nx1 from the last tile (:648-651); tiles of one mosaic
+ * have equal sizes, so nx_in[tile] is used.  One process: the mpp_min/max_double of :672-677 are identities. */
+#define ORC_TOLERANCE 1.e-10                 /* conserve_interp.c:37 */
+int orc_do_scalar_conserve_interp_ex(int order, long nxgrid,
+                                     const int *t_in, const int *i_in, const int *j_in,
+                                     const int *i_out, const int *j_out,
+                                     const double *area_x, const double *di_x, const double *dj_x,
+                                     int ntiles_in, const int *nx_in, const int *ny_in,
+                                     const double *const *data, const double *const *grad_x,
+                                     const double *const *grad_y, const int *const *grad_mask,
+                                     int has_missing, double missing_in,
+                                     const double *const *weight, int cell_methods_sum,
+                                     const double *const *field_area, double area_missing,
+                                     const double *const *cell_area_in,
+                                     int target_grid, const double *cell_area_out, int monotonic_in,
+                                     int nx2, int ny2, int nz, double *out, double *gsum_out)
+{
+  const int weight_exist = weight != NULL, cell_measures = field_area != NULL;
+  const int monotonic = (order == 2) ? monotonic_in : 0;                 /* :525-531 */
+  double missing = -ORC_MAXVAL;
+  if (has_missing) missing = missing_in;
+  if (nz > 1 && has_missing) return -1;
+  if (nz > 1 && cell_measures) return -1;
+  if (nz > 1 && cell_methods_sum) return -1;
+  size_t nout = (size_t)nx2 * ny2 * nz;
+  double *out_area = (double *)calloc(nout, sizeof(double));
+  int *out_miss = (int *)calloc(nout, sizeof(int));
+  int rc = 0;
+  for (size_t k = 0; k < nout; k++) out[k] = 0.0;
+
+  if (order == 1) {
+    for (long n = 0; n < nxgrid && !rc; n++) {
+      int i2 = i_out[n], j2 = j_out[n], i1 = i_in[n], j1 = j_in[n], tile = t_in[n];
+      double area = area_x[n];
+      int nx1 = nx_in[tile], ny1 = ny_in[tile];
+      if (weight_exist) area *= weight[tile][j1 * nx1 + i1];
+      if (has_missing) {
+        int n1 = j1 * nx1 + i1, n0 = j2 * nx2 + i2;
+        if (data[tile][n1] != missing) {
+          if (cell_methods_sum) area /= cell_area_in[tile][n1];
+          else if (cell_measures) {
+            if (field_area[tile][n1] == area_missing) { rc = -2; break; }
+            area *= (field_area[tile][n1] / cell_area_in[tile][n1]);
+          }
+          out[n0] += (data[tile][n1] * area);
+          out_area[n0] += area;
+          out_miss[n0] = 1;
+        }
+      } else {
+        for (int k = 0; k < nz; k++) {
+          size_t n1 = (size_t)k * nx1 * ny1 + j1 * nx1 + i1;
+          size_t n0 = (size_t)k * nx2 * ny2 + j2 * nx2 + i2;
+          if (cell_methods_sum) area /= cell_area_in[tile][n1];
+          else if (cell_measures) area *= (field_area[tile][n1] / cell_area_in[tile][n1]);
+          out[n0] += (data[tile][n1] * area);
+          out_area[n0] += area;
+          out_miss[n0] = 1;
+        }
+      }
+    }
+  } else if (monotonic) {
+    double **fbmax = (double **)malloc(ntiles_in * sizeof(double *)), **fbmin = (double **)malloc(ntiles_in * sizeof(double *));
+    double **fmax = (double **)malloc(ntiles_in * sizeof(double *)), **fmin = (double **)malloc(ntiles_in * sizeof(double *));
+    for (int n = 0; n < ntiles_in; n++) {
+      int nx1 = nx_in[n], ny1 = ny_in[n];
+      fbmax[n] = (double *)malloc((size_t)nx1 * ny1 * sizeof(double)); fbmin[n] = (double *)malloc((size_t)nx1 * ny1 * sizeof(double));
+      fmax[n] = (double *)malloc((size_t)nx1 * ny1 * sizeof(double));  fmin[n] = (double *)malloc((size_t)nx1 * ny1 * sizeof(double));
+      for (int j = 0; j < ny1; j++) for (int i = 0; i < nx1; i++) {
+        int n1 = j * nx1 + i;
+        fbmax[n][n1] = -ORC_MAXVAL; fbmin[n][n1] = ORC_MAXVAL; fmax[n][n1] = -ORC_MAXVAL; fmin[n][n1] = ORC_MAXVAL;
+        for (int jj = j - 1; jj <= j + 1; jj++) for (int ii = i - 1; ii <= i + 1; ii++) {
+          int n2 = (jj + 1) * (nx1 + 2) + ii + 1;
+          if (data[n][n2] != missing) {
+            if (data[n][n2] > fbmax[n][n1]) fbmax[n][n1] = data[n][n2];
+            if (data[n][n2] < fbmin[n][n1]) fbmin[n][n1] = data[n][n2];
+          }
+        }
+      }
+    }
+    double *xdata = (double *)malloc((nxgrid > 0 ? nxgrid : 1) * sizeof(double));
+    for (long n = 0; n < nxgrid; n++) {
+      int i1 = i_in[n], j1 = j_in[n], tile = t_in[n], nx1 = nx_in[tile];
+      double di = di_x[n], dj = dj_x[n];
+      int n1 = j1 * nx1 + i1, n2 = (j1 + 1) * (nx1 + 2) + i1 + 1;
+      if (data[tile][n2] != missing) {
+        if (grad_mask && grad_mask[tile] && grad_mask[tile][n1]) xdata[n] = data[tile][n2];
+        else xdata[n] = data[tile][n2] + grad_x[tile][n1] * di + grad_y[tile][n1] * dj;
+        if (xdata[n] > fmax[tile][n1]) fmax[tile][n1] = xdata[n];
+        if (xdata[n] < fmin[tile][n1]) fmin[tile][n1] = xdata[n];
+      } else
+        xdata[n] = missing;
+    }
+    for (long n = 0; n < nxgrid && !rc; n++) {
+      int i1 = i_in[n], j1 = j_in[n], tile = t_in[n], nx1 = nx_in[tile];
+      int n1 = j1 * nx1 + i1, n2 = (j1 + 1) * (nx1 + 2) + i1 + 1;
+      double f_bar = data[tile][n2];
+      if (xdata[n] == missing) continue;
+      if (fmax[tile][n1] > fbmax[tile][n1]) {
+        xdata[n] = f_bar + ((xdata[n] - f_bar) / (fmax[tile][n1] - f_bar)) * (fbmax[tile][n1] - f_bar);
+        if (xdata[n] > fbmax[tile][n1]) {
+          if (xdata[n] - fbmax[tile][n1] < ORC_TOLERANCE) xdata[n] = fbmax[tile][n1];
+          if (xdata[n] > fbmax[tile][n1]) rc = -3;
+        }
+      } else if (fmin[tile][n1] < fbmin[tile][n1]) {
+        xdata[n] = f_bar + ((xdata[n] - f_bar) / (fmin[tile][n1] - f_bar)) * (fbmin[tile][n1] - f_bar);
+        if (xdata[n] < fbmin[tile][n1]) {
+          if (fbmin[tile][n1] - xdata[n] < ORC_TOLERANCE) xdata[n] = fbmin[tile][n1];
+          if (xdata[n] < fbmin[tile][n1]) rc = -4;
+        }
+      }
+    }
+    for (int n = 0; n < ntiles_in; n++) { free(fbmax[n]); free(fbmin[n]); free(fmax[n]); free(fmin[n]); }
+    free(fbmax); free(fbmin); free(fmax); free(fmin);
+    for (long n = 0; n < nxgrid && !rc; n++) {
+      int i2 = i_out[n], j2 = j_out[n], i1 = i_in[n], j1 = j_in[n], tile = t_in[n], nx1 = nx_in[tile];
+      double area = area_x[n];
+      if (xdata[n] == missing) continue;
+      if (weight_exist) area *= weight[tile][j1 * nx1 + i1];
+      int n1 = j1 * nx1 + i1, n0 = j2 * nx2 + i2;
+      if (cell_methods_sum) area /= cell_area_in[tile][n1];
+      else if (cell_measures) area *= (field_area[tile][n1] / cell_area_in[tile][n1]);
+      out[n0] += xdata[n] * area;
+      out_area[n0] += area;
+    }
+    free(xdata);
+  } else {
+    for (long n = 0; n < nxgrid && !rc; n++) {
+      int i2 = i_out[n], j2 = j_out[n], i1 = i_in[n], j1 = j_in[n], tile = t_in[n];
+      double di = di_x[n], dj = dj_x[n], area = area_x[n];
+      int nx1 = nx_in[tile], ny1 = ny_in[tile];
+      if (weight_exist) area *= weight[tile][j1 * nx1 + i1];
+      if (has_missing) {
+        int n2 = (j1 + 1) * (nx1 + 2) + i1 + 1, n0 = j2 * nx2 + i2;
+        if (data[tile][n2] != missing) {
+          int n1 = j1 * nx1 + i1;
+          if (cell_methods_sum) area /= cell_area_in[tile][n1];
+          else if (cell_measures) {
+            if (field_area[tile][n1] == area_missing) { rc = -2; break; }
+            area *= (field_area[tile][n1] / cell_area_in[tile][n1]);
+          }
+          if (grad_mask[tile][n1]) out[n0] += data[tile][n2] * area;
+          else out[n0] += (data[tile][n2] + grad_x[tile][n1] * di + grad_y[tile][n1] * dj) * area;
+          out_area[n0] += area;
+          out_miss[n0] = 1;
+        }
+      } else {
+        for (int k = 0; k < nz; k++) {
+          size_t n0 = (size_t)k * nx2 * ny2 + j2 * nx2 + i2;
+          size_t n1 = (size_t)k * nx1 * ny1 + j1 * nx1 + i1;
+          size_t n2 = (size_t)k * (nx1 + 2) * (ny1 + 2) + (j1 + 1) * (nx1 + 2) + i1 + 1;
+          if (cell_methods_sum) area /= cell_area_in[tile][n1];
+          else if (cell_measures) area *= (field_area[tile][n1] / cell_area_in[tile][n1]);
+          out[n0] += (data[tile][n2] + grad_x[tile][n1] * di + grad_y[tile][n1] * dj) * area;
+          out_area[n0] += area;
+          out_miss[n0] = 1;
+        }
+      }
+    }
+  }
+  if (rc) { free(out_area); free(out_miss); return rc; }
+
+  if (gsum_out) {                                                        /* :815-819 */
+    double g = 0;
+    for (size_t k = 0; k < nout; k++) if (out_area[k] > 0) g += out[k];
+    *gsum_out = g;
+  }
+  if (cell_methods_sum) {                                                /* :821-830 */
+    for (size_t i = 0; i < nout; i++)
+      if (out_area[i] == 0) {
+        if (out_miss[i] == 0) out[i] = missing;
+        else out[i] = 0.0;
+      }
+  } else {
+    for (size_t i = 0; i < nout; i++) {                                  /* :832-839 */
+      if (out_area[i] > 0) out[i] /= out_area[i];
+      else if (out_miss[i] == 1) out[i] = 0.0;
+      else out[i] = missing;
+    }
+    if (target_grid) {                                                   /* :842-869 */
+      for (int i = 0; i < nx2 * ny2; i++) out_area[i] = 0.0;
+      for (long n = 0; n < nxgrid; n++) {
+        int i2 = i_out[n], j2 = j_out[n], i1 = i_in[n], j1 = j_in[n], tile = t_in[n];
+        double area = area_x[n];
+        int nx1 = nx_in[tile];
+        int n0 = j2 * nx2 + i2, n1 = j1 * nx1 + i1;
+        if (cell_measures) out_area[n0] += (area * field_area[tile][n1] / cell_area_in[tile][n1]);
+        else out_area[n0] += area;
+      }
+      for (size_t i = 0; i < nout; i++)
+        if (out[i] != missing) {
+          size_t i2 = i % ((size_t)nx2 * ny2);
+          out[i] *= (out_area[i2] / cell_area_out[i2]);
+        }
+    }
+  }
+  free(out_area); free(out_miss);
+  return 0;
+}
+
+/* conserve_interp.c:874-900: the three input flux sums */
+double orc_gsum_in_ex(int order, int ntiles_in, const int *nx_in, const int *ny_in, const double *const *data,
+                      const double *const *cell_area, const double *const *field_area, int cell_methods_sum,
+                      int has_missing, double missing_in, int nz)
+{
+  int halo = (order == 2) ? 1 : 0;
+  double missing = -ORC_MAXVAL;
+  if (has_missing) missing = missing_in;
+  double g = 0;
+  for (int n = 0; n < ntiles_in; n++) {
+    int nx1 = nx_in[n], ny1 = ny_in[n];
+    if (field_area) {
+      for (int j = 0; j < ny1; j++) for (int i = 0; i < nx1; i++) {
+        double dd = data[n][(j + halo) * (nx1 + 2 * halo) + i + halo];
+        if (dd != missing) g += dd * field_area[n][j * nx1 + i];
+      }
+    } else if (cell_methods_sum) {
+      for (int j = 0; j < ny1; j++) for (int i = 0; i < nx1; i++) {
+        double dd = data[n][(j + halo) * (nx1 + 2 * halo) + i + halo];
+        if (dd != missing) g += dd;
+      }
+    } else {
+      for (int k = 0; k < nz; k++) for (int j = 0; j < ny1; j++) for (int i = 0; i < nx1; i++) {
+        double dd = data[n][(size_t)k * (nx1 + 2 * halo) * (ny1 + 2 * halo) + (j + halo) * (nx1 + 2 * halo) + i + halo];
+        if (dd != missing) g += dd * cell_area[n][j * nx1 + i];
+      }
+    }
+  }
+  return g;
+}

@@ -65,6 +65,13 @@ def oracle():
                                                     dpp, dpp, dpp, ipp, C.c_int, C.c_double, C.c_int, C.c_int,
                                                     C.c_int, dp, dp]
         L.orc_do_scalar_conserve_interp.restype = C.c_int
+        L.orc_do_scalar_conserve_interp_ex.argtypes = [C.c_int, C.c_long] + [ip] * 5 + [dp] * 3 + [C.c_int, ip, ip,
+                                                       dpp, dpp, dpp, ipp, C.c_int, C.c_double, dpp, C.c_int, dpp,
+                                                       C.c_double, dpp, C.c_int, dp, C.c_int, C.c_int, C.c_int,
+                                                       C.c_int, dp, dp]
+        L.orc_do_scalar_conserve_interp_ex.restype = C.c_int
+        L.orc_gsum_in_ex.argtypes = [C.c_int, C.c_int, ip, ip, dpp, dpp, dpp, C.c_int, C.c_int, C.c_double, C.c_int]
+        L.orc_gsum_in_ex.restype = C.c_double
         L.orc_gsum_in.argtypes = [C.c_int, C.c_int, ip, ip, dpp, dpp, C.c_int, C.c_double, C.c_int]
         L.orc_gsum_in.restype = C.c_double
         _ORACLE = L
@@ -231,3 +238,31 @@ def orc_apply(order, x, nx_in, ny_in, data, grad_x, grad_y, grad_mask, has_missi
                                          1 if has_missing else 0, float(missing), nx2, ny2, nz, _dp(out), C.byref(gs))
     assert rc == 0
     return out, gs.value
+
+
+def orc_apply_ex(order, x, nx_in, ny_in, data, grad_x, grad_y, grad_mask, has_missing, missing, nx2, ny2, nz,
+                 weight=None, cell_methods_sum=False, field_area=None, area_missing=-1e20, cell_area_in=None,
+                 target_grid=False, cell_area_out=None, monotonic=False):
+    """All branches of do_scalar_conserve_interp (orc_do_scalar_conserve_interp_ex).  Returns (rc, out, gsum)."""
+    L = oracle()
+    n = len(x["area"])
+    nxi = np.asarray(nx_in, dtype=np.int32)
+    nyi = np.asarray(ny_in, dtype=np.int32)
+    lst = lambda v: [f64(d).ravel() for d in v] if v is not None else None
+    data, gx, gy, w, fa, ca = lst(data), lst(grad_x), lst(grad_y), lst(weight), lst(field_area), lst(cell_area_in)
+    gm = [np.ascontiguousarray(g, dtype=np.int32).ravel() for g in grad_mask] if grad_mask is not None else None
+    cao = f64(cell_area_out).ravel() if cell_area_out is not None else None
+    out = np.empty(nz * nx2 * ny2)
+    gs = C.c_double(0)
+    ints = [np.ascontiguousarray(x[k], dtype=np.int32) for k in ("t_in", "i_in", "j_in", "i_out", "j_out")]
+    area = f64(x["area"])
+    di = f64(x["di"]) if order == 2 else None
+    dj = f64(x["dj"]) if order == 2 else None
+    pa = lambda v, t=dp: _ptr_array(v, t) if v else None
+    rc = L.orc_do_scalar_conserve_interp_ex(order, n, *[_ip(v) for v in ints], _dp(area), _dp(di), _dp(dj),
+                                            len(data), _ip(nxi), _ip(nyi), pa(data), pa(gx), pa(gy), pa(gm, ip),
+                                            1 if has_missing else 0, float(missing), pa(w),
+                                            1 if cell_methods_sum else 0, pa(fa), float(area_missing), pa(ca),
+                                            1 if target_grid else 0, _dp(cao), 1 if monotonic else 0,
+                                            nx2, ny2, nz, _dp(out), C.byref(gs))
+    return rc, out, gs.value

@@ -162,3 +162,63 @@ def test_tripolar_generator_properties(fg):
     assert np.max(np.abs(top_lat - top_lat[::-1])) < 1e-12          # fold symmetry
     half = nlon // 2
     assert np.max(np.abs(top_lat[:half + 1] - top_lat[:half + 1][::-1])) < 1e-12
+
+
+def _small_case(fg, order):
+    ni, nlon, nlat = 12, 36, 18
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    o = orc.orc_setup(order, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
+    rng = np.random.default_rng(5)
+    h = 1 if order == 2 else 0
+    data = [rng.standard_normal((1, ni + 2 * h, ni + 2 * h)) + 5.0 for _ in range(6)]
+    gx = [rng.standard_normal((1, ni, ni)) for _ in range(6)]
+    gy = [rng.standard_normal((1, ni, ni)) for _ in range(6)]
+    return ni, nlon, nlat, lo, la, o, data, gx, gy
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_oracle_ex_reduces_to_plain_branch(fg, order):
+    """orc_do_scalar_conserve_interp_ex with every option off reproduces the plain-branch oracle bit for bit."""
+    ni, nlon, nlat, lo, la, o, data, gx, gy = _small_case(fg, order)
+    gm = [np.zeros((ni, ni), dtype=np.int32) for _ in range(6)]
+    a, ga = orc.orc_apply(order, o, [ni] * 6, [ni] * 6, data, gx, gy, gm, False, 0.0, nlon, nlat, 1)
+    rc, b, gb = orc.orc_apply_ex(order, o, [ni] * 6, [ni] * 6, data, gx, gy, gm, False, 0.0, nlon, nlat, 1)
+    assert rc == 0 and np.array_equal(a.view(np.uint64), b.view(np.uint64)) and ga == gb
+
+
+def test_oracle_monotone_limiter_bounds(fg):
+    """Monotone branch: every remapped value stays within the extremes of the source field, and a field with zero
+    gradients is untouched by the limiter (equals the first-order remap of the same weights)."""
+    ni, nlon, nlat, lo, la, o, data, gx, gy = _small_case(fg, 2)
+    big = [g * 3.0 for g in gx], [g * 3.0 for g in gy]
+    rc, out, _ = orc.orc_apply_ex(2, o, [ni] * 6, [ni] * 6, data, big[0], big[1], None, False, 0.0, nlon, nlat, 1,
+                                  monotonic=True)
+    assert rc == 0
+    lo_v = min(d.min() for d in data)
+    hi_v = max(d.max() for d in data)
+    assert out.min() >= lo_v - 1e-9 and out.max() <= hi_v + 1e-9
+    rc, unl, _ = orc.orc_apply_ex(2, o, [ni] * 6, [ni] * 6, data, big[0], big[1], None, False, 0.0, nlon, nlat, 1)
+    assert unl.max() > hi_v or unl.min() < lo_v or not np.array_equal(unl, out)
+    zero = [np.zeros_like(g) for g in gx]
+    rc, z, _ = orc.orc_apply_ex(2, o, [ni] * 6, [ni] * 6, data, zero, zero, None, False, 0.0, nlon, nlat, 1,
+                                monotonic=True)
+    rc2, p, _ = orc.orc_apply_ex(2, o, [ni] * 6, [ni] * 6, data, zero, zero, None, False, 0.0, nlon, nlat, 1)
+    assert rc == 0 and rc2 == 0 and np.array_equal(z, p)
+
+
+def test_oracle_sum_and_target_grid_branches(fg):
+    """cell_methods=sum conserves the plain sum of the field; --target_grid rescales by covered/own cell area."""
+    ni, nlon, nlat, lo, la, o, data, gx, gy = _small_case(fg, 1)
+    ca = o["cell_area_in"]                                        # per-tile list (get_grid_area values)
+    rc, out, gs = orc.orc_apply_ex(1, o, [ni] * 6, [ni] * 6, data, None, None, None, False, 0.0, nlon, nlat, 1,
+                                   cell_methods_sum=True, cell_area_in=ca)
+    assert rc == 0
+    tot_in = sum(d.sum() for d in data)
+    assert abs(out.sum() - tot_in) < 1e-8 * abs(tot_in)          # closure of the exchange grid itself ~1e-9
+    cao = orc.orc_get_grid_area(nlon, nlat, lo, la)
+    rc, t, _ = orc.orc_apply_ex(1, o, [ni] * 6, [ni] * 6, data, None, None, None, False, 0.0, nlon, nlat, 1,
+                                target_grid=True, cell_area_out=cao)
+    rc2, p, _ = orc.orc_apply_ex(1, o, [ni] * 6, [ni] * 6, data, None, None, None, False, 0.0, nlon, nlat, 1)
+    assert rc == 0 and rc2 == 0
+    assert np.max(np.abs(t / p - 1)) < 5e-3 and not np.array_equal(t, p)

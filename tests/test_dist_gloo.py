@@ -12,6 +12,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _mono_fields(ncell):
+    rng = np.random.default_rng(11)
+    return rng.standard_normal(ncell) + 5.0, rng.standard_normal(ncell), rng.standard_normal(ncell)
+
+
 def _worker(rank, world, initfile, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -49,7 +54,16 @@ def _worker(rank, world, initfile, outdir):
     di = cl / area - cen_lon[s]
     dj = ct / area - cen_lat[s]
     gsum = fg.allreduce_scalar_sum(float(np.sum(area)))
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), s=s, jo=jo, io=io, area=area, di=di, dj=dj, gsum=gsum, band=[j0, j1])
+    # monotone limiter exchange (conserve_interp.c:672-677): per-source-cell extremes of the second-order exchange-cell
+    # values over ALL bands = MIN / MAX all-reduce of the per-rank extremes
+    f, gxv, gyv = _mono_fields(ncell)
+    xd = f[s] + gxv[s] * di + gyv[s] * dj
+    fmin = np.full(ncell, 1e20); fmax = np.full(ncell, -1e20)
+    np.minimum.at(fmin, s, xd); np.maximum.at(fmax, s, xd)
+    tmin, tmax = torch.from_numpy(fmin), torch.from_numpy(fmax)
+    fg.allreduce_minmax(tmin, tmax)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), s=s, jo=jo, io=io, area=area, di=di, dj=dj, gsum=gsum, band=[j0, j1],
+             fmin=tmin.numpy(), fmax=tmax.numpy())
     dist.destroy_process_group()
 
 
@@ -80,3 +94,12 @@ def test_two_rank_band_decomposition_matches_single_rank(fg):
         assert np.max(np.abs(v - o[k])) < 1e-12 * max(1.0, np.max(np.abs(o[k])))
     assert abs(float(parts[0]["gsum"]) - float(np.sum(o["area"]))) < 1e-6 * np.sum(o["area"]) * 1e-6
     assert float(parts[0]["gsum"]) == float(parts[1]["gsum"])
+    # monotone extremes: both ranks hold the global per-source-cell min / max
+    f, gxv, gyv = _mono_fields(6 * ni * ni)
+    sref = o["t_in"].astype(np.int64) * ni * ni + o["j_in"] * ni + o["i_in"]
+    xd = f[sref] + gxv[sref] * o["di"] + gyv[sref] * o["dj"]
+    fmin = np.full(6 * ni * ni, 1e20); fmax = np.full(6 * ni * ni, -1e20)
+    np.minimum.at(fmin, sref, xd); np.maximum.at(fmax, sref, xd)
+    for p in parts:
+        assert np.allclose(p["fmin"], fmin, rtol=1e-12, atol=1e-12) and np.allclose(p["fmax"], fmax, rtol=1e-12, atol=1e-12)
+    assert np.array_equal(parts[0]["fmin"], parts[1]["fmin"]) and np.array_equal(parts[0]["fmax"], parts[1]["fmax"])

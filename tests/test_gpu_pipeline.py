@@ -123,6 +123,110 @@ def test_sweep_bitwise_with_oracle_weights(fg, gpu_ok, order, nz, has_missing):
     plan.destroy()
 
 
+EX_CASES = [
+    # order, nz, has_missing, weight, sum, measures, target, monotonic
+    (1, 1, False, False, False, False, False, False),
+    (2, 3, False, False, False, False, False, False),
+    (1, 3, False, True, False, False, False, False),
+    (2, 2, False, True, False, False, True, False),
+    (1, 1, True, True, True, False, False, False),
+    (2, 1, True, False, True, False, False, False),
+    (1, 1, True, False, False, True, True, False),
+    (2, 1, True, True, False, True, False, False),
+    (2, 1, False, False, False, True, True, False),
+    (2, 1, False, False, False, False, False, True),
+    (2, 1, True, True, False, False, False, True),
+    (2, 1, True, False, True, False, False, True),
+    (2, 1, False, False, False, True, True, True),
+]
+
+
+@pytest.mark.parametrize("order,nz,has_missing,use_w,use_sum,use_meas,use_target,mono", EX_CASES)
+def test_sweep_every_option_bitwise(fg, gpu_ok, order, nz, has_missing, use_w, use_sum, use_meas, use_target, mono):
+    """fg_plan_apply_ex against the full-branch oracle (conserve_interp.c:507-910) on the oracle's exchange cells:
+    weight field, cell_methods=sum, cell_measures, --target_grid and the monotone limiter, alone and combined.
+    The per-entry operation order is the reference's, so results are bit-identical."""
+    import torch
+    ni, nlon, nlat = 24, 72, 36
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    o = orc.orc_setup(order, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
+    data, gx, gy = make_fields(ni, lon, lat, nz, order, seed=77 + order)
+    if mono:
+        gx, gy = [g * 4.0 for g in gx], [g * 4.0 for g in gy]          # make the limiter bite
+    rng = np.random.default_rng(3)
+    missing = 1.0e20
+    h = 1 if order == 2 else 0
+    gm = [np.zeros((ni, ni), dtype=np.int32) for _ in range(6)]
+    if has_missing:
+        for t in range(6):
+            m = ((np.add.outer(np.arange(ni + 2 * h), np.arange(ni + 2 * h)) % 10) == 0)
+            data[t][0][m] = missing
+        gm = [((np.add.outer(np.arange(ni), np.arange(ni)) % 7) == 0).astype(np.int32) for _ in range(6)]
+    w = [rng.uniform(0.2, 1.0, (ni, ni)) for _ in range(6)] if use_w else None
+    ca = o["cell_area_in"]
+    fa = [np.asarray(ca[t]).reshape(ni, ni) * rng.uniform(0.3, 1.0, (ni, ni)) for t in range(6)] if use_meas else None
+    cao = orc.orc_get_grid_area(nlon, nlat, lo, la) if use_target else None
+    rc, ref, gs_ref = orc.orc_apply_ex(order, o, [ni] * 6, [ni] * 6, [d.reshape(nz, -1) for d in data],
+                                       [g.reshape(nz, -1) for g in gx] if order == 2 else None,
+                                       [g.reshape(nz, -1) for g in gy] if order == 2 else None,
+                                       gm if order == 2 else None, has_missing, missing, nlon, nlat, nz,
+                                       weight=w, cell_methods_sum=use_sum, field_area=fa, area_missing=-1e20,
+                                       cell_area_in=ca, target_grid=use_target, cell_area_out=cao, monotonic=mono)
+    assert rc == 0
+    plan = fg.XgridPlan.create_empty(order, [ni] * 6, [ni] * 6, nlon, nlat)
+    plan.set_xgrid(o["t_in"], o["i_in"], o["j_in"], o["i_out"], o["j_out"], o["area"], o.get("di"), o.get("dj"))
+    dev = "cuda:0"
+    pack = lambda arrs: torch.from_numpy(np.ascontiguousarray(np.stack(
+        [np.concatenate([a[k].ravel() for a in arrs]) for k in range(nz)]))).to(dev)
+    flat = lambda arrs: torch.from_numpy(np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in arrs])).to(dev)
+    d_t = pack(data)
+    gx_t = pack(gx) if order == 2 else None
+    gy_t = pack(gy) if order == 2 else None
+    gm_t = torch.from_numpy(np.concatenate([g.ravel() for g in gm])).to(dev) if order == 2 else None
+    out_t = torch.empty(nz * nlon * nlat, dtype=torch.float64, device=dev)
+    w_t = flat(w) if use_w else None
+    fa_t = flat(fa) if use_meas else None
+    ca_t = flat(ca)
+    cao_t = torch.from_numpy(cao).to(dev) if use_target else None
+    torch.cuda.synchronize()
+    gs = plan.apply_ex(d_t, out_t, nz=nz, grad_x_t=gx_t, grad_y_t=gy_t, grad_mask_t=gm_t, has_missing=has_missing,
+                       missing=missing, weight_t=w_t, cell_methods_sum=use_sum, field_area_t=fa_t, area_missing=-1e20,
+                       cell_area_in_t=ca_t, cell_area_out_t=cao_t, monotonic=mono, want_gsum=True)
+    plan.sync()
+    out = out_t.cpu().numpy()
+    assert np.array_equal(_bits(out), _bits(ref))
+    assert abs(gs - gs_ref) <= 1e-12 * max(abs(gs_ref), 1e-300)
+    plan.destroy()
+
+
+def test_sweep_option_fatal_checks(fg, gpu_ok):
+    """The reference's fatal data checks surface as FG_ERR_DATA with the reference's message: a cell_measures area that
+    is missing under valid data (conserve_interp.c:584-587)."""
+    import torch
+    ni, nlon, nlat = 8, 24, 12
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    o = orc.orc_setup(1, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
+    data = [np.full((1, ni, ni), 2.0) for _ in range(6)]
+    fa = [np.asarray(o["cell_area_in"][t]).reshape(ni, ni).copy() for t in range(6)]
+    fa[1][3, 3] = -1.0e20
+    rc, _, _ = orc.orc_apply_ex(1, o, [ni] * 6, [ni] * 6, [d.reshape(1, -1) for d in data], None, None, None, True, 1e20,
+                                nlon, nlat, 1, field_area=fa, area_missing=-1e20, cell_area_in=o["cell_area_in"])
+    assert rc == -2
+    plan = fg.XgridPlan.create_empty(1, [ni] * 6, [ni] * 6, nlon, nlat)
+    plan.set_xgrid(o["t_in"], o["i_in"], o["j_in"], o["i_out"], o["j_out"], o["area"], None, None)
+    flat = lambda arrs: torch.from_numpy(np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in arrs])).to("cuda:0")
+    out_t = torch.empty(nlon * nlat, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    with pytest.raises(fg.FregridHipError, match="data is not missing but area is missing"):
+        plan.apply_ex(flat(data), out_t, has_missing=True, missing=1e20, field_area_t=flat(fa), area_missing=-1e20,
+                      cell_area_in_t=flat(o["cell_area_in"]))
+    with pytest.raises(fg.FregridHipError, match="cell_measures should be false when nz > 1"):
+        plan.apply_ex(flat(data), out_t, nz=2, field_area_t=flat(fa), cell_area_in_t=flat(o["cell_area_in"]))
+    plan.destroy()
+
+
 def test_end_to_end_mirror_api_and_conservation(fg, gpu_ok, capsys):
     """setup_conserve_interp + do_scalar_conserve_interp with --check_conserve (the flow of
     tests/fregrid/cubedsphere: C48 -> 144x90, conserve_order2)."""
