@@ -74,6 +74,16 @@ def oracle():
         L.orc_gsum_in_ex.restype = C.c_double
         L.orc_gsum_in.argtypes = [C.c_int, C.c_int, ip, ip, dpp, dpp, C.c_int, C.c_double, C.c_int]
         L.orc_gsum_in.restype = C.c_double
+        L.orc_clip_2dx2d_great_circle.argtypes = [dp, dp, dp, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp]
+        L.orc_clip_2dx2d_great_circle.restype = C.c_int
+        L.orc_great_circle_area.argtypes = [C.c_int, dp, dp, dp]
+        L.orc_great_circle_area.restype = C.c_double
+        L.orc_get_grid_great_circle_area.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+        L.orc_get_grid_great_circle_area.restype = None
+        L.orc_latlon2xyz.argtypes = [C.c_int, dp, dp, dp, dp, dp]
+        L.orc_latlon2xyz.restype = None
+        L.orc_create_xgrid_great_circle_rows.argtypes = [C.c_int] * 4 + [dp] * 5 + [C.c_int, C.c_int, C.c_long] + [ip] * 4 + [dp] * 3
+        L.orc_create_xgrid_great_circle_rows.restype = C.c_long
         _ORACLE = L
     return _ORACLE
 
@@ -109,6 +119,14 @@ def ref():
         L.create_xgrid_2dx2d_order2.restype = C.c_int
         L.conserve_interp.argtypes = [C.c_int] * 4 + [dp] * 7
         L.conserve_interp.restype = None
+        L.clip_2dx2d_great_circle.argtypes = [dp, dp, dp, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp]
+        L.clip_2dx2d_great_circle.restype = C.c_int
+        L.great_circle_area.argtypes = [C.c_int, dp, dp, dp]
+        L.great_circle_area.restype = C.c_double
+        L.get_grid_great_circle_area.argtypes = [cip, cip, dp, dp, dp]
+        L.get_grid_great_circle_area.restype = None
+        L.create_xgrid_great_circle.argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp] * 3
+        L.create_xgrid_great_circle.restype = C.c_int
         _REF = L
     return _REF
 
@@ -266,3 +284,46 @@ def orc_apply_ex(order, x, nx_in, ny_in, data, grad_x, grad_y, grad_mask, has_mi
                                             1 if target_grid else 0, _dp(cao), 1 if monotonic else 0,
                                             nx2, ny2, nz, _dp(out), C.byref(gs))
     return rc, out, gs.value
+
+
+def orc_create_xgrid_gc(nx1, ny1, nx2, ny2, lon_in, lat_in, lon_out, lat_out, mask=None, j1_beg=0, j1_end=None, capacity=None):
+    """create_xgrid_great_circle (oracle restatement); source rows [j1_beg, j1_end)."""
+    L = oracle()
+    lon_in, lat_in, lon_out, lat_out = f64(lon_in).ravel(), f64(lat_in).ravel(), f64(lon_out).ravel(), f64(lat_out).ravel()
+    mask = f64(np.ones(nx1 * ny1) if mask is None else mask).ravel()
+    cap = capacity or 8 * (nx1 * ny1 + nx2 * ny2) + 1024
+    ii, ji, io, jo = (np.empty(cap, dtype=np.int32) for _ in range(4))
+    a, cl, ct = np.empty(cap), np.empty(cap), np.empty(cap)
+    n = L.orc_create_xgrid_great_circle_rows(nx1, ny1, nx2, ny2, _dp(lon_in), _dp(lat_in), _dp(lon_out), _dp(lat_out),
+                                             _dp(mask), j1_beg, ny1 if j1_end is None else j1_end, cap,
+                                             _ip(ii), _ip(ji), _ip(io), _ip(jo), _dp(a), _dp(cl), _dp(ct))
+    if n < 0:
+        raise RuntimeError(f"oracle create_xgrid_great_circle failed: {n}")
+    return dict(n=int(n), i_in=ii[:n].copy(), j_in=ji[:n].copy(), i_out=io[:n].copy(), j_out=jo[:n].copy(), area=a[:n].copy())
+
+
+def ref_create_xgrid_gc(nx1, ny1, nx2, ny2, lon_in, lat_in, lon_out, lat_out, mask=None):
+    L = ref()
+    lon_in, lat_in, lon_out, lat_out = f64(lon_in).ravel(), f64(lat_in).ravel(), f64(lon_out).ravel(), f64(lat_out).ravel()
+    mask = f64(np.ones(nx1 * ny1) if mask is None else mask).ravel()
+    cap = 5000000
+    ii, ji, io, jo = (np.empty(cap, dtype=np.int32) for _ in range(4))
+    a, cl, ct = np.empty(cap), np.empty(cap), np.empty(cap)
+    n = L.create_xgrid_great_circle(C.byref(C.c_int(nx1)), C.byref(C.c_int(ny1)), C.byref(C.c_int(nx2)), C.byref(C.c_int(ny2)),
+                                    _dp(lon_in), _dp(lat_in), _dp(lon_out), _dp(lat_out), _dp(mask),
+                                    _ip(ii), _ip(ji), _ip(io), _ip(jo), _dp(a), _dp(cl), _dp(ct))
+    return dict(n=n, i_in=ii[:n].copy(), j_in=ji[:n].copy(), i_out=io[:n].copy(), j_out=jo[:n].copy(), area=a[:n].copy())
+
+
+def orc_get_grid_gc_area(nx, ny, lon, lat):
+    lon, lat = f64(lon).ravel(), f64(lat).ravel()
+    a = np.empty(nx * ny)
+    oracle().orc_get_grid_great_circle_area(nx, ny, _dp(lon), _dp(lat), _dp(a))
+    return a
+
+
+def ref_get_grid_gc_area(nx, ny, lon, lat):
+    lon, lat = f64(lon).ravel(), f64(lat).ravel()
+    a = np.empty(nx * ny)
+    ref().get_grid_great_circle_area(C.byref(C.c_int(nx)), C.byref(C.c_int(ny)), _dp(lon), _dp(lat), _dp(a))
+    return a

@@ -222,3 +222,17 @@ def test_oracle_sum_and_target_grid_branches(fg):
     rc2, p, _ = orc.orc_apply_ex(1, o, [ni] * 6, [ni] * 6, data, None, None, None, False, 0.0, nlon, nlat, 1)
     assert rc == 0 and rc2 == 0
     assert np.max(np.abs(t / p - 1)) < 5e-3 and not np.array_equal(t, p)
+
+
+@pytest.mark.parametrize("t", [0, 2])
+def test_great_circle_oracle_reproduces_reference_golden(t):
+    """tests/golden/gc_c24_xgrid.npz was written by the compiled reference (make_golden_gc.py); this check does not
+    need oracle/_ref, so it also runs where the reference is absent."""
+    g = np.load(os.path.join(GOLD, "gc_c24_xgrid.npz"))
+    o = orc.orc_create_xgrid_gc(24, 24, 144, 90, g[f"lon_t{t}"], g[f"lat_t{t}"], g["lon_out"], g["lat_out"])
+    assert o["n"] == len(g[f"area_t{t}"])
+    for k in ("i_in", "j_in", "i_out", "j_out"):
+        assert np.array_equal(o[k], g[f"{k}_t{t}"]), k
+    assert np.array_equal(o["area"].view(np.uint64), g[f"area_t{t}"].view(np.uint64))
+    ca = orc.orc_get_grid_gc_area(24, 24, g[f"lon_t{t}"], g[f"lat_t{t}"])
+    assert np.array_equal(ca.view(np.uint64), g[f"cell_area_t{t}"].view(np.uint64))

@@ -121,3 +121,60 @@ def test_conserve_interp_ref_small(fg):
         d = x["j_out"][n] * 20 + x["i_out"][n]
         exp[d] += data[x["j_in"][n] * 36 + x["i_in"][n]] * (x["area"][n] / dst_area[d])
     assert np.array_equal(_bits(exp), _bits(out))
+
+
+GC_CASES = {
+    "c24_tile1_144x90": lambda fg: (24, 24, 144, 90) + (fg.gnomonic_ed_corners(24)[0][0], fg.gnomonic_ed_corners(24)[1][0]) + fg.latlon_corners(144, 90),
+    "c24_tile3_polar_144x90": lambda fg: (24, 24, 144, 90) + (fg.gnomonic_ed_corners(24)[0][2], fg.gnomonic_ed_corners(24)[1][2]) + fg.latlon_corners(144, 90),
+    "latlon_aligned_2x_refinement": lambda fg: (36, 18, 72, 36) + fg.latlon_corners(36, 18) + fg.latlon_corners(72, 36),
+    "latlon_regional_offset": lambda fg: (30, 20, 45, 33) + fg.latlon_corners(30, 20, 10., 70., -30., 30.) + fg.latlon_corners(45, 33, 0., 90., -40., 40.),
+    "latlon_to_cubed_polar_tile": lambda fg: (40, 20, 12, 12) + fg.latlon_corners(40, 20) + (fg.gnomonic_ed_corners(12)[0][5], fg.gnomonic_ed_corners(12)[1][5]),
+    "tripolar_to_cubed": lambda fg: (45, 27, 12, 12) + fg.tripolar_corners(45, 27) + (fg.gnomonic_ed_corners(12)[0][2], fg.gnomonic_ed_corners(12)[1][2]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GC_CASES))
+def test_great_circle_oracle_bitwise(fg, name):
+    """gc_oracle.c (array restatement of the Node-list clip) against the reference's own create_xgrid_great_circle /
+    get_grid_great_circle_area: identical exchange-cell lists and bit-identical areas, including the degenerate
+    aligned-edge cases (u snapped to 0/1, coincident planes) and pole cells (duplicate vertices merged by addEnd)."""
+    args = GC_CASES[name](fg)
+    o = orc.orc_create_xgrid_gc(*args)
+    r = orc.ref_create_xgrid_gc(*args)
+    assert o["n"] == r["n"] and o["n"] > 0
+    for k in ("i_in", "j_in", "i_out", "j_out"):
+        assert np.array_equal(o[k], r[k]), k
+    assert np.array_equal(o["area"].view(np.uint64), r["area"].view(np.uint64))
+    a1 = orc.orc_get_grid_gc_area(args[0], args[1], args[4], args[5])
+    a2 = orc.ref_get_grid_gc_area(args[0], args[1], args[4], args[5])
+    assert np.array_equal(a1.view(np.uint64), a2.view(np.uint64))
+
+
+def test_great_circle_clip_vertices_bitwise(fg):
+    """clip_2dx2d_great_circle vertex lists (not just areas) for neighbouring C24 / lat-lon cell pairs."""
+    import ctypes as C
+    R, O = orc.ref(), orc.oracle()
+    lon, lat = fg.gnomonic_ed_corners(24)
+    lo, la = fg.latlon_corners(144, 90)
+    n1 = 25 * 25
+    x1, y1, z1 = (np.empty(n1) for _ in range(3))
+    O.orc_latlon2xyz(n1, orc._dp(orc.f64(lon[2]).ravel()), orc._dp(orc.f64(lat[2]).ravel()), orc._dp(x1), orc._dp(y1), orc._dp(z1))
+    n2 = 145 * 91
+    x2, y2, z2 = (np.empty(n2) for _ in range(3))
+    O.orc_latlon2xyz(n2, orc._dp(orc.f64(lo).ravel()), orc._dp(orc.f64(la).ravel()), orc._dp(x2), orc._dp(y2), orc._dp(z2))
+    cell = lambda x, nxp, i, j: np.array([x[j * nxp + i], x[(j + 1) * nxp + i], x[(j + 1) * nxp + i + 1], x[j * nxp + i + 1]])
+    gc = orc.orc_create_xgrid_gc(24, 24, 144, 90, lon[2], lat[2], lo, la)
+    checked = 0
+    for k in range(0, gc["n"], 7):
+        i1, j1, i2, j2 = (int(gc[key][k]) for key in ("i_in", "j_in", "i_out", "j_out"))
+        a = [cell(v, 25, i1, j1) for v in (x1, y1, z1)]
+        b = [cell(v, 145, i2, j2) for v in (x2, y2, z2)]
+        oo = [np.zeros(50) for _ in range(3)]
+        rr = [np.zeros(50) for _ in range(3)]
+        no = O.orc_clip_2dx2d_great_circle(*[orc._dp(v) for v in a], 4, *[orc._dp(v) for v in b], 4, *[orc._dp(v) for v in oo])
+        nr = R.clip_2dx2d_great_circle(*[orc._dp(v) for v in a], 4, *[orc._dp(v) for v in b], 4, *[orc._dp(v) for v in rr])
+        assert no == nr and no >= 3
+        for u, v in zip(oo, rr):
+            assert np.array_equal(u[:no].view(np.uint64), v[:nr].view(np.uint64))
+        checked += 1
+    assert checked > 500
