@@ -25,7 +25,7 @@ from .c2l import C2lPrep, find_contacts, c2l_grid_info, halo_map  # noqa: F401
 from .remap_file import write_remap_file, read_remap_file  # noqa: F401
 from .parallel import band_rows, allreduce_cell_sums, allreduce_scalar_sum, allreduce_minmax  # noqa: F401
 from .conserve_interp import (  # noqa: F401
-    CONSERVE_ORDER1, CONSERVE_ORDER2, CHECK_CONSERVE, READ, WRITE, TARGET, MONOTONIC, CELL_METHODS_MEAN, CELL_METHODS_SUM,
+    CONSERVE_ORDER1, CONSERVE_ORDER2, CHECK_CONSERVE, READ, WRITE, TARGET, MONOTONIC, GREAT_CIRCLE, LEGACY_CLIP, CELL_METHODS_MEAN, CELL_METHODS_SUM,
     GridConfig, InterpConfig, FieldConfig, VarConfig, XgridPlan,
     setup_conserve_interp, do_scalar_conserve_interp,
 )
@@ -107,3 +107,51 @@ def conserve_interp(nx_src, ny_src, nx_dst, ny_dst, x_src, y_src, x_dst, y_dst, 
     lib().conserve_interp(nx_src, ny_src, nx_dst, ny_dst, _dp(x_src), _dp(y_src), _dp(x_dst), _dp(y_dst),
                           _dp(mask), _dp(data_src), _dp(out))
     return out
+
+
+def create_xgrid_great_circle(nlon_in, nlat_in, nlon_out, nlat_out, lon_in, lat_in, lon_out, lat_out, mask_in=None):
+    """create_xgrid.c:1366 -- returns (nxgrid, i_in, j_in, i_out, j_out, xgrid_area, xgrid_clon, xgrid_clat); the
+    centroid outputs are zero, as in the reference (:1446-1447)."""
+    _lib.require_gpu()
+    lon_in, lat_in, lon_out, lat_out = _f64(lon_in), _f64(lat_in), _f64(lon_out), _f64(lat_out)
+    assert lon_in.size == (nlon_in + 1) * (nlat_in + 1) == lat_in.size
+    assert lon_out.size == (nlon_out + 1) * (nlat_out + 1) == lat_out.size
+    mask = _f64(np.ones(nlon_in * nlat_in) if mask_in is None else mask_in)
+    cap = get_maxxgrid()
+    i_in, j_in, i_out, j_out = (np.empty(cap, dtype=np.int32) for _ in range(4))
+    area, clon, clat = (np.empty(cap, dtype=np.float64) for _ in range(3))
+    n = lib().create_xgrid_great_circle(C.byref(C.c_int(nlon_in)), C.byref(C.c_int(nlat_in)), C.byref(C.c_int(nlon_out)),
+                                        C.byref(C.c_int(nlat_out)), _dp(lon_in), _dp(lat_in), _dp(lon_out), _dp(lat_out),
+                                        _dp(mask), _ip(i_in), _ip(j_in), _ip(i_out), _ip(j_out), _dp(area), _dp(clon), _dp(clat))
+    return (n, i_in[:n].copy(), j_in[:n].copy(), i_out[:n].copy(), j_out[:n].copy(), area[:n].copy(),
+            clon[:n].copy(), clat[:n].copy())
+
+
+def get_grid_great_circle_area(nlon, nlat, lon, lat):
+    """create_xgrid.c:98 -- area[nlat*nlon] (m^2), spherical excess of each cell."""
+    _lib.require_gpu()
+    lon, lat = _f64(lon), _f64(lat)
+    area = np.empty(nlon * nlat, dtype=np.float64)
+    lib().get_grid_great_circle_area(C.byref(C.c_int(nlon)), C.byref(C.c_int(nlat)), _dp(lon), _dp(lat), _dp(area))
+    return area
+
+
+def latlon2xyz(lon, lat):
+    """mosaic_util.c:212 -- unit vectors (host libm, threaded)."""
+    lon, lat = _f64(lon).reshape(-1), _f64(lat).reshape(-1)
+    x, y, z = (np.empty(lon.size) for _ in range(3))
+    lib().fg_latlon2xyz(lon.size, _dp(lon), _dp(lat), _dp(x), _dp(y), _dp(z))
+    return x, y, z
+
+
+def gc_clip_batch(a, b, device=0):
+    """clip_2dx2d_great_circle on npairs quadrilateral pairs: a, b [npairs, 4, 3] unit vectors (clockwise).
+    Returns (n_out [npairs], vertices [npairs, 16, 3], area [npairs])."""
+    _lib.require_gpu()
+    a, b = _f64(a), _f64(b)
+    n = a.shape[0]
+    out = np.zeros((n, 16, 3))
+    n_out = np.zeros(n, dtype=np.int32)
+    area = np.zeros(n)
+    _lib.check(lib().fg_gc_clip_batch(n, _dp(a), _dp(b), _dp(out), _ip(n_out), _dp(area), device))
+    return n_out, out, area

@@ -30,7 +30,10 @@ EXPORTS = [
     "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
     "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
     "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_apply_ex", "fg_plan_mono_begin",
-    "fg_plan_mono_minmax_dev", "fg_plan_mono_copy_minmax", "fg_plan_mono_end", "fg_plan_stream", "fg_plan_sync",
+    "fg_plan_mono_minmax_dev", "fg_plan_mono_copy_minmax", "fg_plan_mono_end",
+    "fg_plan_create_great_circle", "fg_plan_create_great_circle_dev", "fg_latlon2xyz", "create_xgrid_great_circle",
+    "create_xgrid_great_circle_", "get_grid_great_circle_area", "get_grid_great_circle_area_", "clip_2dx2d_great_circle",
+    "great_circle_area", "fg_gc_clip_batch", "fg_plan_stream", "fg_plan_sync",
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
     "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
     "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
@@ -141,6 +144,25 @@ def lib():
     L.fg_plan_mono_copy_minmax.restype = C.c_int
     L.fg_plan_mono_end.argtypes = [vp, ao, vp, vp, dp]
     L.fg_plan_mono_end.restype = C.c_int
+    L.fg_plan_create_great_circle.argtypes = [C.c_int, ip, ip, dpp, dpp, dpp, C.c_int, C.c_int, dp, dp, C.c_int, C.POINTER(vp)]
+    L.fg_plan_create_great_circle.restype = C.c_long
+    L.fg_plan_create_great_circle_dev.argtypes = [C.c_int, ip, ip, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                  C.c_int, C.c_int, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, C.c_int,
+                                                  C.POINTER(vp)]
+    L.fg_plan_create_great_circle_dev.restype = C.c_long
+    L.fg_latlon2xyz.argtypes = [C.c_long, dp, dp, dp, dp, dp]
+    L.fg_latlon2xyz.restype = None
+    cip = C.POINTER(C.c_int)
+    L.create_xgrid_great_circle.argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp] * 3
+    L.create_xgrid_great_circle.restype = C.c_int
+    L.get_grid_great_circle_area.argtypes = [cip, cip, dp, dp, dp]
+    L.get_grid_great_circle_area.restype = None
+    L.clip_2dx2d_great_circle.argtypes = [dp, dp, dp, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp]
+    L.clip_2dx2d_great_circle.restype = C.c_int
+    L.great_circle_area.argtypes = [C.c_int, dp, dp, dp]
+    L.great_circle_area.restype = C.c_double
+    L.fg_gc_clip_batch.argtypes = [C.c_int, dp, dp, dp, ip, dp, C.c_int]
+    L.fg_gc_clip_batch.restype = C.c_int
     L.fg_plan_stream.argtypes = [vp]
     L.fg_plan_stream.restype = vp
     L.fg_plan_sync.argtypes = [vp]

@@ -25,6 +25,8 @@ TARGET = 16
 READ = 256
 WRITE = 512
 CHECK_CONSERVE = 1024
+LEGACY_CLIP = 2048
+GREAT_CIRCLE = 4096
 MONOTONIC = 16384
 CELL_METHODS_MEAN = 0      # globals.h:64-65
 CELL_METHODS_SUM = 1
@@ -150,6 +152,57 @@ class XgridPlan:
                                    C.c_void_p(lon_out_t.data_ptr()), C.c_void_p(lat_out_t.data_ptr()),
                                    float(mean_dlat), float(mean_dlon), device, sptr, use, C.byref(h)))
         return cls(h.value, order, device)
+
+    @classmethod
+    def create_great_circle(cls, grids_in, grid_out, masks=None, device=0):
+        """Great-circle search (create_xgrid_great_circle semantics) with host corner arrays; first order."""
+        _lib.require_gpu()
+        L = lib()
+        nt = len(grids_in)
+        nx = (C.c_int * nt)(*[g.nx for g in grids_in])
+        ny = (C.c_int * nt)(*[g.ny for g in grids_in])
+        keep = []
+        dpt = C.POINTER(C.c_double)
+
+        def arr(a, n):
+            a = _f64(a).reshape(-1)
+            assert a.size == n, (a.size, n)
+            keep.append(a)
+            return _dp(a)
+
+        lon = (dpt * nt)(*[arr(g.lonc, (g.nx + 1) * (g.ny + 1)) for g in grids_in])
+        lat = (dpt * nt)(*[arr(g.latc, (g.nx + 1) * (g.ny + 1)) for g in grids_in])
+        msk = None
+        if masks is not None:
+            msk = (dpt * nt)(*[arr(m, g.nx * g.ny) if m is not None else dpt() for m, g in zip(masks, grids_in)])
+        lo = arr(grid_out.lonc, (grid_out.nx + 1) * (grid_out.ny + 1))
+        la = arr(grid_out.latc, (grid_out.nx + 1) * (grid_out.ny + 1))
+        h = C.c_void_p()
+        check(L.fg_plan_create_great_circle(nt, nx, ny, lon, lat, msk, grid_out.nx, grid_out.ny, lo, la, device, C.byref(h)))
+        return cls(h.value, 1, device)
+
+    @classmethod
+    def create_great_circle_dev(cls, nx_in, ny_in, xyz_in_t, nx_out, ny_out, xyz_out_t, mean_dlat=0.0, mean_dlon=0.0,
+                                device=0, stream=None, masks_t=None):
+        """Great-circle search on unit vectors already on the device: xyz_in_t[m] = (x, y, z) torch tensors."""
+        L = lib()
+        nt = len(nx_in)
+        nx = (C.c_int * nt)(*nx_in)
+        ny = (C.c_int * nt)(*ny_in)
+        xs = (C.c_void_p * nt)(*[t[0].data_ptr() for t in xyz_in_t])
+        ys = (C.c_void_p * nt)(*[t[1].data_ptr() for t in xyz_in_t])
+        zs = (C.c_void_p * nt)(*[t[2].data_ptr() for t in xyz_in_t])
+        msk = None
+        if masks_t is not None:
+            msk = (C.c_void_p * nt)(*[(t.data_ptr() if t is not None else None) for t in masks_t])
+        h = C.c_void_p()
+        use = 0 if stream is None else 1
+        sptr = C.c_void_p(0 if stream is None else int(stream))
+        check(L.fg_plan_create_great_circle_dev(nt, nx, ny, xs, ys, zs, msk, nx_out, ny_out,
+                                                C.c_void_p(xyz_out_t[0].data_ptr()), C.c_void_p(xyz_out_t[1].data_ptr()),
+                                                C.c_void_p(xyz_out_t[2].data_ptr()), float(mean_dlat), float(mean_dlon),
+                                                device, sptr, use, C.byref(h)))
+        return cls(h.value, 1, device)
 
     @classmethod
     def create_empty(cls, order, nx_in, ny_in, nx_out, ny_out, device=0):
@@ -353,8 +406,14 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
         print("NOTE: Finish reading index and weight for conservative interpolation from file.")   # :125
         return interp
     plans = []
+    great_circle = bool(opcode & GREAT_CIRCLE)
+    if great_circle and order != 1:
+        raise ValueError("fregrid: when clip_method is 'conserve_great_circle', interp_method must be 'conserve_order1'")  # fregrid.c:763
     for n in range(ntiles_out):
-        plans.append(XgridPlan.create(order, grid_in[:ntiles_in], grid_out[n], device=device))
+        if great_circle:                                               # conserve_interp.c:164-168 (whole tiles, no row trim)
+            plans.append(XgridPlan.create_great_circle(grid_in[:ntiles_in], grid_out[n], device=device))
+        else:
+            plans.append(XgridPlan.create(order, grid_in[:ntiles_in], grid_out[n], device=device))
     # cell areas (fregrid_util.c:363-408) come for free from the search
     for n in range(ntiles_out):
         a_in, a_out = plans[n].get_cell_area(grid_out[n].nx * grid_out[n].ny)

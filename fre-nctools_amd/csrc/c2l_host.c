@@ -316,3 +316,45 @@ int fg_halo_map(int ntiles, const int *nx, const int *ny, int ncontacts, const i
   free(tile); free(is); free(ie); free(js); free(je); free(dir);
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------ latlon2xyz
+ * mosaic_util.c:212-222 for the great-circle search: the corner unit vectors must be the reference's bit for bit
+ * (the great-circle areas amplify a last-place difference in a coordinate to ~1e-8 relative at C768), so they are
+ * taken with the host's libm -- the same five calls per point -- and uploaded; O(vertices), split over threads. */
+#include <pthread.h>
+#include <unistd.h>
+typedef struct { size_t b, e; const double *lon, *lat; double *x, *y, *z; } Ll2Job;
+static void *ll2_worker(void *arg)
+{
+  Ll2Job *j = (Ll2Job *)arg;
+  for (size_t n = j->b; n < j->e; n++) {
+    j->x[n] = cos_sep(j->lat[n]) * cos_sep(j->lon[n]);
+    j->y[n] = cos_sep(j->lat[n]) * sin_sep(j->lon[n]);
+    j->z[n] = sin_sep(j->lat[n]);
+  }
+  return NULL;
+}
+void fg_latlon2xyz(long size, const double *lon, const double *lat, double *x, double *y, double *z)
+{
+  if (size <= 0) return;
+  long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+  int nt = (int)(size / 32768);
+  if (nt > ncpu) nt = (int)ncpu;
+  if (nt > 32) nt = 32;
+  if (nt < 1) nt = 1;
+  Ll2Job jobs[32];
+  pthread_t th[32];
+  int started[32];
+  size_t chunk = ((size_t)size + nt - 1) / nt;
+  for (int k = 0; k < nt; k++) {
+    size_t b = (size_t)k * chunk, e = b + chunk;
+    if (b > (size_t)size) b = (size_t)size;
+    if (e > (size_t)size) e = (size_t)size;
+    jobs[k].b = b; jobs[k].e = e;
+    jobs[k].lon = lon; jobs[k].lat = lat; jobs[k].x = x; jobs[k].y = y; jobs[k].z = z;
+    started[k] = 0;
+    if (k > 0) started[k] = (pthread_create(&th[k], NULL, ll2_worker, &jobs[k]) == 0);
+  }
+  ll2_worker(&jobs[0]);
+  for (int k = 1; k < nt; k++) { if (started[k]) pthread_join(th[k], NULL); else ll2_worker(&jobs[k]); }
+}

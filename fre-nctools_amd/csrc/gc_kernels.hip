@@ -1,0 +1,547 @@
+// gc_kernels.hip -- great-circle exchange-grid search for gfx950 (MI355X).
+//
+// create_xgrid_great_circle (tools/libfrencutils/create_xgrid.c:1366-1466) clips every (source cell, destination
+// cell) pair with clip_2dx2d_great_circle (:1479-1908): cell edges are great-circle arcs, vertices are unit vectors,
+// the intersection parameters are solved in x87 extended precision (mosaic_util.c:967-1044) and the exchange-cell
+// area is the spherical excess from acosl angles (mosaic_util.c:763-838).  Here:
+//
+//   k_gc_cell_struct   per cell: the four corners as xyz (clockwise), the great-circle cell area
+//                      [get_grid_great_circle_area, create_xgrid.c:98-137], a bounding cap (centre, cos radius) and
+//                      the cap's lat/lon box -- the box feeds the SAME binning / candidate kernels as the legacy path
+//                      (xgrid_kernels.hip), which therefore emit a superset of the pairs whose caps touch
+//   k_gc_clip          one lane per candidate pair: the reference's xyz bounding-box reject (RANGE_CHECK_CRITERIA),
+//                      a cap-separation reject that is provably "n_out == 0" (DESIGN.md), then the reference's clip
+//                      on small per-lane ordered arrays (the linked Node pool of mosaic_util.c:1046-1541 restated
+//                      as arrays), area, and the 1e-6 area-ratio test
+//
+// Bit-faithfulness: every double operation has the reference's expression tree (-ffp-contract=off); the extended
+// precision solve runs on the software x87 of fp80.h; acosl is fp80.h's fg_acosl.  Compaction into the canonical
+// order (source cell, destination index) is the legacy path's k_scatter_xcells.
+#include "xgrid_device.h"
+#include "fp80.h"
+
+#define GC_EPSLN8 (1.e-8)
+#define GC_EPSLN10 (1.e-10)
+#define GC_EPSLN30 (1.e-30)
+#define GC_RANGE_CHECK 0.05
+#define GC_RADIUS 6371000.0
+#define GC_PI 3.14159265358979323846
+#define GC_NCAP 14          // nodes per grid list: 4 corners + at most 8 intersections (convex x convex) + slack
+#define GC_ICAP 12          // intersection list
+#define GC_PCAP 16          // output polygon
+
+struct GcNode { double x, y, z, u; int intersect, inbound, inside, pad; };
+struct GcInter { double x, y, z, u, u_clip; int subj_index, clip_index, inbound, pad; };
+struct GcList { int n; GcNode v[GC_NCAP]; };
+
+__device__ __forceinline__ bool gc_same_point(double x1, double y1, double z1, double x2, double y2, double z2)
+{
+  return !(fabs(x1 - x2) > GC_EPSLN10 || fabs(y1 - y2) > GC_EPSLN10 || fabs(z1 - z2) > GC_EPSLN10);
+}
+
+// spherical_angle, mosaic_util.c:799-836 (double branch); EXACT selects the reference-exact acosl
+template <bool EXACT>
+__device__ double gc_spherical_angle(const double *v1, const double *v2, const double *v3)
+{
+  double angle, px, py, pz, qx, qy, qz, ddd;
+  px = v1[1] * v2[2] - v1[2] * v2[1];
+  py = v1[2] * v2[0] - v1[0] * v2[2];
+  pz = v1[0] * v2[1] - v1[1] * v2[0];
+  qx = v1[1] * v3[2] - v1[2] * v3[1];
+  qy = v1[2] * v3[0] - v1[0] * v3[2];
+  qz = v1[0] * v3[1] - v1[1] * v3[0];
+  ddd = (px * px + py * py + pz * pz) * (qx * qx + qy * qy + qz * qz);
+  if (ddd <= 0.0) angle = 0.;
+  else {
+    ddd = (px * qx + py * qy + pz * qz) / sqrt(ddd);
+    if (fabs(ddd - 1) < GC_EPSLN30) ddd = 1;
+    if (fabs(ddd + 1) < GC_EPSLN30) ddd = -1;
+    if (ddd > 1. || ddd < -1.) {
+      if (ddd < 0.) angle = GC_PI;
+      else angle = 0.;
+    } else
+      angle = EXACT ? fg_acosl(ddd) : acos(ddd);
+  }
+  return angle;
+}
+
+// great_circle_area, mosaic_util.c:763-787, on a polygon given as strided xyz
+__device__ double gc_area(int n, const double *p, int stride)
+{
+  double sum = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double *p0 = p + (size_t)i * stride, *p1 = p + (size_t)((i + 1) % n) * stride, *p2 = p + (size_t)((i + 2) % n) * stride;
+    sum += gc_spherical_angle<true>(p1, p2, p0);
+  }
+  return (sum - (n - 2.) * GC_PI) * GC_RADIUS * GC_RADIUS;
+}
+
+// insidePolygon, mosaic_util.c:1546-1589.  The angle sum is only compared with 2*pi to 1e-8, so it is taken with the
+// fast acos first and redone with the exact one only if it lands within 1e-12 of the threshold.
+__device__ int gc_inside_polygon(const GcNode &node, const GcList &l)
+{
+  const double pnt0[3] = {node.x, node.y, node.z};
+  double anglesum = 0;
+  for (int k = 0; k < l.n; k++) {
+    const int kn = (k + 1 < l.n) ? k + 1 : 0;
+    const double pnt1[3] = {l.v[k].x, l.v[k].y, l.v[k].z}, pnt2[3] = {l.v[kn].x, l.v[kn].y, l.v[kn].z};
+    if (gc_same_point(pnt0[0], pnt0[1], pnt0[2], pnt1[0], pnt1[1], pnt1[2])) return 1;
+    anglesum += gc_spherical_angle<false>(pnt0, pnt2, pnt1);
+  }
+  double dev = fabs(anglesum - 2 * GC_PI);
+  if (fabs(dev - GC_EPSLN8) < 1.e-12) {
+    anglesum = 0;
+    for (int k = 0; k < l.n; k++) {
+      const int kn = (k + 1 < l.n) ? k + 1 : 0;
+      const double pnt1[3] = {l.v[k].x, l.v[k].y, l.v[k].z}, pnt2[3] = {l.v[kn].x, l.v[kn].y, l.v[kn].z};
+      anglesum += gc_spherical_angle<true>(pnt0, pnt2, pnt1);
+    }
+    dev = fabs(anglesum - 2 * GC_PI);
+  }
+  return dev < GC_EPSLN8;
+}
+
+// intersect_tri_with_line + invert_matrix_3x3 + mult (mosaic_util.c:967-1044) on the software x87; the third plane
+// point is the origin.  Only t = X[0] is consumed by line_intersect_2D_3D.
+__device__ bool gc_tri_line_t(const double *pnt0, const double *pnt1, const double *l1, const double *l2, double *t)
+{
+  const x80 m0 = x80_from_double(l1[0] - l2[0]), m1 = x80_from_double(pnt1[0] - pnt0[0]), m2 = x80_from_double(0.0 - pnt0[0]);
+  const x80 m3 = x80_from_double(l1[1] - l2[1]), m4 = x80_from_double(pnt1[1] - pnt0[1]), m5 = x80_from_double(0.0 - pnt0[1]);
+  const x80 m6 = x80_from_double(l1[2] - l2[2]), m7 = x80_from_double(pnt1[2] - pnt0[2]), m8 = x80_from_double(0.0 - pnt0[2]);
+  const x80 c0 = x80_sub(x80_mul(m4, m8), x80_mul(m5, m7));
+  const x80 c1 = x80_sub(x80_mul(m3, m8), x80_mul(m5, m6));
+  const x80 c2 = x80_sub(x80_mul(m3, m7), x80_mul(m4, m6));
+  const x80 det = x80_add(x80_sub(x80_mul(m0, c0), x80_mul(m1, c1)), x80_mul(m2, c2));
+  if (x80_abs_lt(det, x80_from_double(1.e-15))) return false;
+  const x80 deti = x80_div(x80_from_double(1.0), det);
+  const x80 inv0 = x80_mul(c0, deti);
+  const x80 inv1 = x80_mul(x80_sub(x80_mul(m2, m7), x80_mul(m1, m8)), deti);
+  const x80 inv2 = x80_mul(x80_sub(x80_mul(m1, m5), x80_mul(m2, m4)), deti);
+  const x80 V0 = x80_from_double(l1[0] - pnt0[0]), V1 = x80_from_double(l1[1] - pnt0[1]), V2 = x80_from_double(l1[2] - pnt0[2]);
+  *t = x80_to_double(x80_add(x80_add(x80_mul(inv0, V0), x80_mul(inv1, V1)), x80_mul(inv2, V2)));
+  return true;
+}
+
+__device__ __forceinline__ void gc_cross(const double *p1, const double *p2, double *e)
+{
+  e[0] = p1[1] * p2[2] - p1[2] * p2[1];
+  e[1] = p1[2] * p2[0] - p1[0] * p2[2];
+  e[2] = p1[0] * p2[1] - p1[1] * p2[0];
+}
+__device__ __forceinline__ double gc_metric(const double *p) { return sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]); }
+
+// line_intersect_2D_3D, create_xgrid.c:1919-2081
+__device__ int gc_line_intersect(const double *a1, const double *a2, const double *q1, const double *q2, const double *q3,
+                                 double *I, double *u_a, double *u_q, int *inbound)
+{
+  *inbound = 0;
+  if (gc_same_point(a1[0], a1[1], a1[2], q1[0], q1[1], q1[2])) { *u_a = 0; *u_q = 0; I[0] = a1[0]; I[1] = a1[1]; I[2] = a1[2]; return 1; }
+  else if (gc_same_point(a1[0], a1[1], a1[2], q2[0], q2[1], q2[2])) { *u_a = 0; *u_q = 1; I[0] = a1[0]; I[1] = a1[1]; I[2] = a1[2]; return 1; }
+  else if (gc_same_point(a2[0], a2[1], a2[2], q1[0], q1[1], q1[2])) { *u_a = 1; *u_q = 0; I[0] = a2[0]; I[1] = a2[1]; I[2] = a2[2]; return 1; }
+  else if (gc_same_point(a2[0], a2[1], a2[2], q2[0], q2[1], q2[2])) { *u_a = 1; *u_q = 1; I[0] = a2[0]; I[1] = a2[1]; I[2] = a2[2]; return 1; }
+  if (!gc_tri_line_t(q1, q2, a1, a2, u_a)) return 0;
+  if (fabs(*u_a) < GC_EPSLN8) *u_a = 0;
+  if (fabs(*u_a - 1) < GC_EPSLN8) *u_a = 1;
+  if ((*u_a < 0) || (*u_a > 1)) return 0;
+  if (!gc_tri_line_t(a1, a2, q1, q2, u_q)) return 0;
+  if (fabs(*u_q) < GC_EPSLN8) *u_q = 0;
+  if (fabs(*u_q - 1) < GC_EPSLN8) *u_q = 1;
+  if ((*u_q < 0) || (*u_q > 1)) return 0;
+  const double u = *u_a;
+  double c1[3], c2[3], c3[3];
+  gc_cross(a1, a2, c1);
+  gc_cross(q1, q2, c2);
+  gc_cross(c1, c2, c3);
+  const double coincident = gc_metric(c3);
+  if (fabs(coincident) < GC_EPSLN30) return 0;
+  I[0] = a1[0] + u * (a2[0] - a1[0]);
+  I[1] = a1[1] + u * (a2[1] - a1[1]);
+  I[2] = a1[2] + u * (a2[2] - a1[2]);
+  const double norm = gc_metric(I);
+  I[0] /= norm; I[1] /= norm; I[2] /= norm;
+  if (*u_q != 0 && *u_q != 1) {
+    const double p1[3] = {a2[0] - a1[0], a2[1] - a1[1], a2[2] - a1[2]};
+    const double v1[3] = {q2[0] - q1[0], q2[1] - q1[1], q2[2] - q1[2]};
+    const double v2[3] = {q3[0] - q2[0], q3[1] - q2[1], q3[2] - q2[2]};
+    gc_cross(v1, v2, c1);
+    gc_cross(v1, p1, c2);
+    const double sense = c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2];
+    *inbound = 1;
+    if (sense > 0) *inbound = 2;
+  }
+  return 1;
+}
+
+// addEnd (mosaic_util.c:1096-1135) on a grid list: append unless a point within 1e-10 is present
+__device__ int gc_add_end(GcList &l, double x, double y, double z, int intersect, double u, int inbound, int inside)
+{
+  for (int k = 0; k < l.n; k++) if (gc_same_point(l.v[k].x, l.v[k].y, l.v[k].z, x, y, z)) return 0;
+  if (l.n >= GC_NCAP) return -9;
+  GcNode &t = l.v[l.n++];
+  t.x = x; t.y = y; t.z = z; t.u = u; t.intersect = intersect; t.inbound = inbound; t.inside = inside; t.pad = 0;
+  return 0;
+}
+
+// insertIntersect, mosaic_util.c:1313-1397
+__device__ int gc_insert_intersect(GcList &l, double x, double y, double z, double u1, double u2, int inbound,
+                                   double x2, double y2, double z2)
+{
+  int k1 = -1;
+  for (int k = 0; k < l.n; k++) if (l.v[k].x == x2 && l.v[k].y == y2 && l.v[k].z == z2) { k1 = k; break; }
+  if (k1 < 0) return -7;
+  double u_cur = u1;
+  if (u1 == 1) { u_cur = 0; k1 = (k1 + 1 < l.n) ? k1 + 1 : 0; }
+  if (u_cur == 0) {
+    GcNode &t = l.v[k1];
+    t.intersect = 2; t.inside = 1; t.u = u_cur; t.x = x; t.y = y; t.z = z;
+    return 0;
+  }
+  if (u2 != 0 && u2 != 1) {
+    if (inbound == 1) {
+      int k2 = (k1 + 1 < l.n) ? k1 + 1 : 0, guard = 0;
+      while (l.v[k2].intersect) { k2 = (k2 + 1 < l.n) ? k2 + 1 : 0; if (++guard > 2 * GC_NCAP) return -7; }
+      l.v[k2].inside = 0;
+    } else if (inbound == 2)
+      l.v[k1].inside = 0;
+  }
+  int k2 = k1 + 1;
+  while (k2 < l.n) {
+    if (l.v[k2].intersect == 1) { if (l.v[k2].u > u_cur) break; }
+    else break;
+    k1 = k2; k2++;
+  }
+  if (l.n >= GC_NCAP) return -9;
+  for (int k = l.n; k > k2; k--) l.v[k] = l.v[k - 1];
+  l.n++;
+  GcNode &t = l.v[k2];
+  t.x = x; t.y = y; t.z = z; t.u = u_cur; t.intersect = 1; t.inbound = inbound; t.inside = 1; t.pad = 0;
+  return 0;
+}
+
+__device__ __forceinline__ int gc_find(const GcList &l, double x, double y, double z)
+{
+  for (int k = 0; k < l.n; k++) if (l.v[k].x == x && l.v[k].y == y && l.v[k].z == z) return k;
+  return -1;
+}
+
+// polyList: addNode -> addEnd (dedup within 1e-10)
+struct GcPoly { int n; double p[GC_PCAP][3]; };
+__device__ int gc_poly_add(GcPoly &pl, double x, double y, double z)
+{
+  for (int k = 0; k < pl.n; k++) if (gc_same_point(pl.p[k][0], pl.p[k][1], pl.p[k][2], x, y, z)) return 0;
+  if (pl.n >= GC_PCAP) return -9;
+  pl.p[pl.n][0] = x; pl.p[pl.n][1] = y; pl.p[pl.n][2] = z; pl.n++;
+  return 0;
+}
+
+// clip_2dx2d_great_circle (create_xgrid.c:1479-1908) after its bounding-box rejects.  a, b: the four corners of the
+// two cells, [k*3 + axis].  Returns n_out (vertices in out) or a negative error code (see oracle/gc_oracle.c).
+__device__ int gc_clip(const double *a, const double *b, GcPoly &out)
+{
+  GcList g1, g2;
+  GcInter il[GC_ICAP];
+  int nil = 0;
+  g1.n = g2.n = 0; out.n = 0;
+  for (int i = 0; i < 4; i++) if (gc_add_end(g1, a[i * 3], a[i * 3 + 1], a[i * 3 + 2], 0, 0, 0, -1)) return -9;
+  for (int i = 0; i < 4; i++) if (gc_add_end(g2, b[i * 3], b[i * 3 + 1], b[i * 3 + 2], 0, 0, 0, -1)) return -9;
+  const int npts1 = g1.n, npts2 = g2.n;
+  for (int k = 0; k < g1.n; k++) g1.v[k].inside = gc_inside_polygon(g1.v[k], g2);
+  for (int k = 0; k < g2.n; k++) g2.v[k].inside = gc_inside_polygon(g2.v[k], g1);
+
+  double pt1[4][3], pt2[4][3];
+  for (int i = 0; i < npts1; i++) { pt1[i][0] = g1.v[i].x; pt1[i][1] = g1.v[i].y; pt1[i][2] = g1.v[i].z; }
+  for (int i = 0; i < npts2; i++) { pt2[i][0] = g2.v[i].x; pt2[i][1] = g2.v[i].y; pt2[i][2] = g2.v[i].z; }
+
+  for (int i1 = 0; i1 < npts1; i1++) {
+    const int i1p = (i1 + 1) % npts1;
+    double *p1_0 = pt1[i1], *p1_1 = pt1[i1p];
+    for (int i2 = 0; i2 < npts2; i2++) {
+      const int i2p = (i2 + 1) % npts2, i2p2 = (i2 + 2) % npts2;
+      double *p2_0 = pt2[i2], *p2_1 = pt2[i2p], *p2_2 = pt2[i2p2], I[3], u1, u2;
+      int inbound;
+      if (!gc_line_intersect(p1_0, p1_1, p2_0, p2_1, p2_2, I, &u1, &u2, &inbound)) continue;
+      // addIntersect, mosaic_util.c:1139-1190
+      double u1c = u1, u2c = u2;
+      int i1c = i1, i2c = i2;
+      if (u1c == 1) { u1c = 0; i1c = i1p; }
+      if (u2c == 1) { u2c = 0; i2c = i2p; }
+      bool dup = false;
+      for (int k = 0; k < nil; k++) {
+        if (il[k].u == u1c && il[k].subj_index == i1c) { dup = true; break; }
+        if (il[k].u_clip == u2c && il[k].clip_index == i2c) { dup = true; break; }
+      }
+      if (dup) continue;
+      if (nil >= GC_ICAP) return -9;
+      GcInter &t = il[nil++];
+      t.x = I[0]; t.y = I[1]; t.z = I[2]; t.u = u1c; t.u_clip = u2c; t.subj_index = i1c; t.clip_index = i2c; t.inbound = inbound; t.pad = 0;
+      int rc;
+      if (u1 == 1) rc = gc_insert_intersect(g1, I[0], I[1], I[2], 0.0, u2, inbound, p1_1[0], p1_1[1], p1_1[2]);
+      else rc = gc_insert_intersect(g1, I[0], I[1], I[2], u1, u2, inbound, p1_0[0], p1_0[1], p1_0[2]);
+      if (rc) return rc;
+      if (u1 == 1) { p1_1[0] = I[0]; p1_1[1] = I[1]; p1_1[2] = I[2]; }
+      else if (u1 == 0) { p1_0[0] = I[0]; p1_0[1] = I[1]; p1_0[2] = I[2]; }
+      if (u2 == 1) rc = gc_insert_intersect(g2, I[0], I[1], I[2], 0.0, u1, 0, p2_1[0], p2_1[1], p2_1[2]);
+      else rc = gc_insert_intersect(g2, I[0], I[1], I[2], u2, u1, 0, p2_0[0], p2_0[1], p2_0[2]);
+      if (rc) return rc;
+      if (u2 == 1) { p2_1[0] = I[0]; p2_1[1] = I[1]; p2_1[2] = I[2]; }
+      else if (u2 == 0) { p2_0[0] = I[0]; p2_0[1] = I[1]; p2_0[2] = I[2]; }
+    }
+  }
+
+  // first inbound intersection (getFirstInbound / setInbound, mosaic_util.c:1448-1535)
+  int nintersect = nil, first = -1;
+  if (nintersect > 1) for (int k = 0; k < nil; k++) if (il[k].inbound == 2) { first = k; break; }
+  if (first < 0 && nintersect > 1) {
+    for (int k = 0; k < nil; k++) {
+      if (il[k].inbound) continue;
+      const int f = gc_find(g1, il[k].x, il[k].y, il[k].z);
+      if (f < 0) return -8;
+      const GcNode &prev = g1.v[f > 0 ? f - 1 : g1.n - 1], &next = g1.v[f + 1 < g1.n ? f + 1 : 0];
+      il[k].inbound = (prev.inside == 0 && next.inside == 1) ? 2 : 1;
+    }
+    for (int k = 0; k < nil; k++) if (il[k].inbound == 2) { first = k; break; }
+  }
+
+  int n_out = 0;
+  if (first >= 0) {
+    const double fx = il[first].x, fy = il[first].y, fz = il[first].z;
+    const int maxiter1 = nintersect;
+    if (gc_find(g1, fx, fy, fz) < 0) return -3;
+    if (gc_poly_add(out, fx, fy, fz)) return -9;
+    nintersect--;
+    GcList *curl = &g1;
+    int cur_num = 0, iter1 = 0, found1 = 0, found2 = 0;
+    double cx = fx, cy = fy, cz = fz;
+    while (iter1 < maxiter1) {
+      const int k1 = gc_find(*curl, cx, cy, cz);
+      if (k1 < 0) return -4;
+      int k2 = (k1 + 1 < curl->n) ? k1 + 1 : 0;
+      const int maxiter2 = curl->n;
+      int iter2 = 0;
+      found2 = 0;
+      while (iter2 < maxiter2) {
+        int t2_is_inter = 0;
+        const GcNode &t2 = curl->v[k2];
+        if (t2.intersect) {
+          if (t2.x == fx && t2.y == fy && t2.z == fz) { found1 = 1; break; }
+          const GcNode &t3 = curl->v[(k2 + 1 < curl->n) ? k2 + 1 : 0];
+          found2 = 1;
+          t2_is_inter = 1;
+          if (t3.intersect || (t3.inside == 1)) found2 = 0;
+        }
+        if (found2) { cx = t2.x; cy = t2.y; cz = t2.z; break; }
+        else {
+          if (gc_poly_add(out, t2.x, t2.y, t2.z)) return -9;
+          if (t2_is_inter) nintersect--;
+        }
+        k2 = (k2 + 1 < curl->n) ? k2 + 1 : 0;
+        iter2++;
+      }
+      if (found1) break;
+      if (!found2) return -4;
+      if (cx == fx && cy == fy && cz == fz) { found1 = 1; break; }
+      if (gc_poly_add(out, cx, cy, cz)) return -9;
+      nintersect--;
+      if (cur_num == 0) { curl = &g2; cur_num = 1; }
+      else { curl = &g1; cur_num = 0; }
+      iter1++;
+    }
+    if (!found1) return -5;
+    if (nintersect > 0) return -6;
+    n_out = out.n;
+    if (n_out < 3) n_out = 0;
+  }
+  if (n_out == 0) {                                   // grid1 inside grid2, :1839-1870
+    int n1in2 = 0;
+    for (int k = 0; k < g1.n; k++) if (g1.v[k].intersect != 1 && g1.v[k].inside == 1) n1in2++;
+    if (npts1 == n1in2) {
+      n_out = npts1;
+      for (int k = 0; k < npts1; k++) { out.p[k][0] = g1.v[k].x; out.p[k][1] = g1.v[k].y; out.p[k][2] = g1.v[k].z; }
+    }
+    if (n_out > 0) { out.n = n_out; return n_out; }
+  }
+  if (n_out == 0) {                                   // grid2 inside grid1, :1873-1904
+    int n2in1 = 0;
+    for (int k = 0; k < g2.n; k++) if (g2.v[k].intersect != 1 && g2.v[k].inside == 1) n2in1++;
+    if (npts2 == n2in1) {
+      n_out = npts2;
+      for (int k = 0; k < npts2; k++) { out.p[k][0] = g2.v[k].x; out.p[k][1] = g2.v[k].y; out.p[k][2] = g2.v[k].z; }
+    }
+  }
+  out.n = n_out;
+  return n_out;
+}
+
+// ------------------------------------------------------------------------------------------------ cell records
+// FgCells reuse: verts[c*16 + 0..11] = corners xyz (clockwise), [12..14] = cap centre, [15] = cos(cap radius), or -2
+// when the cell is too large for a useful cap.  lat/lon box = the cap's, so the candidate scan is a superset.
+#define GC_CAP_MARGIN 2.e-6
+__global__ __launch_bounds__(256) void k_gc_cell_struct(const FgTileXyz *tiles, int ntiles, int ncells, FgCells c)
+{
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ncells) return;
+  int t = 0;
+  while (t + 1 < ntiles && s >= tiles[t + 1].cell_off) t++;
+  const FgTileXyz T = tiles[t];
+  const int loc = s - T.cell_off, i = loc % T.nx, j = loc / T.nx, nxp = T.nx + 1;
+  const int idx[4] = {j * nxp + i, (j + 1) * nxp + i, (j + 1) * nxp + i + 1, j * nxp + i + 1};   // clockwise, create_xgrid.c:1413-1420
+  double v[12];
+  for (int k = 0; k < 4; k++) { v[k * 3] = T.x[idx[k]]; v[k * 3 + 1] = T.y[idx[k]]; v[k * 3 + 2] = T.z[idx[k]]; }
+  double *o = c.verts + (size_t)s * 16;
+  for (int k = 0; k < 12; k++) o[k] = v[k];
+  // cell area on the de-duplicated vertex list (addEnd merges the two pole corners of a lat-lon cap cell)
+  double p[12]; int n = 0;
+  for (int k = 0; k < 4; k++) {
+    bool dup = false;
+    for (int m = 0; m < n; m++) if (gc_same_point(p[m * 3], p[m * 3 + 1], p[m * 3 + 2], v[k * 3], v[k * 3 + 1], v[k * 3 + 2])) dup = true;
+    if (!dup) { p[n * 3] = v[k * 3]; p[n * 3 + 1] = v[k * 3 + 1]; p[n * 3 + 2] = v[k * 3 + 2]; n++; }
+  }
+  c.area[s] = gc_area(n, p, 3);
+  c.nv[s] = 4;
+  // bounding cap
+  double cx = v[0] + v[3] + v[6] + v[9], cy = v[1] + v[4] + v[7] + v[10], cz = v[2] + v[5] + v[8] + v[11];
+  const double nrm = sqrt(cx * cx + cy * cy + cz * cz);
+  bool nocap = !(nrm > 1.e-3);
+  double r = 0;
+  if (!nocap) {
+    cx /= nrm; cy /= nrm; cz /= nrm;
+    for (int k = 0; k < 4; k++) {
+      double d = cx * v[k * 3] + cy * v[k * 3 + 1] + cz * v[k * 3 + 2];
+      d = fmin(1.0, fmax(-1.0, d));
+      // acos loses accuracy near 1: use the chord for small separations
+      const double ex = v[k * 3] - cx, ey = v[k * 3 + 1] - cy, ez = v[k * 3 + 2] - cz;
+      const double chord = sqrt(ex * ex + ey * ey + ez * ez);
+      const double ang = (chord < 0.5) ? 2.0 * asin(0.5 * chord) : acos(d);
+      r = fmax(r, ang);
+    }
+    r = r * (1.0 + 1.e-9) + GC_CAP_MARGIN;
+    if (r > 0.5) nocap = true;
+  }
+  const double hpi = 0.5 * GC_PI, tpi = 2.0 * GC_PI;
+  if (nocap) {
+    o[12] = 0; o[13] = 0; o[14] = 1; o[15] = -2.0;
+    c.lat_min[s] = -hpi; c.lat_max[s] = hpi; c.lon_min[s] = 0.0; c.lon_max[s] = tpi; c.lon_avg[s] = GC_PI;
+    return;
+  }
+  o[12] = cx; o[13] = cy; o[14] = cz; o[15] = cos(r);
+  const double latc = asin(fmin(1.0, fmax(-1.0, cz)));
+  double lonc = atan2(cy, cx);
+  if (lonc < 0) lonc += tpi;
+  c.lat_min[s] = fmax(-hpi, latc - r);
+  c.lat_max[s] = fmin(hpi, latc + r);
+  if (fabs(latc) + r >= hpi - 1.e-6) { c.lon_min[s] = 0.0; c.lon_max[s] = tpi; c.lon_avg[s] = GC_PI; }
+  else {
+    const double w = asin(fmin(1.0, sin(r) / cos(latc))) * (1.0 + 1.e-9) + 1.e-9;
+    c.lon_min[s] = lonc - w; c.lon_max[s] = lonc + w; c.lon_avg[s] = lonc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pair kernel
+__global__ __launch_bounds__(64) void k_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask,
+                                                 FgCells D, double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  const int s = pair_src[p], d = pair_dst[p];
+  const double *a = S.verts + (size_t)s * 16, *b = D.verts + (size_t)d * 16;
+  // create_xgrid.c:1508-1528
+  bool far = false;
+  for (int ax = 0; ax < 3 && !far; ax++) {
+    double mn1 = a[ax], mx1 = a[ax], mn2 = b[ax], mx2 = b[ax];
+    for (int k = 1; k < 4; k++) {
+      mn1 = fmin(mn1, a[k * 3 + ax]); mx1 = fmax(mx1, a[k * 3 + ax]);
+      mn2 = fmin(mn2, b[k * 3 + ax]); mx2 = fmax(mx2, b[k * 3 + ax]);
+    }
+    if (mn1 >= mx2 + GC_RANGE_CHECK || mn2 >= mx1 + GC_RANGE_CHECK) far = true;
+  }
+  if (far) { pair_dst[p] = -1; return; }
+  const double area1 = S.area[s], area2 = D.area[d];
+  if (area1 <= 0) atomicOr(err, G_ERRBIT_GC_CONVEX1);         // :1575-1578 (fatal in the reference)
+  if (area2 <= 0) atomicOr(err, G_ERRBIT_GC_CONVEX2);
+  if (area1 <= 0 || area2 <= 0) { pair_dst[p] = -1; return; }
+  // caps further apart than the sum of their radii (+2e-6 rad each): no vertex inside, no edge crossing
+  if (a[15] > -1.5 && b[15] > -1.5) {
+    const double dotc = a[12] * b[12] + a[13] * b[13] + a[14] * b[14];
+    const double sr1 = sqrt(fmax(0.0, 1.0 - a[15] * a[15])), sr2 = sqrt(fmax(0.0, 1.0 - b[15] * b[15]));
+    const double cos_sum = a[15] * b[15] - sr1 * sr2;
+    if (dotc < cos_sum - 1.e-12) { pair_dst[p] = -1; return; }
+  }
+  GcPoly out;
+  const int n_out = gc_clip(a, b, out);
+  if (n_out < 0) { atomicOr(err, G_ERRBIT_GC_CLIP); atomicMax((int *)(err + 1), -n_out); pair_dst[p] = -1; return; }
+  if (n_out == 0) { pair_dst[p] = -1; return; }
+  const double m = mask ? mask[s] : 1.0;
+  const double xarea = gc_area(n_out, &out.p[0][0], 3) * m;
+  const double min_area = (area1 < area2) ? area1 : area2;
+  const double ratio = xarea / min_area;
+  if (fabs(ratio - 1.e-6) < 1.e-12) atomicAdd(&stats[FG_STAT_BORDERLINE], 1ull);
+  if (ratio > 1.e-6) { tmp_area[p] = xarea; atomicAdd(&nacc[s], 1); }
+  else { pair_dst[p] = -1; atomicAdd(&stats[FG_STAT_BELOW], 1ull); }
+}
+
+static inline int gc_nblk(long n, int t) { return (int)((n + t - 1) / t); }
+
+void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st)
+{
+  if (ncells > 0) k_gc_cell_struct<<<gc_nblk(ncells, 256), 256, 0, st>>>(tiles_dev, ntiles, ncells, c);
+}
+
+void fgd_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
+                 double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err, hipStream_t st)
+{
+  if (npairs > 0) k_gc_clip<<<gc_nblk(npairs, 64), 64, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, nacc, stats, err);
+}
+
+// ------------------------------------------------------------------------------------------------ batch primitives
+// clip_2dx2d_great_circle / great_circle_area on arrays of polygons (B1 mirrors and tests): one lane per polygon pair
+__global__ __launch_bounds__(64) void k_gc_clip_batch(int n, const double *a, const double *b, double *out, int *n_out, double *area)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double *pa = a + (size_t)p * 12, *pb = b + (size_t)p * 12;
+  bool far = false;
+  for (int ax = 0; ax < 3 && !far; ax++) {
+    double mn1 = pa[ax], mx1 = pa[ax], mn2 = pb[ax], mx2 = pb[ax];
+    for (int k = 1; k < 4; k++) {
+      mn1 = fmin(mn1, pa[k * 3 + ax]); mx1 = fmax(mx1, pa[k * 3 + ax]);
+      mn2 = fmin(mn2, pb[k * 3 + ax]); mx2 = fmax(mx2, pb[k * 3 + ax]);
+    }
+    if (mn1 >= mx2 + GC_RANGE_CHECK || mn2 >= mx1 + GC_RANGE_CHECK) far = true;
+  }
+  GcPoly o; o.n = 0;
+  int no = 0;
+  if (!far) {
+    // gridArea of both lists (create_xgrid.c:1575-1578), on the de-duplicated corners
+    for (int which = 0; which < 2 && no == 0; which++) {
+      const double *v = which ? pb : pa;
+      double q[12]; int n = 0;
+      for (int k = 0; k < 4; k++) {
+        bool dup = false;
+        for (int m = 0; m < n; m++) if (gc_same_point(q[m * 3], q[m * 3 + 1], q[m * 3 + 2], v[k * 3], v[k * 3 + 1], v[k * 3 + 2])) dup = true;
+        if (!dup) { q[n * 3] = v[k * 3]; q[n * 3 + 1] = v[k * 3 + 1]; q[n * 3 + 2] = v[k * 3 + 2]; n++; }
+      }
+      if (gc_area(n, q, 3) <= 0) no = which ? -2 : -1;
+    }
+    if (no == 0) no = gc_clip(pa, pb, o);
+  }
+  n_out[p] = no;
+  for (int k = 0; k < GC_PCAP; k++) for (int ax = 0; ax < 3; ax++) out[((size_t)p * GC_PCAP + k) * 3 + ax] = (k < no) ? o.p[k][ax] : 0.0;
+  area[p] = (no > 0) ? gc_area(no, &o.p[0][0], 3) : 0.0;
+}
+
+void fgd_gc_clip_batch(int n, const double *a, const double *b, double *out, int *n_out, double *area, hipStream_t st)
+{
+  if (n > 0) k_gc_clip_batch<<<gc_nblk(n, 64), 64, 0, st>>>(n, a, b, out, n_out, area);
+}
+
+// great_circle_area of polygons given as [npoly][stride_pts][3] with n[npoly] vertices each
+__global__ __launch_bounds__(64) void k_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *n, double *area)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npoly) return;
+  area[p] = gc_area(n[p], xyz + (size_t)p * stride_pts * 3, 3);
+}
+void fgd_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *n, double *area, hipStream_t st)
+{
+  if (npoly > 0) k_gc_area_batch<<<gc_nblk(npoly, 64), 64, 0, st>>>(npoly, stride_pts, xyz, n, area);
+}

@@ -139,6 +139,7 @@ struct fg_plan {
   PhaseTimer apply_pt;
   int apply_spans = 0;
   int order = 0, device = 0;
+  bool great_circle = false;   // exchange cells from create_xgrid_great_circle semantics (order 1 only)
   hipStream_t stream = nullptr;
   bool own_stream = true;
   int ntiles = 0;
@@ -266,10 +267,28 @@ static DevCounters *pinned_counters()
 }
 
 // the search proper; all grid pointers are device pointers
+// Great-circle plans pass the corner unit vectors instead (gc_in[m] = {x, y, z} device pointers of source tile m,
+// gc_out likewise); d_lon/d_lat are then unused.
+struct GcXyz { const double *x, *y, *z; };
+static const char *gc_clip_error(int code)
+{
+  switch (code) {
+    case 3: return "firstIntersect is not in the grid1List";
+    case 4: return " not found the next intersection ";
+    case 5: return "not return back to the first intersection";
+    case 6: return "After clipping, nintersect should be 0";
+    case 7: return "inserAfter: point (x,y,z) is not found in the list";
+    case 8: return "Error from create_xgrid.c: temp is not in list1";
+    default: return "clip_2dx2d_great_circle: more intersections than two convex quadrilaterals can have (list capacity)";
+  }
+}
+
 static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
-                        double mean_dlat, double mean_dlon)
+                        double mean_dlat, double mean_dlon, const GcXyz *gc_in = nullptr, const GcXyz *gc_out = nullptr)
 {
+  const bool gc = gc_in != nullptr;
+  pl->great_circle = gc;
   hipStream_t st = pl->stream;
   const int nsrc = pl->nsrc, ndst = pl->ndst, order = pl->order;
   DevCounters *hc = pinned_counters();
@@ -278,11 +297,21 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   // tile descriptors: source tiles + the destination tile as entry [ntiles]
   std::vector<FgTile> &th = pl->tiles_host;  // owned by the plan: the upload below needs no sync
   th.resize(pl->ntiles + 1);
-  for (int m = 0; m < pl->ntiles; m++) th[m] = FgTile{d_lon_in[m], d_lat_in[m], pl->nx_in[m], pl->ny_in[m], pl->cell_off[m]};
+  for (int m = 0; m < pl->ntiles; m++) th[m] = FgTile{gc ? nullptr : d_lon_in[m], gc ? nullptr : d_lat_in[m], pl->nx_in[m], pl->ny_in[m], pl->cell_off[m]};
   th[pl->ntiles] = FgTile{d_lon_out, d_lat_out, pl->nx_out, pl->ny_out, 0};
   pl->tiles_dev = pl->alloc<FgTile>(pl->ntiles + 1);
   if (!pl->tiles_dev) return fail(FG_ERR_HIP, "out of device memory");
   HIPCHK(hipMemcpyAsync(pl->tiles_dev, th.data(), sizeof(FgTile) * th.size(), hipMemcpyHostToDevice, st));
+  FgTileXyz *gct_dev = nullptr;
+  std::vector<FgTileXyz> gct;                       // must outlive the async upload: synchronised at the first readback
+  if (gc) {
+    gct.resize(pl->ntiles + 1);
+    for (int m = 0; m < pl->ntiles; m++) gct[m] = FgTileXyz{gc_in[m].x, gc_in[m].y, gc_in[m].z, pl->nx_in[m], pl->ny_in[m], pl->cell_off[m]};
+    gct[pl->ntiles] = FgTileXyz{gc_out->x, gc_out->y, gc_out->z, pl->nx_out, pl->ny_out, 0};
+    gct_dev = pl->alloc<FgTileXyz>(pl->ntiles + 1);
+    if (!gct_dev) return fail(FG_ERR_HIP, "out of device memory");
+    HIPCHK(hipMemcpyAsync(gct_dev, gct.data(), sizeof(FgTileXyz) * gct.size(), hipMemcpyHostToDevice, st));
+  }
 
   bool any_mask = false;
   if (d_mask_in) for (int m = 0; m < pl->ntiles; m++) if (d_mask_in[m]) any_mask = true;
@@ -335,8 +364,13 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   for (int k = 0; k < PH_COUNT; k++) pl->phase_ms[k] = 0;
   ptot.begin(PH_SEARCH_TOTAL);
   pt.begin(PH_CELL_STRUCT);
-  fgd_cell_struct(pl->tiles_dev, pl->ntiles, nsrc, pl->S, dc->err, st);
-  fgd_cell_struct(pl->tiles_dev + pl->ntiles, 1, ndst, pl->D, dc->err, st);
+  if (gc) {
+    fgd_gc_cell_struct(gct_dev, pl->ntiles, nsrc, pl->S, st);
+    fgd_gc_cell_struct(gct_dev + pl->ntiles, 1, ndst, pl->D, st);
+  } else {
+    fgd_cell_struct(pl->tiles_dev, pl->ntiles, nsrc, pl->S, dc->err, st);
+    fgd_cell_struct(pl->tiles_dev + pl->ntiles, 1, ndst, pl->D, dc->err, st);
+  }
   pt.end();
   pl->have_geom = true;
 
@@ -377,14 +411,20 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pt.end();
 
   // --- clip, area, centroid integrals (+ accepted count per source cell)
-  pt.begin(PH_CLIP_QUAD);
-  fgd_clip_quad(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-                nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
-  pt.end();
-  pt.begin(PH_CLIP_GENERAL);
-  fgd_clip_general(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-                   nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
-  pt.end();
+  if (gc) {
+    pt.begin(PH_CLIP_GENERAL);
+    fgd_gc_clip(npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, nacc, dc->stats, dc->err, st);
+    pt.end();
+  } else {
+    pt.begin(PH_CLIP_QUAD);
+    fgd_clip_quad(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
+                  nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
+    pt.end();
+    pt.begin(PH_CLIP_GENERAL);
+    fgd_clip_general(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
+                     nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
+    pt.end();
+  }
 
   // --- compaction into canonical order
   pt.begin(PH_COMPACT);
@@ -394,6 +434,9 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   if (hc->err[0] & 2u) return fail(FG_ERR_PARALLEL, "the line between <x1_0,y1_0> and  <x1_1,y1_1> should not parallel to "
                                                     "the line between <x2_0,y2_0> and  <x2_1,y2_1>");
   if (hc->err[0] & 4u) return fail(FG_ERR_MAXV, "clipped polygon exceeds 16 vertices");
+  if (hc->err[0] & G_ERRBIT_GC_CONVEX1) return fail(FG_ERR_PARALLEL, "create_xgrid.c(clip_2dx2d_great_circle): grid box 1 is not convex");
+  if (hc->err[0] & G_ERRBIT_GC_CONVEX2) return fail(FG_ERR_PARALLEL, "create_xgrid.c(clip_2dx2d_great_circle): grid box 2 is not convex");
+  if (hc->err[0] & G_ERRBIT_GC_CLIP) return fail(FG_ERR_PARALLEL, "%s", gc_clip_error((int)hc->err[1]));
   pl->nx = (long)hc->total[2];
   pl->stats[FG_STAT_PAIRS] = npairs;
   pl->stats[FG_STAT_NONEMPTY] = (long)(hc->total[2] + hc->stats[FG_STAT_BELOW]);
@@ -529,6 +572,116 @@ extern "C" long fg_plan_create_dev(int order, int ntiles_in, const int *nx_in, c
   long nx = plan_search(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon);
   if (nx < 0) { fg_plan_destroy(pl); return nx; }
   *plan_out = pl;
+  return nx;
+}
+
+// ------------------------------------------------------------------------------------- great-circle plans
+// typical destination cap-box extent from a strided sample of unit-vector corners (host copies)
+static void sample_extents_xyz(int nx, int ny, const double *x, const double *y, const double *z, double *mdlat, double *mdlon)
+{
+  const double PI = 3.14159265358979323846;
+  long ncell = (long)nx * ny;
+  long step = ncell / 4096; if (step < 1) step = 1;
+  double sl = 0, sw = 0; long cnt = 0;
+  for (long c = 0; c < ncell; c += step) {
+    int i = (int)(c % nx), j = (int)(c / nx);
+    long n0 = (long)j * (nx + 1) + i, n2 = n0 + nx + 2;
+    double dx = x[n0] - x[n2], dy = y[n0] - y[n2], dz = z[n0] - z[n2];
+    double diag = sqrt(dx * dx + dy * dy + dz * dz);
+    double zc = 0.5 * (z[n0] + z[n2]);
+    double coslat = sqrt(fmax(0.0, 1.0 - zc * zc));
+    if (coslat < 0.2) continue;
+    sl += diag; sw += diag / coslat; cnt++;
+  }
+  if (cnt == 0) { *mdlat = PI / 180; *mdlon = PI / 180; return; }
+  *mdlat = sl / cnt; *mdlon = sw / cnt;
+  if (*mdlat < 1e-7) *mdlat = 1e-7;
+  if (*mdlon < 1e-7) *mdlon = 1e-7;
+}
+
+extern "C" long fg_plan_create_great_circle_dev(int ntiles_in, const int *nx_in, const int *ny_in,
+                                                const double *const *d_x_in, const double *const *d_y_in, const double *const *d_z_in,
+                                                const double *const *d_mask_in, int nx_out, int ny_out,
+                                                const double *d_x_out, const double *d_y_out, const double *d_z_out,
+                                                double mean_dlat, double mean_dlon, int device, void *stream, int use_caller_stream,
+                                                fg_plan **plan_out)
+{
+  if (!d_x_in || !d_y_in || !d_z_in || !d_x_out || !d_y_out || !d_z_out) return fail(FG_ERR_ARG, "null grid pointer");
+  fg_plan *pl = nullptr;
+  int rc = plan_base(FG_CONSERVE_ORDER1, ntiles_in, nx_in, ny_in, nx_out, ny_out, device, &pl);
+  if (rc) return rc;
+  if (use_caller_stream) {
+    (void)hipStreamDestroy(pl->stream);
+    pl->stream = (hipStream_t)stream; pl->own_stream = false;
+  }
+  if (!(mean_dlat > 0) || !(mean_dlon > 0)) {
+    size_t npo = (size_t)(nx_out + 1) * (ny_out + 1);
+    std::vector<double> hx(npo), hy(npo), hz(npo);
+    if (hipMemcpy(hx.data(), d_x_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(hy.data(), d_y_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(hz.data(), d_z_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+      fg_plan_destroy(pl); return fail(FG_ERR_HIP, "copy of destination corners failed");
+    }
+    sample_extents_xyz(nx_out, ny_out, hx.data(), hy.data(), hz.data(), &mean_dlat, &mean_dlon);
+  }
+  std::vector<GcXyz> gin(ntiles_in);
+  for (int m = 0; m < ntiles_in; m++) gin[m] = GcXyz{d_x_in[m], d_y_in[m], d_z_in[m]};
+  GcXyz gout{d_x_out, d_y_out, d_z_out};
+  long nx = plan_search(pl, nullptr, nullptr, d_mask_in, nullptr, nullptr, mean_dlat, mean_dlon, gin.data(), &gout);
+  if (nx < 0) { fg_plan_destroy(pl); return nx; }
+  *plan_out = pl;
+  return nx;
+}
+
+extern "C" long fg_plan_create_great_circle(int ntiles_in, const int *nx_in, const int *ny_in,
+                                            const double *const *lon_in, const double *const *lat_in, const double *const *mask_in,
+                                            int nx_out, int ny_out, const double *lon_out, const double *lat_out,
+                                            int device, fg_plan **plan_out)
+{
+  if (!lon_in || !lat_in || !lon_out || !lat_out || !nx_in || !ny_in) return fail(FG_ERR_ARG, "null grid pointer");
+  if (ntiles_in < 1 || nx_out < 1 || ny_out < 1) return fail(FG_ERR_ARG, "bad grid sizes");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(FG_ERR_HIP, "no HIP device visible: libfregrid_hip needs an MI355X-class GPU");
+  if (device < 0 || device >= ndev) return fail(FG_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+  HIPCHK(hipSetDevice(device));
+  // unit vectors on the host (libm, as the reference), then one upload per array
+  std::vector<double *> dev_ptrs;
+  auto cleanup = [&]() { for (double *p : dev_ptrs) g_pool.put(p); };
+  auto to_dev_xyz = [&](int nx, int ny, const double *lon, const double *lat, GcXyz *out) -> bool {
+    const size_t np = (size_t)(nx + 1) * (ny + 1);
+    std::vector<double> h(3 * np);
+    fg_latlon2xyz((long)np, lon, lat, h.data(), h.data() + np, h.data() + 2 * np);
+    double *d = (double *)g_pool.get(device, 3 * np * sizeof(double));
+    if (!d) return false;
+    dev_ptrs.push_back(d);
+    if (hipMemcpy(d, h.data(), 3 * np * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return false;
+    out->x = d; out->y = d + np; out->z = d + 2 * np;
+    return true;
+  };
+  std::vector<GcXyz> gin(ntiles_in);
+  std::vector<const double *> xs(ntiles_in), ys(ntiles_in), zs(ntiles_in), dmask(ntiles_in, nullptr);
+  bool ok = true;
+  for (int m = 0; m < ntiles_in && ok; m++) {
+    if (nx_in[m] < 1 || ny_in[m] < 1) { cleanup(); return fail(FG_ERR_ARG, "bad source tile size"); }
+    ok = to_dev_xyz(nx_in[m], ny_in[m], lon_in[m], lat_in[m], &gin[m]);
+    xs[m] = gin[m].x; ys[m] = gin[m].y; zs[m] = gin[m].z;
+    if (ok && mask_in && mask_in[m]) {
+      const size_t nc = (size_t)nx_in[m] * ny_in[m];
+      double *d = (double *)g_pool.get(device, nc * sizeof(double));
+      ok = d && hipMemcpy(d, mask_in[m], nc * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+      if (d) dev_ptrs.push_back(d);
+      dmask[m] = d;
+    }
+  }
+  GcXyz gout{};
+  ok = ok && to_dev_xyz(nx_out, ny_out, lon_out, lat_out, &gout);
+  if (!ok) { cleanup(); return fail(FG_ERR_HIP, "grid upload failed (out of device memory?)"); }
+  double mdlat, mdlon;
+  sample_extents(nx_out, ny_out, lon_out, lat_out, &mdlat, &mdlon);
+  long nx = fg_plan_create_great_circle_dev(ntiles_in, nx_in, ny_in, xs.data(), ys.data(), zs.data(), mask_in ? dmask.data() : nullptr,
+                                            nx_out, ny_out, gout.x, gout.y, gout.z, mdlat, mdlon, device, nullptr, 0, plan_out);
+  cleanup();
   return nx;
 }
 
@@ -1075,6 +1228,114 @@ extern "C" void get_grid_area(const int *nlon, const int *nlat, const double *lo
 extern "C" void get_grid_area_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area)
 {
   get_grid_area(nlon, nlat, lon, lat, area);
+}
+
+extern "C" int create_xgrid_great_circle(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
+                                         const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,
+                                         const double *mask_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                                         double *xgrid_area, double *xgrid_clon, double *xgrid_clat)
+{
+  int nx1 = *nlon_in, ny1 = *nlat_in;
+  const double *lons[1] = {lon_in}, *lats[1] = {lat_in}, *masks[1] = {mask_in};
+  fg_plan *pl = nullptr;
+  long nx = fg_plan_create_great_circle(1, &nx1, &ny1, lons, lats, masks, *nlon_out, *nlat_out, lon_out, lat_out, b1_device(), &pl);
+  if (nx < 0) fatal(fg_last_error());
+  if (nx > (long)MAXXGRID) fatal("nxgrid is greater than MAXXGRID, increase MAXXGRID");      // create_xgrid.c:1444
+  if (fg_plan_get_xgrid(pl, nullptr, i_in, j_in, i_out, j_out, xgrid_area, nullptr, nullptr)) fatal(fg_last_error());
+  for (long k = 0; k < nx; k++) { if (xgrid_clon) xgrid_clon[k] = 0; if (xgrid_clat) xgrid_clat[k] = 0; }   // :1446-1447
+  fg_plan_destroy(pl);
+  return (int)nx;
+}
+extern "C" int create_xgrid_great_circle_(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
+                                          const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,
+                                          const double *mask_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                                          double *xgrid_area, double *xgrid_clon, double *xgrid_clat)
+{
+  return create_xgrid_great_circle(nlon_in, nlat_in, nlon_out, nlat_out, lon_in, lat_in, lon_out, lat_out, mask_in,
+                                   i_in, j_in, i_out, j_out, xgrid_area, xgrid_clon, xgrid_clat);
+}
+
+extern "C" void get_grid_great_circle_area(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area)
+{
+  int nx = *nlon, ny = *nlat, one = 1;
+  const double dl[4] = {0, 0.01, 0, 0.01}, da[4] = {0, 0, 0.01, 0.01};      // dummy 1x1 destination
+  const double *lons[1] = {lon}, *lats[1] = {lat};
+  fg_plan *pl = nullptr;
+  long rc = fg_plan_create_great_circle(1, &nx, &ny, lons, lats, nullptr, one, one, dl, da, b1_device(), &pl);
+  if (rc < 0) fatal(fg_last_error());
+  if (fg_plan_get_cell_area(pl, area, nullptr)) fatal(fg_last_error());
+  fg_plan_destroy(pl);
+}
+extern "C" void get_grid_great_circle_area_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area)
+{
+  get_grid_great_circle_area(nlon, nlat, lon, lat, area);
+}
+
+extern "C" int fg_gc_clip_batch(int npairs, const double *a, const double *b, double *out, int *n_out, double *area, int device)
+{
+  if (npairs < 0 || !a || !b || !out || !n_out || !area) return fail(FG_ERR_ARG, "null argument");
+  if (npairs == 0) return 0;
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(FG_ERR_HIP, "no HIP device visible: libfregrid_hip needs an MI355X-class GPU");
+  HIPCHK(hipSetDevice(device));
+  const size_t na = (size_t)npairs * 12, no = (size_t)npairs * FG_GC_POLY_CAP * 3;
+  double *d_a = (double *)g_pool.get(device, (2 * na + no + npairs) * sizeof(double));
+  int *d_n = (int *)g_pool.get(device, (size_t)npairs * sizeof(int));
+  if (!d_a || !d_n) { if (d_a) g_pool.put(d_a); if (d_n) g_pool.put(d_n); return fail(FG_ERR_HIP, "out of device memory"); }
+  double *d_b = d_a + na, *d_o = d_b + na, *d_ar = d_o + no;
+  int rc = 0;
+  if (hipMemcpy(d_a, a, na * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_b, b, na * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = FG_ERR_HIP;
+  if (!rc) {
+    fgd_gc_clip_batch(npairs, d_a, d_b, d_o, d_n, d_ar, nullptr);
+    if (hipMemcpy(out, d_o, no * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(n_out, d_n, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(area, d_ar, (size_t)npairs * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = FG_ERR_HIP;
+  }
+  g_pool.put(d_a); g_pool.put(d_n);
+  if (rc) return fail(rc, "fg_gc_clip_batch: HIP copy/launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
+extern "C" double great_circle_area(int n, const double *x, const double *y, const double *z)
+{
+  if (n < 1 || n > 64) fatal("great_circle_area (HIP): 1 <= n <= 64");
+  double h[64 * 3], area = 0;
+  for (int k = 0; k < n; k++) { h[k * 3] = x[k]; h[k * 3 + 1] = y[k]; h[k * 3 + 2] = z[k]; }
+  if (hipSetDevice(b1_device()) != hipSuccess) fatal("no HIP device visible: libfregrid_hip needs an MI355X-class GPU");
+  double *d = (double *)g_pool.get(b1_device(), (64 * 3 + 2) * sizeof(double));
+  if (!d) fatal("out of device memory");
+  int *dn = (int *)(d + 64 * 3 + 1);
+  bool ok = hipMemcpy(d, h, n * 3 * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(dn, &n, sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    fgd_gc_area_batch(1, 64, d, dn, d + 64 * 3, nullptr);
+    ok = hipMemcpy(&area, d + 64 * 3, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  g_pool.put(d);
+  if (!ok) fatal("great_circle_area: HIP copy/launch failed");
+  return area;
+}
+
+// clip_2dx2d_great_circle / great_circle_area, one polygon pair per call (create_xgrid.h / mosaic_util.h prototypes)
+extern "C" int clip_2dx2d_great_circle(const double x1_in[], const double y1_in[], const double z1_in[], int n1_in,
+                                       const double x2_in[], const double y2_in[], const double z2_in[], int n2_in,
+                                       double x_out[], double y_out[], double z_out[])
+{
+  if (n1_in != 4 || n2_in != 4) fatal("clip_2dx2d_great_circle (HIP): quadrilaterals only (n1_in == n2_in == 4, as every caller in the reference passes)");
+  double a[12], b[12], out[FG_GC_POLY_CAP * 3], area;
+  int n_out = 0;
+  for (int k = 0; k < 4; k++) {
+    a[k * 3] = x1_in[k]; a[k * 3 + 1] = y1_in[k]; a[k * 3 + 2] = z1_in[k];
+    b[k * 3] = x2_in[k]; b[k * 3 + 1] = y2_in[k]; b[k * 3 + 2] = z2_in[k];
+  }
+  if (fg_gc_clip_batch(1, a, b, out, &n_out, &area, b1_device())) fatal(fg_last_error());
+  if (n_out == -1) fatal("create_xgrid.c(clip_2dx2d_great_circle): grid box 1 is not convex");
+  if (n_out == -2) fatal("create_xgrid.c(clip_2dx2d_great_circle): grid box 2 is not convex");
+  if (n_out < 0) fatal(gc_clip_error(-n_out));
+  for (int k = 0; k < n_out; k++) { x_out[k] = out[k * 3]; y_out[k] = out[k * 3 + 1]; z_out[k] = out[k * 3 + 2]; }
+  return n_out;
 }
 
 static int b1_create_xgrid(int order, const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,

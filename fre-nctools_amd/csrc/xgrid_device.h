@@ -10,6 +10,16 @@ struct FgTile {
   int cell_off;        // index of this tile's first cell in the flattened cell numbering
 };
 
+// great-circle path: corners as unit vectors (latlon2xyz, mosaic_util.c:212-222), same indexing as FgTile
+struct FgTileXyz {
+  const double *x, *y, *z;
+  int nx, ny;
+  int cell_off;
+};
+#define G_ERRBIT_GC_CONVEX1 16u    // "grid box 1 is not convex" (create_xgrid.c:1575)
+#define G_ERRBIT_GC_CONVEX2 32u
+#define G_ERRBIT_GC_CLIP    64u    // one of the clip's fatal checks; code in err[1]
+
 // per-cell records, SoA scalars + one 128-byte vertex record per cell
 // (the quantities of create_xgrid.c:991-1016 plus the cell area of :66-88)
 struct FgCells {
@@ -122,6 +132,14 @@ void fgd_mono_xdata(long nx, FgCsr csr, const double *f, const double *gx, const
                     double *xdata, double *fmax, double *fmin, hipStream_t st);
 void fgd_mono_limit(long nx, FgCsr csr, const double *f, double missing, const double *fbmax, const double *fbmin,
                     const double *fmax, const double *fmin, double *xdata, int *err, hipStream_t st);
+
+// ---- great-circle path (gc_kernels.hip)
+void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st);
+void fgd_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
+                 double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err, hipStream_t st);
+#define FG_GC_POLY_CAP 16
+void fgd_gc_clip_batch(int n, const double *a, const double *b, double *out, int *n_out, double *area, hipStream_t st);
+void fgd_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *n, double *area, hipStream_t st);
 
 // ---- batched polygon primitives (poly_kernels.hip); polygons are rows of [npoly][FG_POLY_STRIDE]
 #define FG_POLY_STRIDE 24

@@ -45,6 +45,7 @@ extern "C" {
 #define FG_ERR_PARALLEL   (-4)   /* clip hit parallel edges, |determ| < 1e-30 (create_xgrid.c:1314) */
 #define FG_ERR_CAPACITY   (-5)   /* caller's output arrays too small (reference: MAXXGRID fatal, :1087) */
 #define FG_ERR_STATE      (-6)   /* call made in the wrong plan state                          */
+#define FG_ERR_GEOM       (-8)   /* the great-circle clip hit one of the reference's fatal geometry checks (create_xgrid.c:1575-1834) */
 #define FG_ERR_DATA       (-7)   /* the field data hit one of the reference's fatal checks (conserve_interp.c:584,:697,:709) */
 
 /* option bits, same values as tools/libfrencutils/globals.h:46-61 where they exist */
@@ -340,6 +341,48 @@ int fg_gnomonic_ed_grid(int ni, double shift_fac, int via_degrees, double *lonc,
  * lonc/latc[(nlat+1)*(nlon+1)]. */
 int fg_latlon_corners(int nlon, int nlat, double lonbegin, double lonend, double latbegin,
                       double latend, int center_y, double *lonc, double *latc);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Great-circle exchange grid: create_xgrid_great_circle (create_xgrid.c:1366-1466), used by fregrid for grids
+ * flagged great_circle_algorithm (opcode GREAT_CIRCLE, conserve_interp.c:164-168; first order only, fregrid.c:763).
+ * Cell edges are great-circle arcs; areas are spherical excesses.  The plan that results is an ordinary first-order
+ * plan: fg_plan_finalize / fg_plan_get_xgrid / fg_plan_apply* work on it unchanged (xgrid_clon/clat are zero in the
+ * reference, :1446-1447).  fg_plan_create_great_circle takes host corner arrays (radians); the unit vectors are
+ * formed on the host with libm exactly like latlon2xyz (mosaic_util.c:212-222) -- see fg_latlon2xyz -- everything
+ * else runs on the device.  fg_plan_create_great_circle_dev takes DEVICE arrays of unit vectors.
+ * The source rows are not trimmed (conserve_interp.c:164 passes the whole tile).  Returns nxgrid or FG_ERR_*;
+ * FG_ERR_GEOM carries the reference's fatal message ("grid box 1 is not convex", ...). */
+long fg_plan_create_great_circle(int ntiles_in, const int *nx_in, const int *ny_in,
+                                 const double *const *lon_in, const double *const *lat_in, const double *const *mask_in,
+                                 int nx_out, int ny_out, const double *lon_out, const double *lat_out,
+                                 int device, fg_plan **plan);
+long fg_plan_create_great_circle_dev(int ntiles_in, const int *nx_in, const int *ny_in,
+                                     const double *const *d_x_in, const double *const *d_y_in, const double *const *d_z_in,
+                                     const double *const *d_mask_in, int nx_out, int ny_out,
+                                     const double *d_x_out, const double *d_y_out, const double *d_z_out,
+                                     double mean_dlat, double mean_dlon, int device, void *stream, int use_caller_stream,
+                                     fg_plan **plan);
+/* latlon2xyz (mosaic_util.c:212-222) with the host libm, threaded */
+void fg_latlon2xyz(long size, const double *lon, const double *lat, double *x, double *y, double *z);
+/* B1 drop-ins (create_xgrid.h): same prototypes as the reference */
+int create_xgrid_great_circle(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
+                              const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,
+                              const double *mask_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                              double *xgrid_area, double *xgrid_clon, double *xgrid_clat);
+int create_xgrid_great_circle_(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
+                               const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,
+                               const double *mask_in, int *i_in, int *j_in, int *i_out, int *j_out,
+                               double *xgrid_area, double *xgrid_clon, double *xgrid_clat);
+void get_grid_great_circle_area(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
+void get_grid_great_circle_area_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
+int clip_2dx2d_great_circle(const double x1_in[], const double y1_in[], const double z1_in[], int n1_in,
+                            const double x2_in[], const double y2_in[], const double z2_in[], int n2_in,
+                            double x_out[], double y_out[], double z_out[]);
+double great_circle_area(int n, const double *x, const double *y, const double *z);
+/* npairs quadrilateral pairs at once: a, b [npairs][4][3] unit vectors (clockwise); out [npairs][16][3], n_out[npairs]
+ * (negative = the reference would have aborted, code as in oracle/gc_oracle.c), area[npairs] of the clipped polygon.
+ * Host pointers. */
+int fg_gc_clip_batch(int npairs, const double *a, const double *b, double *out, int *n_out, double *area, int device);
 
 /* Tripolar ocean grid (make_hgrid --grid_type tripolar_grid, uniform bounds, Murray bipolar cap north of lat_join):
  * nlon x nlat model cells, bounds in degrees, lonc/latc[(nlat+1)*(nlon+1)] radians.  Input synthesis only (see grid_gen.c). */

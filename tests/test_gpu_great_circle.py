@@ -1,0 +1,119 @@
+"""GPU parity of the great-circle path (create_xgrid_great_circle semantics) against the oracle
+(gc_oracle.c, itself pinned bit for bit to the compiled reference): exchange-cell lists identical, areas within 1e-10
+relative -- and in fact bit-identical except where the x87 fpatan inside glibc's acosl rounds differently from the
+device's correctly rounded replacement (csrc/fp80.h), which the tests quantify."""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _cases(fg):
+    c24 = fg.gnomonic_ed_corners(24)
+    c12 = fg.gnomonic_ed_corners(12)
+    return {
+        "c24_tile1_144x90": (24, 24, 144, 90, c24[0][0], c24[1][0]) + fg.latlon_corners(144, 90),
+        "c24_tile3_polar_144x90": (24, 24, 144, 90, c24[0][2], c24[1][2]) + fg.latlon_corners(144, 90),
+        "latlon_aligned_2x": (36, 18, 72, 36) + fg.latlon_corners(36, 18) + fg.latlon_corners(72, 36),
+        "latlon_regional_offset": (30, 20, 45, 33) + fg.latlon_corners(30, 20, 10., 70., -30., 30.) + fg.latlon_corners(45, 33, 0., 90., -40., 40.),
+        "latlon_to_cubed_polar": (40, 20, 12, 12) + fg.latlon_corners(40, 20) + (c12[0][5], c12[1][5]),
+        "tripolar_to_cubed": (45, 27, 12, 12) + fg.tripolar_corners(45, 27) + (c12[0][2], c12[1][2]),
+    }
+
+
+@pytest.mark.parametrize("name", ["c24_tile1_144x90", "c24_tile3_polar_144x90", "latlon_aligned_2x", "latlon_regional_offset",
+                                  "latlon_to_cubed_polar", "tripolar_to_cubed"])
+def test_create_xgrid_great_circle_vs_oracle(fg, gpu_ok, name):
+    args = _cases(fg)[name]
+    o = orc.orc_create_xgrid_gc(*args)
+    n, i_in, j_in, i_out, j_out, area, clon, clat = fg.create_xgrid_great_circle(*args)
+    assert n == o["n"] and n > 0
+    assert np.array_equal(i_in, o["i_in"]) and np.array_equal(j_in, o["j_in"])
+    assert np.array_equal(i_out, o["i_out"]) and np.array_equal(j_out, o["j_out"])
+    rel = np.abs(area - o["area"]) / o["area"]
+    assert rel.max() < RTOL
+    same = np.mean(_bits(area) == _bits(o["area"]))
+    assert same > 0.98, same                       # the rest: one final double rounding of an angle (fpatan vs exact)
+    assert not clon.any() and not clat.any()       # create_xgrid.c:1446-1447
+    ca = fg.get_grid_great_circle_area(args[0], args[1], args[4], args[5])
+    cref = orc.orc_get_grid_gc_area(args[0], args[1], args[4], args[5])
+    assert np.max(np.abs(ca - cref) / np.abs(cref)) < RTOL
+    assert np.mean(_bits(ca) == _bits(cref)) > 0.98
+
+
+def test_clip_vertices_bitwise(fg, gpu_ok):
+    """clip_2dx2d_great_circle vertex lists: the soft-x87 intersection solve reproduces the reference's vertices bit for
+    bit (no acos involved in the vertices)."""
+    import ctypes as C
+    O = orc.oracle()
+    lon, lat = fg.gnomonic_ed_corners(24)
+    lo, la = fg.latlon_corners(144, 90)
+    x1, y1, z1 = fg.latlon2xyz(lon[2], lat[2])
+    x2, y2, z2 = fg.latlon2xyz(lo, la)
+    ox, oy, oz = (np.empty(25 * 25) for _ in range(3))
+    O.orc_latlon2xyz(25 * 25, orc._dp(orc.f64(lon[2]).ravel()), orc._dp(orc.f64(lat[2]).ravel()), orc._dp(ox), orc._dp(oy), orc._dp(oz))
+    assert np.array_equal(_bits(x1), _bits(ox)) and np.array_equal(_bits(y1), _bits(oy)) and np.array_equal(_bits(z1), _bits(oz))
+    cell = lambda x, nxp, i, j: np.array([x[j * nxp + i], x[(j + 1) * nxp + i], x[(j + 1) * nxp + i + 1], x[j * nxp + i + 1]])
+    gc = orc.orc_create_xgrid_gc(24, 24, 144, 90, lon[2], lat[2], lo, la)
+    idx = np.arange(0, gc["n"], 3)
+    a = np.stack([np.stack([cell(v, 25, int(gc["i_in"][k]), int(gc["j_in"][k])) for v in (x1, y1, z1)], axis=1) for k in idx])
+    b = np.stack([np.stack([cell(v, 145, int(gc["i_out"][k]), int(gc["j_out"][k])) for v in (x2, y2, z2)], axis=1) for k in idx])
+    n_out, verts, area = fg.gc_clip_batch(a, b)
+    nbad_area = 0
+    for q, k in enumerate(idx):
+        aa = [np.ascontiguousarray(a[q][:, ax]) for ax in range(3)]
+        bb = [np.ascontiguousarray(b[q][:, ax]) for ax in range(3)]
+        oo = [np.zeros(50) for _ in range(3)]
+        no = O.orc_clip_2dx2d_great_circle(*[orc._dp(v) for v in aa], 4, *[orc._dp(v) for v in bb], 4, *[orc._dp(v) for v in oo])
+        assert no == n_out[q] and no >= 3
+        for ax in range(3):
+            assert np.array_equal(_bits(verts[q, :no, ax]), _bits(oo[ax][:no]))
+        ar = O.orc_great_circle_area(no, *[orc._dp(v) for v in oo])
+        assert abs(ar - area[q]) <= RTOL * abs(ar)
+        nbad_area += ar != area[q]
+    assert nbad_area < 0.02 * len(idx)
+    # an antipodal cell (whose edge planes do cross the first cell's chords) is rejected by the reference's bounding box
+    # (create_xgrid.c:1508-1528) and so it is here
+    anti = -a[0][::-1]
+    n_far, _, _ = fg.gc_clip_batch(a[:1], anti[None])
+    assert n_far[0] == 0
+
+
+def test_setup_conserve_interp_great_circle_and_sweep(fg, gpu_ok, capsys):
+    """opcode GREAT_CIRCLE through the mirror API: whole-tile search for all six tiles, first-order sweep, conservation."""
+    ni, nlon, nlat = 16, 48, 24
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grid_in = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    grid_out = [fg.GridConfig(nlon, nlat, lo, la)]
+    interp = [fg.InterpConfig()]
+    fg.setup_conserve_interp(6, grid_in, 1, grid_out, interp, fg.CONSERVE_ORDER1 | fg.GREAT_CIRCLE)
+    tot = 0
+    for t in range(6):
+        o = orc.orc_create_xgrid_gc(ni, ni, nlon, nlat, lon[t], lat[t], lo, la)
+        sel = interp[0].t_in == t
+        assert sel.sum() == o["n"]
+        assert np.array_equal(interp[0].i_in[sel], o["i_in"]) and np.array_equal(interp[0].j_out[sel], o["j_out"])
+        assert np.max(np.abs(interp[0].area[sel] - o["area"]) / o["area"]) < RTOL
+        tot += o["n"]
+    assert interp[0].nxgrid == tot
+    R = 6371000.0
+    assert abs(interp[0].area.sum() / (4 * np.pi * R * R) - 1) < 1e-9          # great-circle cells tile the sphere
+    # cell areas handed back are the great-circle ones (get_input_output_cell_area with GREAT_CIRCLE)
+    assert np.max(np.abs(grid_in[2].cell_area - orc.orc_get_grid_gc_area(ni, ni, lon[2], lat[2])) / grid_in[2].cell_area) < RTOL
+    rng = np.random.default_rng(2)
+    field_in = [fg.FieldConfig(data=rng.standard_normal((1, ni, ni)) + 3.0, var=[fg.VarConfig(name="t", interp_method=fg.CONSERVE_ORDER1)])
+                for _ in range(6)]
+    field_out = [fg.FieldConfig()]
+    gin, gout = fg.do_scalar_conserve_interp(interp, 0, 6, grid_in, 1, grid_out, field_in, field_out,
+                                             fg.CONSERVE_ORDER1 | fg.CHECK_CONSERVE, 1)
+    assert abs(gout - gin) < 1e-10 * abs(gin)
+    with pytest.raises(ValueError):
+        fg.setup_conserve_interp(6, grid_in, 1, grid_out, [fg.InterpConfig()], fg.CONSERVE_ORDER2 | fg.GREAT_CIRCLE)
