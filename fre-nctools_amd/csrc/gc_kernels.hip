@@ -429,10 +429,22 @@ __global__ __launch_bounds__(256) void k_gc_cell_struct(const FgTileXyz *tiles, 
   if (lonc < 0) lonc += tpi;
   c.lat_min[s] = fmax(-hpi, latc - r);
   c.lat_max[s] = fmin(hpi, latc + r);
-  if (fabs(latc) + r >= hpi - 1.e-6) { c.lon_min[s] = 0.0; c.lon_max[s] = tpi; c.lon_avg[s] = GC_PI; }
+  // longitude: a great-circle arc that stays clear of the pole is monotone in longitude, so the polygon's extent is
+  // that of its corners; the angular margin becomes margin / cos(lat) in longitude.  Cells whose cap reaches a pole
+  // (or nearly) take the whole circle.
+  const double cosmin = cos(fmin(hpi, fabs(latc) + r));
+  if (fabs(latc) + r >= hpi - 1.e-6 || cosmin < 0.02) { c.lon_min[s] = 0.0; c.lon_max[s] = tpi; c.lon_avg[s] = GC_PI; }
   else {
-    const double w = asin(fmin(1.0, sin(r) / cos(latc))) * (1.0 + 1.e-9) + 1.e-9;
-    c.lon_min[s] = lonc - w; c.lon_max[s] = lonc + w; c.lon_avg[s] = lonc;
+    double dmin = 0.0, dmax = 0.0;
+    for (int k = 0; k < 4; k++) {
+      double dl = atan2(v[k * 3 + 1], v[k * 3]) - lonc;
+      if (dl > GC_PI) dl -= tpi;
+      if (dl < -GC_PI) dl += tpi;
+      if (dl > GC_PI) dl -= tpi;
+      dmin = fmin(dmin, dl); dmax = fmax(dmax, dl);
+    }
+    const double mlon = (GC_CAP_MARGIN + 1.e-9) / cosmin + 1.e-9;
+    c.lon_min[s] = lonc + dmin - mlon; c.lon_max[s] = lonc + dmax + mlon; c.lon_avg[s] = lonc;
   }
 }
 
