@@ -1,0 +1,130 @@
+"""BASELINE.json configs 4 and 5 at full size on the device, checked through size-independent properties plus oracle
+parity on sampled source rows (the brute-force oracle cannot finish these sizes):
+  config 4a  C768 -> 2880x1440, great-circle clip, first order, write the remap file (order 2 + great circle is rejected
+             by the reference itself, fregrid.c:763 -- SURVEY §8d)
+  config 5   tripolar 1440x1080 -> C384 mosaic (six destination tiles), first order, cached remap files read back,
+             3-D field sweep through the READ-branch plans"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+R = 6371000.0
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_config4_c768_great_circle_full_size(fg, gpu_ok, tmp_path):
+    import torch
+    ni, nlon, nlat = 768, 2880, 1440
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    plan = fg.XgridPlan.create_great_circle(grids, fg.GridConfig(nlon, nlat, lo, la))
+    st = plan.stats()
+    assert st["borderline"] == 0
+    plan.finalize()
+    x = plan.get_xgrid()
+    n = plan.nxgrid
+    assert 16_000_000 < n < 17_500_000                      # ~16.7 M (4.02 x the C384 count)
+    s = x["t_in"].astype(np.int64) * ni * ni + x["j_in"].astype(np.int64) * ni + x["i_in"]
+    d = x["j_out"].astype(np.int64) * nlon + x["i_out"]
+    assert np.all(np.diff(s * (nlon * nlat) + d) > 0)       # canonical order, no duplicates
+    assert abs(x["area"].sum() / (4 * np.pi * R * R) - 1) < 5e-9
+    a_in, a_out = plan.get_cell_area(nlon * nlat)
+    # great-circle cells tile the sphere, so exchange cells cover each source cell and each destination cell.  The
+    # spherical-excess formula itself is only good to ~1e-16/cell-size^2 (1e-7 relative for 13 km cells), which is the
+    # reference's own noise floor -- hence the loose bound; the sampled rows below are compared exactly.
+    cov_s = np.bincount(s, weights=x["area"], minlength=6 * ni * ni)
+    assert np.max(np.abs(cov_s / a_in - 1)) < 5e-5
+    cov_d = np.bincount(d, weights=x["area"], minlength=nlon * nlat)
+    assert np.max(np.abs(cov_d / a_out - 1)) < 5e-5
+    # oracle parity on one equatorial and one polar source row (brute force against all 4.1 M destination cells)
+    for t, j0 in ((0, ni // 2), (2, 0)):
+        o = orc.orc_create_xgrid_gc(ni, ni, nlon, nlat, lon[t], lat[t], lo, la, j1_beg=j0, j1_end=j0 + 1, capacity=200000)
+        sel = (x["t_in"] == t) & (x["j_in"] == j0)
+        assert sel.sum() == o["n"] > 0
+        for k in ("i_in", "i_out", "j_out"):
+            assert np.array_equal(x[k][sel], o[k]), k
+        assert np.max(np.abs(x["area"][sel] - o["area"]) / o["area"]) < 1e-10
+        assert np.mean(_bits(x["area"][sel]) == _bits(o["area"])) > 0.98
+    # first-order sweep on the great-circle plan: constants preserved, conservation
+    dev = "cuda:0"
+    data = torch.full((2, 6 * ni * ni), 3.25, dtype=torch.float64, device=dev)
+    data[1] = torch.from_numpy(np.random.default_rng(0).standard_normal(6 * ni * ni) + 4.0).to(dev)
+    out = torch.empty(2, nlon * nlat, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    gs = plan.apply(data, out, nz=2, want_gsum=True)
+    plan.sync()
+    o2 = out.cpu().numpy()
+    assert np.max(np.abs(o2[0] - 3.25)) < 1e-13
+    ref_sum = 3.25 * x["area"].sum() + float(np.sum(data[1].cpu().numpy()[s] * x["area"]))
+    assert abs(gs - ref_sum) < 1e-11 * abs(ref_sum)
+    # write the remap file (fregrid --remap_file, conserve_interp.c:368-445) and read it back
+    path = os.path.join(str(tmp_path), "remap_C768_2880x1440_gc.nc")
+    fg.write_remap_file(path, 1, x["t_in"], x["i_in"], x["j_in"], x["i_out"], x["j_out"], x["area"])
+    y = fg.read_remap_file(path, 1)
+    for k in ("t_in", "i_in", "j_in", "i_out", "j_out"):
+        assert np.array_equal(y[k], x[k]), k
+    assert np.max(np.abs(y["area"] - x["area"]) / x["area"]) < 1e-15      # stored as area/(4 pi R^2)... and back
+    plan.destroy()
+
+
+def test_config5_tripolar_to_c384_cached_remap_and_3d_sweep(fg, gpu_ok, tmp_path):
+    import torch
+    nx, ny, ni, nz = 1440, 1080, 384, 50
+    tlon, tlat = fg.tripolar_corners(nx, ny)
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    grid_in = [fg.GridConfig(nx, ny, tlon, tlat)]
+    grid_out = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    interp = [fg.InterpConfig(remap_file=os.path.join(str(tmp_path), f"remap.tile{t + 1}.nc")) for t in range(6)]
+    fg.setup_conserve_interp(1, grid_in, 6, grid_out, interp, fg.CONSERVE_ORDER1 | fg.WRITE)
+    ntot = sum(ic.nxgrid for ic in interp)
+    assert ntot > 6 * ni * ni
+    # exchange cells cover every atmosphere cell south of the ocean grid's northern... the ocean grid spans -82..90:
+    # atmosphere cells north of 80S are fully covered
+    for t in (0, 2):
+        ic = interp[t]
+        cov = np.bincount(ic.j_out.astype(np.int64) * ni + ic.i_out, weights=ic.area, minlength=ni * ni)
+        latc = 0.25 * (lat[t][:-1, :-1] + lat[t][1:, :-1] + lat[t][:-1, 1:] + lat[t][1:, 1:]).ravel()
+        inside = latc > np.radians(-75.0)
+        assert np.max(np.abs(cov[inside] / grid_out[t].cell_area[inside] - 1)) < 2e-3     # legacy area model, conserve_interp.c:479
+    # oracle parity on one ocean row (a fold row of the bipolar cap and a mid-latitude row) against tile 3 (north polar)
+    for j0 in (ny - 1, ny // 2):
+        o = orc.orc_create_xgrid(1, nx, ny, ni, ni, tlon, tlat, lon[2], lat[2], j1_beg=j0, j1_end=j0 + 1, capacity=200000)
+        ic = interp[2]
+        sel = ic.j_in == j0
+        assert sel.sum() == o["n"]
+        if o["n"]:
+            for k in ("i_in", "i_out", "j_out"):
+                assert np.array_equal(getattr(ic, k)[sel], o[k]), k
+            assert np.max(np.abs(ic.area[sel] - o["area"]) / o["area"]) < 1e-10
+    # cached remap files: READ branch (conserve_interp.c:62-126) gives plans whose sweep equals the computed plans'
+    interp_r = [fg.InterpConfig(remap_file=ic.remap_file, file_exist=1) for ic in interp]
+    fg.setup_conserve_interp(1, grid_in, 6, grid_out, interp_r, fg.CONSERVE_ORDER1 | fg.READ)
+    dev = "cuda:0"
+    rng = np.random.default_rng(4)
+    field = torch.from_numpy(rng.standard_normal((nz, nx * ny)) + 10.0).to(dev)      # one 3-D field, 50 levels
+    gsum_in = float((field.cpu().numpy() * grid_in[0].cell_area[None, :]).sum())
+    gsum_out = 0.0
+    for t in range(6):
+        assert interp_r[t].nxgrid == interp[t].nxgrid
+        o_c = torch.empty(nz, ni * ni, dtype=torch.float64, device=dev)
+        o_r = torch.empty_like(o_c)
+        torch.cuda.synchronize()
+        g1 = interp[t].plan.apply(field, o_c, nz=nz, want_gsum=True)
+        g2 = interp_r[t].plan.apply(field, o_r, nz=nz, want_gsum=True)
+        interp[t].plan.sync(); interp_r[t].plan.sync()
+        a, b = o_c.cpu().numpy(), o_r.cpu().numpy()
+        assert np.max(np.abs(a - b)) < 1e-12 * np.max(np.abs(a))        # areas round-trip through area/(4 pi R^2)
+        assert abs(g1 - g2) < 1e-12 * abs(g1)
+        gsum_out += g1
+    # ocean -> atmosphere conserves the part of the ocean field that lies on the atmosphere grid (= all of it)
+    assert abs(gsum_out - gsum_in) < 2e-6 * abs(gsum_in)
+    for ic in interp + interp_r:
+        ic.plan.destroy()
