@@ -449,7 +449,10 @@ __global__ __launch_bounds__(256) void k_gc_cell_struct(const FgTileXyz *tiles, 
 }
 
 // ------------------------------------------------------------------------------------------------ pair kernel
-__global__ __launch_bounds__(64) void k_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask,
+#ifndef GC_WAVES_PER_EU
+#define GC_WAVES_PER_EU 4   // measured on MI355X (C384 -> 0.25 deg): 1: 46.8 ms, 2: 27.0, 3: 21.0, 4: 19.9, 5: 23.1 -- latency bound on scratch
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_WAVES_PER_EU, GC_WAVES_PER_EU))) void k_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask,
                                                  FgCells D, double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,4 +1,5 @@
-"""Minimal profiling target: a few search + finalize + sweep steps on C384 -> 1440x720 (used under rocprofv3)."""
+"""Minimal profiling target (used under rocprofv3): a few search + finalize + sweep steps on C384 -> 1440x720.
+usage: prof_step.py [steps] [legacy|gc]   -- inputs are made on the host (no torch kernels run under the counters)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,18 +8,31 @@ import __graft_entry__ as ge
 fg = ge.load_package()
 ni, nlon, nlat, nz = 384, 1440, 720, 8
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+mode = sys.argv[2] if len(sys.argv) > 2 else "legacy"
 lon, lat = fg.gnomonic_ed_corners(ni); lo, la = fg.latlon_corners(nlon, nlat)
 dev = "cuda:0"
-lon_t = [torch.from_numpy(lon[t]).to(dev) for t in range(6)]; lat_t = [torch.from_numpy(lat[t]).to(dev) for t in range(6)]
-lo_t, la_t = torch.from_numpy(lo).to(dev), torch.from_numpy(la).to(dev)
-data = torch.randn(nz, 6 * (ni + 2) ** 2, dtype=torch.float64, device=dev)
-gx = torch.randn(nz, 6 * ni * ni, dtype=torch.float64, device=dev); gy = torch.randn(nz, 6 * ni * ni, dtype=torch.float64, device=dev)
-out = torch.empty(nz * nlon * nlat, dtype=torch.float64, device=dev)
+rng = np.random.default_rng(0)
+h2d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+out = h2d(np.zeros(nz * nlon * nlat))
+if mode == "gc":
+    xin = [tuple(h2d(a) for a in fg.latlon2xyz(lon[t], lat[t])) for t in range(6)]
+    xout = tuple(h2d(a) for a in fg.latlon2xyz(lo, la))
+    data = h2d(rng.standard_normal((nz, 6 * ni * ni)))
+else:
+    lon_t = [h2d(lon[t]) for t in range(6)]; lat_t = [h2d(lat[t]) for t in range(6)]
+    lo_t, la_t = h2d(lo), h2d(la)
+    data = h2d(rng.standard_normal((nz, 6 * (ni + 2) ** 2)))
+    gx = h2d(rng.standard_normal((nz, 6 * ni * ni))); gy = h2d(rng.standard_normal((nz, 6 * ni * ni)))
 torch.cuda.synchronize()
 for it in range(steps):
-    p = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, nlat, lo_t, la_t, np.pi / nlat, 2 * np.pi / nlon)
-    p.finalize()
-    p.apply(data, out, nz=nz, grad_x_t=gx, grad_y_t=gy)
+    if mode == "gc":
+        p = fg.XgridPlan.create_great_circle_dev([ni] * 6, [ni] * 6, xin, nlon, nlat, xout, np.pi / nlat, 2 * np.pi / nlon)
+        p.finalize()
+        p.apply(data, out, nz=nz)
+    else:
+        p = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, nlat, lo_t, la_t, np.pi / nlat, 2 * np.pi / nlon)
+        p.finalize()
+        p.apply(data, out, nz=nz, grad_x_t=gx, grad_y_t=gy)
     p.sync()
     if it < steps - 1: p.destroy()
 print("nxgrid", p.nxgrid)
