@@ -103,6 +103,25 @@ __device__ int gc_inside_polygon(const GcNode &node, const GcList &l)
 
 // intersect_tri_with_line + invert_matrix_3x3 + mult (mosaic_util.c:967-1044) on the software x87; the third plane
 // point is the origin.  Only t = X[0] is consumed by line_intersect_2D_3D.
+// Double-precision screen of one plane/segment solve: when the system is well conditioned
+// (det^2 > 1e-6 * |l1-l2|^2 * |pnt1-pnt0|^2, both edges longer than 1e-4 rad) the double solution is within ~1e-10 of
+// the extended one, and stays within 1e-6 of it when an endpoint is later snapped onto an intersection (a move of at most
+// 1e-10 absolute or 1e-8 of an edge), so a t outside [-1e-5, 1+1e-5] is certainly outside the reference's accepted
+// range [-1e-8, 1+1e-8] (create_xgrid.c:1993-2001): line_intersect_2D_3D returns 0 for that edge pair.
+__device__ bool gc_screen_out(const double *pnt0, const double *pnt1, const double *l1, const double *l2)
+{
+  const double d0 = l1[0] - l2[0], d1 = pnt1[0] - pnt0[0], d2 = 0.0 - pnt0[0];
+  const double d3 = l1[1] - l2[1], d4 = pnt1[1] - pnt0[1], d5 = 0.0 - pnt0[1];
+  const double d6 = l1[2] - l2[2], d7 = pnt1[2] - pnt0[2], d8 = 0.0 - pnt0[2];
+  const double e0 = d4 * d8 - d5 * d7, e1 = d3 * d8 - d5 * d6, e2 = d3 * d7 - d4 * d6;
+  const double det = d0 * e0 - d1 * e1 + d2 * e2;
+  const double n1 = d0 * d0 + d3 * d3 + d6 * d6, n2 = d1 * d1 + d4 * d4 + d7 * d7;
+  if (!(n1 > 1.e-8 && n2 > 1.e-8 && det * det > 1.e-6 * n1 * n2)) return false;
+  const double v0 = l1[0] - pnt0[0], v1 = l1[1] - pnt0[1], v2 = l1[2] - pnt0[2];
+  const double td = (e0 * v0 + (d2 * d7 - d1 * d8) * v1 + (d1 * d5 - d2 * d4) * v2) / det;
+  return td < -1.e-5 || td > 1.0 + 1.e-5;
+}
+
 __device__ bool gc_tri_line_t(const double *pnt0, const double *pnt1, const double *l1, const double *l2, double *t)
 {
   const x80 m0 = x80_from_double(l1[0] - l2[0]), m1 = x80_from_double(pnt1[0] - pnt0[0]), m2 = x80_from_double(0.0 - pnt0[0]);
@@ -372,6 +391,296 @@ __device__ int gc_clip(const double *a, const double *b, GcPoly &out)
   return n_out;
 }
 
+// ------------------------------------------------------------------------------------------------ compact clip
+// The same algorithm with ~0.5 KB of per-lane state instead of 2.6 KB (k_gc_clip was bound by scratch traffic:
+// 65 GB per launch at C384, profiles/r01_summary.md).  Coordinates live once in three small tables -- the two vertex
+// arrays (which ARE the reference's pt1/pt2 arrays, create_xgrid.c:1589-1598: a vertex node and its pt entry are always
+// rewritten together, :1639-1665) and the intersections (each appears in both grid lists with the same coordinates);
+// the lists are byte codes packed in one 128-bit register value:
+//   bits 0-3 ref (0..3 own vertex, 4..15 intersection ref-4), bits 4-5 intersect (0/1/2), bit 6 isInside.
+// Every search stays a search by coordinate VALUE in list order, as in the reference.  The two situations the shared
+// tables cannot represent (an anchor search that lands on a node other than the expected vertex while a vertex is being
+// rewritten) return GC_FALLBACK and the pair is redone by the array version above (k_gc_clip_slow); they need two
+// distinct nodes with bit-identical coordinates and have not been observed.
+#define GC_FALLBACK (-10)
+#define GC_FI 8             // intersections kept by the compact version (two convex quads cross at most 8 times)
+typedef unsigned __int128 gc_u128;
+struct GcPacked { gc_u128 bits; int n; };
+__device__ __forceinline__ unsigned gcp_get(const GcPacked &l, int k) { return (unsigned)(l.bits >> (8 * k)) & 0xffu; }
+__device__ __forceinline__ void gcp_set(GcPacked &l, int k, unsigned v)
+{
+  l.bits = (l.bits & ~((gc_u128)0xff << (8 * k))) | ((gc_u128)(v & 0xffu) << (8 * k));
+}
+__device__ __forceinline__ void gcp_insert(GcPacked &l, int k, unsigned v)
+{
+  const gc_u128 low = (k == 0) ? (gc_u128)0 : (l.bits & (((gc_u128)1 << (8 * k)) - 1));
+  const gc_u128 high = (l.bits >> (8 * k)) << (8 * (k + 1));
+  l.bits = low | ((gc_u128)(v & 0xffu) << (8 * k)) | high;
+  l.n++;
+}
+#define GCN_REF(c) ((c) & 15u)
+#define GCN_INTER(c) (((c) >> 4) & 3u)
+#define GCN_INSIDE(c) (((c) >> 6) & 1u)
+
+struct GcTables {
+  double vt[2][4][3];        // pt1 / pt2
+  double ix[GC_FI][3];       // intersection coordinates
+  double iu[GC_FI][2];       // u along the grid-1 edge, u along the grid-2 edge (0 when snapped onto a vertex)
+  unsigned imeta[GC_FI];     // subj_index | clip_index << 4 | inbound << 8
+};
+__device__ __forceinline__ const double *gct_xyz(const GcTables &T, int L, unsigned code)
+{
+  const unsigned r = GCN_REF(code);
+  return (r < 4) ? T.vt[L][r] : T.ix[r - 4];
+}
+__device__ __forceinline__ int gcp_find(const GcTables &T, int L, const GcPacked &l, double x, double y, double z)
+{
+  for (int k = 0; k < l.n; k++) {
+    const double *q = gct_xyz(T, L, gcp_get(l, k));
+    if (q[0] == x && q[1] == y && q[2] == z) return k;
+  }
+  return -1;
+}
+
+// insidePolygon against the (not yet modified) vertices of list L
+__device__ int gcf_inside(const double *pnt0, const GcTables &T, int L, int n)
+{
+  double anglesum = 0;
+  for (int k = 0; k < n; k++) {
+    const int kn = (k + 1 < n) ? k + 1 : 0;
+    const double *pnt1 = T.vt[L][k], *pnt2 = T.vt[L][kn];
+    if (gc_same_point(pnt0[0], pnt0[1], pnt0[2], pnt1[0], pnt1[1], pnt1[2])) return 1;
+    anglesum += gc_spherical_angle<false>(pnt0, pnt2, pnt1);
+  }
+  double dev = fabs(anglesum - 2 * GC_PI);
+  if (fabs(dev - GC_EPSLN8) < 1.e-12) {
+    anglesum = 0;
+    for (int k = 0; k < n; k++) {
+      const int kn = (k + 1 < n) ? k + 1 : 0;
+      anglesum += gc_spherical_angle<true>(pnt0, T.vt[L][kn], T.vt[L][k]);
+    }
+    dev = fabs(anglesum - 2 * GC_PI);
+  }
+  return dev < GC_EPSLN8;
+}
+
+// insertIntersect (mosaic_util.c:1313-1397) on the packed list L.  expect = vertex index whose pt entry the caller
+// rewrites when u_cur == 0; iref = index of the intersection in the tables.
+__device__ int gcf_insert(GcTables &T, int L, GcPacked &l, const double *I, double u_cur, double u2, int inbound,
+                          const double *anchor, int expect, int iref)
+{
+  int k1 = gcp_find(T, L, l, anchor[0], anchor[1], anchor[2]);
+  if (k1 < 0) return -7;
+  if (u_cur == 0) {
+    const unsigned c = gcp_get(l, k1);
+    if ((int)GCN_REF(c) != expect) return GC_FALLBACK;
+    gcp_set(l, k1, (c & 15u) | (2u << 4) | (1u << 6));        // intersect = 2, isInside = 1; coordinates: caller rewrites vt
+    return 0;
+  }
+  if (u2 != 0 && u2 != 1) {
+    if (inbound == 1) {
+      int k2 = (k1 + 1 < l.n) ? k1 + 1 : 0, guard = 0;
+      while (GCN_INTER(gcp_get(l, k2))) { k2 = (k2 + 1 < l.n) ? k2 + 1 : 0; if (++guard > 32) return -7; }
+      gcp_set(l, k2, gcp_get(l, k2) & ~(1u << 6));
+    } else if (inbound == 2)
+      gcp_set(l, k1, gcp_get(l, k1) & ~(1u << 6));
+  }
+  int k2 = k1 + 1;
+  while (k2 < l.n) {
+    const unsigned c = gcp_get(l, k2);
+    if (GCN_INTER(c) == 1) { if (T.iu[GCN_REF(c) - 4][L] > u_cur) break; }
+    else break;
+    k2++;
+  }
+  if (l.n >= 12) return -9;
+  gcp_insert(l, k2, (unsigned)(4 + iref) | (1u << 4) | (1u << 6));
+  return 0;
+}
+
+// output polygon as refs: 0..3 grid-1 vertex, 4..7 grid-2 vertex, 8.. intersection; dedup by samePoint like addEnd
+struct GcPolyRefs { unsigned long long bits; int n; };
+__device__ __forceinline__ const double *gcpoly_xyz(const GcTables &T, unsigned r)
+{
+  return (r < 4) ? T.vt[0][r] : (r < 8 ? T.vt[1][r - 4] : T.ix[r - 8]);
+}
+__device__ int gcpoly_add(const GcTables &T, GcPolyRefs &pl, int L, unsigned code)
+{
+  const unsigned r = (GCN_REF(code) < 4) ? GCN_REF(code) + 4u * L : GCN_REF(code) + 4u;
+  const double *q = gcpoly_xyz(T, r);
+  for (int k = 0; k < pl.n; k++) {
+    const double *e = gcpoly_xyz(T, (unsigned)(pl.bits >> (4 * k)) & 15u);
+    if (gc_same_point(e[0], e[1], e[2], q[0], q[1], q[2])) return 0;
+  }
+  if (pl.n >= 16) return -9;
+  pl.bits |= (unsigned long long)r << (4 * pl.n);
+  pl.n++;
+  return 0;
+}
+
+// Returns n_out and the polygon coordinates in out[n_out][3], GC_FALLBACK, or a negative error code.
+__device__ int gc_clip_fast(const double *a, const double *b, double *out)
+{
+  GcTables T;
+  GcPacked g[2];
+  int nil = 0;
+  // addEnd: de-duplicated corners; pt arrays are filled from the lists (create_xgrid.c:1589-1598)
+  for (int L = 0; L < 2; L++) {
+    const double *v = L ? b : a;
+    int n = 0;
+    g[L].bits = 0;
+    for (int i = 0; i < 4; i++) {
+      bool dup = false;
+      for (int m = 0; m < n; m++) if (gc_same_point(T.vt[L][m][0], T.vt[L][m][1], T.vt[L][m][2], v[i * 3], v[i * 3 + 1], v[i * 3 + 2])) dup = true;
+      if (dup) continue;
+      T.vt[L][n][0] = v[i * 3]; T.vt[L][n][1] = v[i * 3 + 1]; T.vt[L][n][2] = v[i * 3 + 2];
+      g[L].bits |= (gc_u128)(unsigned)n << (8 * n);
+      n++;
+    }
+    g[L].n = n;
+  }
+  const int npts1 = g[0].n, npts2 = g[1].n;
+  for (int L = 0; L < 2; L++)
+    for (int k = 0; k < g[L].n; k++)
+      if (gcf_inside(T.vt[L][k], T, 1 - L, g[1 - L].n)) gcp_set(g[L], k, gcp_get(g[L], k) | (1u << 6));
+
+  // pass 1 (all lanes, double only): edge pairs that certainly do not intersect.  Lanes then loop only over their
+  // remaining pairs, in the reference's (i1, i2) order -- a wave runs max-over-lanes of ~4-8 extended solves instead of 16.
+  unsigned need = 0;
+  for (int i1 = 0; i1 < npts1; i1++) {
+    const int i1p = (i1 + 1) % npts1;
+    for (int i2 = 0; i2 < npts2; i2++) {
+      const int i2p = (i2 + 1) % npts2;
+      const bool out = gc_screen_out(T.vt[1][i2], T.vt[1][i2p], T.vt[0][i1], T.vt[0][i1p]) ||
+                       gc_screen_out(T.vt[0][i1], T.vt[0][i1p], T.vt[1][i2], T.vt[1][i2p]);
+      if (!out) need |= 1u << (i1 * 4 + i2);
+    }
+  }
+  while (need) {
+    const int bit = __ffs((int)need) - 1;
+    need &= need - 1;
+    const int i1 = bit >> 2, i2 = bit & 3;
+    {
+      const int i1p = (i1 + 1) % npts1;
+      const int i2p = (i2 + 1) % npts2, i2p2 = (i2 + 2) % npts2;
+      double *p1_0 = T.vt[0][i1], *p1_1 = T.vt[0][i1p], *p2_0 = T.vt[1][i2], *p2_1 = T.vt[1][i2p], *p2_2 = T.vt[1][i2p2];
+      double I[3], u1, u2;
+      int inbound;
+      if (!gc_line_intersect(p1_0, p1_1, p2_0, p2_1, p2_2, I, &u1, &u2, &inbound)) continue;
+      double u1c = u1, u2c = u2;
+      int i1c = i1, i2c = i2;
+      if (u1c == 1) { u1c = 0; i1c = i1p; }
+      if (u2c == 1) { u2c = 0; i2c = i2p; }
+      bool dup = false;
+      for (int k = 0; k < nil; k++) {
+        if (T.iu[k][0] == u1c && (int)(T.imeta[k] & 15u) == i1c) { dup = true; break; }
+        if (T.iu[k][1] == u2c && (int)((T.imeta[k] >> 4) & 15u) == i2c) { dup = true; break; }
+      }
+      if (dup) continue;
+      if (nil >= GC_FI) return GC_FALLBACK;
+      const int iref = nil++;
+      T.ix[iref][0] = I[0]; T.ix[iref][1] = I[1]; T.ix[iref][2] = I[2];
+      T.iu[iref][0] = u1c; T.iu[iref][1] = u2c;
+      T.imeta[iref] = (unsigned)i1c | ((unsigned)i2c << 4) | ((unsigned)inbound << 8);
+      int rc;
+      if (u1 == 1) rc = gcf_insert(T, 0, g[0], I, 0.0, u2, inbound, p1_1, i1p, iref);
+      else rc = gcf_insert(T, 0, g[0], I, u1, u2, inbound, p1_0, i1, iref);
+      if (rc) return rc;
+      if (u1 == 1) { p1_1[0] = I[0]; p1_1[1] = I[1]; p1_1[2] = I[2]; }
+      else if (u1 == 0) { p1_0[0] = I[0]; p1_0[1] = I[1]; p1_0[2] = I[2]; }
+      if (u2 == 1) rc = gcf_insert(T, 1, g[1], I, 0.0, u1, 0, p2_1, i2p, iref);
+      else rc = gcf_insert(T, 1, g[1], I, u2, u1, 0, p2_0, i2, iref);
+      if (rc) return rc;
+      if (u2 == 1) { p2_1[0] = I[0]; p2_1[1] = I[1]; p2_1[2] = I[2]; }
+      else if (u2 == 0) { p2_0[0] = I[0]; p2_0[1] = I[1]; p2_0[2] = I[2]; }
+    }
+  }
+
+  int nintersect = nil, first = -1;
+  if (nintersect > 1) for (int k = 0; k < nil; k++) if (((T.imeta[k] >> 8) & 3u) == 2) { first = k; break; }
+  if (first < 0 && nintersect > 1) {
+    for (int k = 0; k < nil; k++) {
+      if ((T.imeta[k] >> 8) & 3u) continue;
+      const int f = gcp_find(T, 0, g[0], T.ix[k][0], T.ix[k][1], T.ix[k][2]);
+      if (f < 0) return -8;
+      const unsigned prev = gcp_get(g[0], f > 0 ? f - 1 : g[0].n - 1), next = gcp_get(g[0], f + 1 < g[0].n ? f + 1 : 0);
+      T.imeta[k] |= ((GCN_INSIDE(prev) == 0 && GCN_INSIDE(next) == 1) ? 2u : 1u) << 8;
+    }
+    for (int k = 0; k < nil; k++) if (((T.imeta[k] >> 8) & 3u) == 2) { first = k; break; }
+  }
+
+  int n_out = 0;
+  GcPolyRefs poly; poly.bits = 0; poly.n = 0;
+  if (first >= 0) {
+    const double fx = T.ix[first][0], fy = T.ix[first][1], fz = T.ix[first][2];
+    const int maxiter1 = nintersect;
+    const int kf = gcp_find(T, 0, g[0], fx, fy, fz);
+    if (kf < 0) return -3;
+    // addNode(polyList, firstIntersect): the coordinates of the intersection-list entry
+    poly.bits = (unsigned long long)(8 + first); poly.n = 1;
+    nintersect--;
+    int L = 0, iter1 = 0, found1 = 0, found2 = 0;
+    double cx = fx, cy = fy, cz = fz;
+    unsigned ccode = 0;
+    while (iter1 < maxiter1) {
+      const int k1 = gcp_find(T, L, g[L], cx, cy, cz);
+      if (k1 < 0) return -4;
+      int k2 = (k1 + 1 < g[L].n) ? k1 + 1 : 0;
+      const int maxiter2 = g[L].n;
+      int iter2 = 0;
+      found2 = 0;
+      while (iter2 < maxiter2) {
+        int t2_is_inter = 0;
+        const unsigned c2 = gcp_get(g[L], k2);
+        const double *q2 = gct_xyz(T, L, c2);
+        if (GCN_INTER(c2)) {
+          if (q2[0] == fx && q2[1] == fy && q2[2] == fz) { found1 = 1; break; }
+          const unsigned c3 = gcp_get(g[L], (k2 + 1 < g[L].n) ? k2 + 1 : 0);
+          found2 = 1;
+          t2_is_inter = 1;
+          if (GCN_INTER(c3) || GCN_INSIDE(c3) == 1) found2 = 0;
+        }
+        if (found2) { cx = q2[0]; cy = q2[1]; cz = q2[2]; ccode = c2; break; }
+        else {
+          if (gcpoly_add(T, poly, L, c2)) return -9;
+          if (t2_is_inter) nintersect--;
+        }
+        k2 = (k2 + 1 < g[L].n) ? k2 + 1 : 0;
+        iter2++;
+      }
+      if (found1) break;
+      if (!found2) return -4;
+      if (cx == fx && cy == fy && cz == fz) { found1 = 1; break; }
+      if (gcpoly_add(T, poly, L, ccode)) return -9;
+      nintersect--;
+      L = 1 - L;
+      iter1++;
+    }
+    if (!found1) return -5;
+    if (nintersect > 0) return -6;
+    n_out = poly.n;
+    if (n_out < 3) n_out = 0;
+    for (int k = 0; k < n_out; k++) {
+      const double *q = gcpoly_xyz(T, (unsigned)(poly.bits >> (4 * k)) & 15u);
+      out[k * 3] = q[0]; out[k * 3 + 1] = q[1]; out[k * 3 + 2] = q[2];
+    }
+  }
+  if (n_out == 0) {
+    for (int L = 0; L < 2 && n_out == 0; L++) {        // grid1 inside grid2 (:1839-1870), then grid2 inside grid1 (:1873-1904)
+      const int npts = L ? npts2 : npts1;
+      int nin = 0;
+      for (int k = 0; k < g[L].n; k++) { const unsigned c = gcp_get(g[L], k); if (GCN_INTER(c) != 1 && GCN_INSIDE(c) == 1) nin++; }
+      if (npts == nin) {
+        n_out = npts;
+        for (int k = 0; k < npts; k++) {
+          const double *q = gct_xyz(T, L, gcp_get(g[L], k));
+          out[k * 3] = q[0]; out[k * 3 + 1] = q[1]; out[k * 3 + 2] = q[2];
+        }
+      }
+    }
+  }
+  return n_out;
+}
+
 // ------------------------------------------------------------------------------------------------ cell records
 // FgCells reuse: verts[c*16 + 0..11] = corners xyz (clockwise), [12..14] = cap centre, [15] = cos(cap radius), or -2
 // when the cell is too large for a useful cap.  lat/lon box = the cap's, so the candidate scan is a superset.
@@ -448,50 +757,77 @@ __global__ __launch_bounds__(256) void k_gc_cell_struct(const FgTileXyz *tiles, 
   }
 }
 
-// ------------------------------------------------------------------------------------------------ pair kernel
+// ------------------------------------------------------------------------------------------------ pair kernels
 #ifndef GC_WAVES_PER_EU
-#define GC_WAVES_PER_EU 4   // measured on MI355X (C384 -> 0.25 deg): 1: 46.8 ms, 2: 27.0, 3: 21.0, 4: 19.9, 5: 23.1 -- latency bound on scratch
+#define GC_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_WAVES_PER_EU, GC_WAVES_PER_EU))) void k_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask,
-                                                 FgCells D, double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err)
+// the reference's bounding-box reject, convexity check and the cap reject; true = pair survives
+__device__ bool gc_prefilter(const double *a, const double *b, double area1, double area2, unsigned *err)
 {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npairs) return;
-  const int s = pair_src[p], d = pair_dst[p];
-  const double *a = S.verts + (size_t)s * 16, *b = D.verts + (size_t)d * 16;
-  // create_xgrid.c:1508-1528
-  bool far = false;
-  for (int ax = 0; ax < 3 && !far; ax++) {
+  for (int ax = 0; ax < 3; ax++) {                               // create_xgrid.c:1508-1528
     double mn1 = a[ax], mx1 = a[ax], mn2 = b[ax], mx2 = b[ax];
     for (int k = 1; k < 4; k++) {
       mn1 = fmin(mn1, a[k * 3 + ax]); mx1 = fmax(mx1, a[k * 3 + ax]);
       mn2 = fmin(mn2, b[k * 3 + ax]); mx2 = fmax(mx2, b[k * 3 + ax]);
     }
-    if (mn1 >= mx2 + GC_RANGE_CHECK || mn2 >= mx1 + GC_RANGE_CHECK) far = true;
+    if (mn1 >= mx2 + GC_RANGE_CHECK || mn2 >= mx1 + GC_RANGE_CHECK) return false;
   }
-  if (far) { pair_dst[p] = -1; return; }
-  const double area1 = S.area[s], area2 = D.area[d];
-  if (area1 <= 0) atomicOr(err, G_ERRBIT_GC_CONVEX1);         // :1575-1578 (fatal in the reference)
+  if (area1 <= 0) atomicOr(err, G_ERRBIT_GC_CONVEX1);            // :1575-1578 (fatal in the reference)
   if (area2 <= 0) atomicOr(err, G_ERRBIT_GC_CONVEX2);
-  if (area1 <= 0 || area2 <= 0) { pair_dst[p] = -1; return; }
+  if (area1 <= 0 || area2 <= 0) return false;
   // caps further apart than the sum of their radii (+2e-6 rad each): no vertex inside, no edge crossing
   if (a[15] > -1.5 && b[15] > -1.5) {
     const double dotc = a[12] * b[12] + a[13] * b[13] + a[14] * b[14];
     const double sr1 = sqrt(fmax(0.0, 1.0 - a[15] * a[15])), sr2 = sqrt(fmax(0.0, 1.0 - b[15] * b[15]));
     const double cos_sum = a[15] * b[15] - sr1 * sr2;
-    if (dotc < cos_sum - 1.e-12) { pair_dst[p] = -1; return; }
+    if (dotc < cos_sum - 1.e-12) return false;
   }
-  GcPoly out;
-  const int n_out = gc_clip(a, b, out);
+  return true;
+}
+
+__device__ void gc_finish(int p, int s, int n_out, const double *poly, double m, double area1, double area2, int *pair_dst,
+                          double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err)
+{
   if (n_out < 0) { atomicOr(err, G_ERRBIT_GC_CLIP); atomicMax((int *)(err + 1), -n_out); pair_dst[p] = -1; return; }
   if (n_out == 0) { pair_dst[p] = -1; return; }
-  const double m = mask ? mask[s] : 1.0;
-  const double xarea = gc_area(n_out, &out.p[0][0], 3) * m;
+  const double xarea = gc_area(n_out, poly, 3) * m;
   const double min_area = (area1 < area2) ? area1 : area2;
   const double ratio = xarea / min_area;
   if (fabs(ratio - 1.e-6) < 1.e-12) atomicAdd(&stats[FG_STAT_BORDERLINE], 1ull);
   if (ratio > 1.e-6) { tmp_area[p] = xarea; atomicAdd(&nacc[s], 1); }
   else { pair_dst[p] = -1; atomicAdd(&stats[FG_STAT_BELOW], 1ull); }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_WAVES_PER_EU, GC_WAVES_PER_EU)))
+void k_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D, double *tmp_area, int *nacc,
+               int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  const int s = pair_src[p], d = pair_dst[p];
+  const double *a = S.verts + (size_t)s * 16, *b = D.verts + (size_t)d * 16;
+  const double area1 = S.area[s], area2 = D.area[d];
+  if (!gc_prefilter(a, b, area1, area2, err)) { pair_dst[p] = -1; return; }
+  double poly[16 * 3];
+  const int n_out = gc_clip_fast(a, b, poly);
+  if (n_out == GC_FALLBACK) { defer_list[atomicAdd(defer_cnt, 1)] = p; return; }
+  gc_finish(p, s, n_out, poly, mask ? mask[s] : 1.0, area1, area2, pair_dst, tmp_area, nacc, stats, err);
+}
+
+// pairs the compact version handed back: the array version (prefilter already passed)
+__global__ __launch_bounds__(64) void k_gc_clip_slow(const int *defer_list, const int *defer_cnt, const int *pair_src, int *pair_dst,
+                                                      FgCells S, const double *mask, FgCells D, double *tmp_area, int *nacc,
+                                                      unsigned long long *stats, unsigned *err)
+{
+  const int nd = *defer_cnt;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nd; q += gridDim.x * blockDim.x) {
+    const int p = defer_list[q];
+    const int s = pair_src[p], d = pair_dst[p];
+    const double *a = S.verts + (size_t)s * 16, *b = D.verts + (size_t)d * 16;
+    GcPoly out;
+    const int n_out = gc_clip(a, b, out);
+    gc_finish(p, s, n_out, &out.p[0][0], mask ? mask[s] : 1.0, S.area[s], D.area[d], pair_dst, tmp_area, nacc, stats, err);
+  }
 }
 
 static inline int gc_nblk(long n, int t) { return (int)((n + t - 1) / t); }
@@ -502,9 +838,11 @@ void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCe
 }
 
 void fgd_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
-                 double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err, hipStream_t st)
+                 double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st)
 {
-  if (npairs > 0) k_gc_clip<<<gc_nblk(npairs, 64), 64, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, nacc, stats, err);
+  if (npairs <= 0) return;
+  k_gc_clip<<<gc_nblk(npairs, 64), 64, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, nacc, defer_list, defer_cnt, stats, err);
+  k_gc_clip_slow<<<64, 64, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, nacc, stats, err);
 }
 
 // ------------------------------------------------------------------------------------------------ batch primitives
@@ -537,7 +875,12 @@ __global__ __launch_bounds__(64) void k_gc_clip_batch(int n, const double *a, co
       }
       if (gc_area(n, q, 3) <= 0) no = which ? -2 : -1;
     }
-    if (no == 0) no = gc_clip(pa, pb, o);
+    if (no == 0) {
+      double q[16 * 3];
+      no = gc_clip_fast(pa, pb, q);
+      if (no == GC_FALLBACK) no = gc_clip(pa, pb, o);
+      else for (int k = 0; k < no; k++) { o.p[k][0] = q[k * 3]; o.p[k][1] = q[k * 3 + 1]; o.p[k][2] = q[k * 3 + 2]; }
+    }
   }
   n_out[p] = no;
   for (int k = 0; k < GC_PCAP; k++) for (int ax = 0; ax < 3; ax++) out[((size_t)p * GC_PCAP + k) * 3 + ax] = (k < no) ? o.p[k][ax] : 0.0;

@@ -413,7 +413,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   // --- clip, area, centroid integrals (+ accepted count per source cell)
   if (gc) {
     pt.begin(PH_CLIP_GENERAL);
-    fgd_gc_clip(npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, nacc, dc->stats, dc->err, st);
+    fgd_gc_clip(npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
     pt.end();
   } else {
     pt.begin(PH_CLIP_QUAD);

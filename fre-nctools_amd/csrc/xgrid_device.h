@@ -136,7 +136,7 @@ void fgd_mono_limit(long nx, FgCsr csr, const double *f, double missing, const d
 // ---- great-circle path (gc_kernels.hip)
 void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st);
 void fgd_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
-                 double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err, hipStream_t st);
+                 double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st);
 #define FG_GC_POLY_CAP 16
 void fgd_gc_clip_batch(int n, const double *a, const double *b, double *out, int *n_out, double *area, hipStream_t st);
 void fgd_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *n, double *area, hipStream_t st);
