@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--apply-steps", type=int, default=50)
     ap.add_argument("--no-phase-timing", action="store_true", help="do not record per-phase HIP events in the timed region")
     ap.add_argument("--cpu-rows", type=int, default=32, help="source rows in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--gc-steps", type=int, default=3, help="timed great-circle searches of the same grids (N=1 only; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -225,7 +226,8 @@ def main():
                 "achieved": (alg_search / 1e9) / (clip_ms / 1e3) if clip_ms > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "algorithmic_bytes_per_launch": alg_search, "kernel_ms": clip_ms,
-                "note": "FP64-VALU/latency bound polygon clipping, not HBM bound (SURVEY.md §8d); "
+                "note": "FP64-VALU bound polygon clipping, not HBM bound (SURVEY.md §8d): 1.59e8 wave VALU instructions x 4 issue "
+                        "cycles = 77 % of the SIMD cycles of the launch (profiles/r01_summary.md); "
                         "the HBM-bound kernel of the path is the sweep, see roofline_apply"}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
         # sweep: weights streamed once per launch of nz levels + per level the source fields and the output
@@ -263,6 +265,35 @@ def main():
             "phase_ms": phases, "search_stats": stats,
             "roofline": roof, "roofline_apply": roof_a,
         }
+        if world == 1 and args.gc_steps > 0:
+            # BASELINE config 4's clip method on the same grids (create_xgrid_great_circle semantics, first order): unit
+            # vectors made on the host with libm as the reference does (not timed), search timed with inputs resident
+            th = time.perf_counter()
+            xyz_in = [fg.latlon2xyz(lon[t], lat[t]) for t in range(6)]
+            xyz_out = fg.latlon2xyz(lo, la)
+            t_xyz = time.perf_counter() - th
+            xin = [tuple(torch.from_numpy(a).to(dev) for a in t) for t in xyz_in]
+            xout = tuple(torch.from_numpy(a).to(dev) for a in xyz_out)
+            gp = None
+            gc_ph = {}
+            for it in range(args.gc_steps + 1):
+                if it == 1:
+                    torch.cuda.synchronize(); tg = time.perf_counter()
+                if gp is not None:
+                    gp.destroy()
+                gp = fg.XgridPlan.create_great_circle_dev([ni] * 6, [ni] * 6, xin, nlon, nlat, xout, mean_dlat, mean_dlon,
+                                                          device=local_rank)
+                gp.finalize(None)
+                if it >= 1:
+                    for k, v in gp.phase_ms().items():
+                        gc_ph[k] = gc_ph.get(k, 0.0) + v / args.gc_steps
+            gp.sync(); torch.cuda.synchronize()
+            dtg = (time.perf_counter() - tg) / args.gc_steps
+            line["great_circle"] = {"workload": f"C{ni} -> {nlon}x{nlat}, create_xgrid_great_circle semantics, first order",
+                                    "nxgrid": gp.nxgrid, "ms_per_step": dtg * 1e3, "exchange_cells_per_s": gp.nxgrid / dtg,
+                                    "clip_kernel_ms": gc_ph.get("clip_general"), "search_device_ms": gc_ph.get("search_total"),
+                                    "host_latlon2xyz_ms": t_xyz * 1e3, "search_stats": gp.stats()}
+            gp.destroy()
         if world == 1 and args.cpu_rows > 0:
             cb, _, _ = cpu_baseline(fg, lon, lat, lo, la, ni, nlon, nlat, args.cpu_rows)
             line["cpu_baseline"] = cb
