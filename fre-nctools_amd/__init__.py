@@ -155,3 +155,15 @@ def gc_clip_batch(a, b, device=0):
     area = np.zeros(n)
     _lib.check(lib().fg_gc_clip_batch(n, _dp(a), _dp(b), _dp(out), _ip(n_out), _dp(area), device))
     return n_out, out, area
+
+
+def conserve_interp_great_circle(nx_src, ny_src, nx_dst, ny_dst, x_src, y_src, x_dst, y_dst, mask_src, data_src):
+    """interp.c:312 -- first-order remap through the great-circle exchange grid; returns data_dst[ny_dst*nx_dst]."""
+    _lib.require_gpu()
+    x_src, y_src, x_dst, y_dst = _f64(x_src), _f64(y_src), _f64(x_dst), _f64(y_dst)
+    mask = _f64(np.ones(nx_src * ny_src) if mask_src is None else mask_src)
+    data_src = _f64(data_src)
+    out = np.empty(nx_dst * ny_dst, dtype=np.float64)
+    lib().conserve_interp_great_circle(nx_src, ny_src, nx_dst, ny_dst, _dp(x_src), _dp(y_src), _dp(x_dst), _dp(y_dst),
+                                       _dp(mask), _dp(data_src), _dp(out))
+    return out

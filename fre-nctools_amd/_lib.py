@@ -33,7 +33,7 @@ EXPORTS = [
     "fg_plan_mono_minmax_dev", "fg_plan_mono_copy_minmax", "fg_plan_mono_end",
     "fg_plan_create_great_circle", "fg_plan_create_great_circle_dev", "fg_latlon2xyz", "create_xgrid_great_circle",
     "create_xgrid_great_circle_", "get_grid_great_circle_area", "get_grid_great_circle_area_", "clip_2dx2d_great_circle",
-    "great_circle_area", "fg_gc_clip_batch", "fg_plan_stream", "fg_plan_sync",
+    "great_circle_area", "fg_gc_clip_batch", "conserve_interp_great_circle", "fg_plan_stream", "fg_plan_sync",
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
     "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
     "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
@@ -161,6 +161,8 @@ def lib():
     L.clip_2dx2d_great_circle.restype = C.c_int
     L.great_circle_area.argtypes = [C.c_int, dp, dp, dp]
     L.great_circle_area.restype = C.c_double
+    L.conserve_interp_great_circle.argtypes = [C.c_int] * 4 + [dp] * 7
+    L.conserve_interp_great_circle.restype = None
     L.fg_gc_clip_batch.argtypes = [C.c_int, dp, dp, dp, ip, dp, C.c_int]
     L.fg_gc_clip_batch.restype = C.c_int
     L.fg_plan_stream.argtypes = [vp]

@@ -1413,6 +1413,26 @@ extern "C" void conserve_interp(int nx_src, int ny_src, int nx_dst, int ny_dst, 
   fg_plan_destroy(pl);
 }
 
+// interp.c:312 -- the same with the great-circle exchange grid
+extern "C" void conserve_interp_great_circle(int nx_src, int ny_src, int nx_dst, int ny_dst, const double *x_src,
+                                             const double *y_src, const double *x_dst, const double *y_dst,
+                                             const double *mask_src, const double *data_src, double *data_dst)
+{
+  const double *lons[1] = {x_src}, *lats[1] = {y_src}, *masks[1] = {mask_src};
+  fg_plan *pl = nullptr;
+  long nx = fg_plan_create_great_circle(1, &nx_src, &ny_src, lons, lats, masks, nx_dst, ny_dst, x_dst, y_dst, b1_device(), &pl);
+  if (nx < 0) fatal(fg_last_error());
+  if (nx > (long)MAXXGRID) fatal("nxgrid is greater than MAXXGRID, increase MAXXGRID");
+  if (fg_plan_finalize(pl, nullptr)) fatal(fg_last_error());
+  size_t ns = (size_t)nx_src * ny_src, nd = (size_t)nx_dst * ny_dst;
+  double *dsrc = nullptr, *ddst = nullptr;
+  if (hipMalloc(&dsrc, ns * sizeof(double)) != hipSuccess || hipMalloc(&ddst, nd * sizeof(double)) != hipSuccess) fatal("hipMalloc failed");
+  if (hipMemcpy(dsrc, data_src, ns * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) fatal("hipMemcpy failed");
+  if (plan_apply_frac(pl, dsrc, ddst)) fatal(fg_last_error());
+  if (hipMemcpy(data_dst, ddst, nd * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) fatal("hipMemcpy failed");
+  (void)hipFree(dsrc); (void)hipFree(ddst);
+  fg_plan_destroy(pl);
+}
 
 // ----------------------------------------------------------------------------- polygon primitives
 // Batched device versions + the single-polygon libfrencutils symbols built on them.

@@ -375,6 +375,10 @@ int create_xgrid_great_circle_(const int *nlon_in, const int *nlat_in, const int
                                double *xgrid_area, double *xgrid_clon, double *xgrid_clat);
 void get_grid_great_circle_area(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
 void get_grid_great_circle_area_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
+/* interp.c:312: first-order remap through the great-circle exchange grid (same contract as conserve_interp) */
+void conserve_interp_great_circle(int nx_src, int ny_src, int nx_dst, int ny_dst, const double *x_src, const double *y_src,
+                                  const double *x_dst, const double *y_dst, const double *mask_src, const double *data_src,
+                                  double *data_dst);
 int clip_2dx2d_great_circle(const double x1_in[], const double y1_in[], const double z1_in[], int n1_in,
                             const double x2_in[], const double y2_in[], const double z2_in[], int n2_in,
                             double x_out[], double y_out[], double z_out[]);

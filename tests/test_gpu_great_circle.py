@@ -117,3 +117,25 @@ def test_setup_conserve_interp_great_circle_and_sweep(fg, gpu_ok, capsys):
     assert abs(gout - gin) < 1e-10 * abs(gin)
     with pytest.raises(ValueError):
         fg.setup_conserve_interp(6, grid_in, 1, grid_out, [fg.InterpConfig()], fg.CONSERVE_ORDER2 | fg.GREAT_CIRCLE)
+
+
+def test_conserve_interp_great_circle_b1(fg, gpu_ok):
+    """interp.c:312 drop-in against the same formula on the oracle's exchange cells (sum of area fractions per
+    destination cell, in exchange-cell order)."""
+    ni, nlon, nlat = 12, 36, 18
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    rng = np.random.default_rng(9)
+    data = rng.standard_normal(ni * ni) + 2.0
+    mask = np.ones(ni * ni); mask[5] = 0.0
+    got = fg.conserve_interp_great_circle(ni, ni, nlon, nlat, lon[0], lat[0], lo, la, mask, data)
+    o = orc.orc_create_xgrid_gc(ni, ni, nlon, nlat, lon[0], lat[0], lo, la, mask=mask)
+    d = o["j_out"].astype(np.int64) * nlon + o["i_out"]
+    dst_area = np.zeros(nlon * nlat)
+    for k in range(o["n"]):
+        dst_area[d[k]] += o["area"][k]
+    ref = np.zeros(nlon * nlat)
+    for k in range(o["n"]):
+        ref[d[k]] += data[o["j_in"][k] * ni + o["i_in"][k]] * (o["area"][k] / dst_area[d[k]])
+    assert np.max(np.abs(got - ref)) < 1e-12 * np.max(np.abs(ref))
+    assert np.count_nonzero(got) == np.count_nonzero(ref) > 0
