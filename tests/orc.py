@@ -84,6 +84,16 @@ def oracle():
         L.orc_latlon2xyz.restype = None
         L.orc_create_xgrid_great_circle_rows.argtypes = [C.c_int] * 4 + [dp] * 5 + [C.c_int, C.c_int, C.c_long] + [ip] * 4 + [dp] * 3
         L.orc_create_xgrid_great_circle_rows.restype = C.c_long
+        L.orc_clip.argtypes = [dp, dp, C.c_int] + [C.c_double] * 4 + [dp, dp]
+        L.orc_clip.restype = C.c_int
+        L.orc_box_ctrlat.argtypes = [C.c_double] * 4
+        L.orc_box_ctrlat.restype = C.c_double
+        L.orc_box_ctrlon.argtypes = [C.c_double] * 5
+        L.orc_box_ctrlon.restype = C.c_double
+        L.orc_get_grid_area_no_adjust.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+        L.orc_get_grid_area_no_adjust.restype = None
+        L.orc_create_xgrid_box.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, dp, dp, dp, C.c_long] + [ip] * 4 + [dp] * 3
+        L.orc_create_xgrid_box.restype = C.c_long
         _ORACLE = L
     return _ORACLE
 
@@ -127,6 +137,20 @@ def ref():
         L.get_grid_great_circle_area.restype = None
         L.create_xgrid_great_circle.argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp] * 3
         L.create_xgrid_great_circle.restype = C.c_int
+        L.clip.argtypes = [dp, dp, C.c_int] + [C.c_double] * 4 + [dp, dp]
+        L.clip.restype = C.c_int
+        L.box_ctrlat.argtypes = [C.c_double] * 4
+        L.box_ctrlat.restype = C.c_double
+        L.box_ctrlon.argtypes = [C.c_double] * 5
+        L.box_ctrlon.restype = C.c_double
+        L.get_grid_area_no_adjust.argtypes = [cip, cip, dp, dp, dp]
+        L.get_grid_area_no_adjust.restype = None
+        for nm in ("create_xgrid_1dx2d_order1", "create_xgrid_2dx1d_order1"):
+            getattr(L, nm).argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp]
+            getattr(L, nm).restype = C.c_int
+        for nm in ("create_xgrid_1dx2d_order2", "create_xgrid_2dx1d_order2"):
+            getattr(L, nm).argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp] * 3
+            getattr(L, nm).restype = C.c_int
         _REF = L
     return _REF
 
@@ -327,3 +351,50 @@ def ref_get_grid_gc_area(nx, ny, lon, lat):
     a = np.empty(nx * ny)
     ref().get_grid_great_circle_area(C.byref(C.c_int(nx)), C.byref(C.c_int(ny)), _dp(lon), _dp(lat), _dp(a))
     return a
+
+
+def orc_create_xgrid_box(box_is_src, order, lon_b, lat_b, nxq, nyq, lon_q, lat_q, mask=None):
+    """create_xgrid_1dx2d (box_is_src) / create_xgrid_2dx1d, order 1 or 2; lon_b/lat_b are the 1-D bounds."""
+    L = oracle()
+    lon_b, lat_b, lon_q, lat_q = f64(lon_b).ravel(), f64(lat_b).ravel(), f64(lon_q).ravel(), f64(lat_q).ravel()
+    nxb, nyb = lon_b.size - 1, lat_b.size - 1
+    nm = nxb * nyb if box_is_src else nxq * nyq
+    mask = f64(np.ones(nm) if mask is None else mask).ravel()
+    cap = 16 * (nxb * nyb + nxq * nyq) + 1024
+    ii, ji, io, jo = (np.empty(cap, dtype=np.int32) for _ in range(4))
+    a, cl, ct = np.empty(cap), np.empty(cap), np.empty(cap)
+    n = L.orc_create_xgrid_box(1 if box_is_src else 0, order, nxb, nyb, _dp(lon_b), _dp(lat_b), nxq, nyq, _dp(lon_q), _dp(lat_q),
+                               _dp(mask), cap, _ip(ii), _ip(ji), _ip(io), _ip(jo), _dp(a), _dp(cl), _dp(ct))
+    assert n >= 0
+    out = dict(n=int(n), i_in=ii[:n].copy(), j_in=ji[:n].copy(), i_out=io[:n].copy(), j_out=jo[:n].copy(), area=a[:n].copy())
+    if order == 2:
+        out["clon"], out["clat"] = cl[:n].copy(), ct[:n].copy()
+    return out
+
+
+def ref_create_xgrid_box(box_is_src, order, lon_b, lat_b, nxq, nyq, lon_q, lat_q, mask=None):
+    L = ref()
+    lon_b, lat_b, lon_q, lat_q = f64(lon_b).ravel(), f64(lat_b).ravel(), f64(lon_q).ravel(), f64(lat_q).ravel()
+    nxb, nyb = lon_b.size - 1, lat_b.size - 1
+    nm = nxb * nyb if box_is_src else nxq * nyq
+    mask = f64(np.ones(nm) if mask is None else mask).ravel()
+    cap = 5000000
+    ii, ji, io, jo = (np.empty(cap, dtype=np.int32) for _ in range(4))
+    a, cl, ct = np.empty(cap), np.empty(cap), np.empty(cap)
+    ci = lambda v: C.byref(C.c_int(v))
+    if box_is_src:
+        sizes = [ci(nxb), ci(nyb), ci(nxq), ci(nyq)]
+        grids = [_dp(lon_b), _dp(lat_b), _dp(lon_q), _dp(lat_q)]
+        fn = L.create_xgrid_1dx2d_order1 if order == 1 else L.create_xgrid_1dx2d_order2
+    else:
+        sizes = [ci(nxq), ci(nyq), ci(nxb), ci(nyb)]
+        grids = [_dp(lon_q), _dp(lat_q), _dp(lon_b), _dp(lat_b)]
+        fn = L.create_xgrid_2dx1d_order1 if order == 1 else L.create_xgrid_2dx1d_order2
+    args = sizes + grids + [_dp(mask), _ip(ii), _ip(ji), _ip(io), _ip(jo), _dp(a)]
+    if order == 2:
+        args += [_dp(cl), _dp(ct)]
+    n = fn(*args)
+    out = dict(n=int(n), i_in=ii[:n].copy(), j_in=ji[:n].copy(), i_out=io[:n].copy(), j_out=jo[:n].copy(), area=a[:n].copy())
+    if order == 2:
+        out["clon"], out["clat"] = cl[:n].copy(), ct[:n].copy()
+    return out

@@ -178,3 +178,58 @@ def test_great_circle_clip_vertices_bitwise(fg):
             assert np.array_equal(u[:no].view(np.uint64), v[:nr].view(np.uint64))
         checked += 1
     assert checked > 500
+
+
+def _box_cases(fg):
+    D2R = np.pi / 180
+    c16 = fg.gnomonic_ed_corners(16)
+    tl, ta = fg.tripolar_corners(40, 24)
+    return {
+        "global_box_vs_cubed_equatorial": (np.linspace(0, 360, 37) * D2R, np.linspace(-90, 90, 19) * D2R, 16, 16, c16[0][0], c16[1][0]),
+        "global_box_vs_cubed_polar": (np.linspace(0, 360, 37) * D2R, np.linspace(-90, 90, 19) * D2R, 16, 16, c16[0][2], c16[1][2]),
+        "shifted_box_vs_tripolar": (np.linspace(-180, 180, 31) * D2R, np.linspace(-80, 88, 22) * D2R, 40, 24, tl, ta),
+        "regional_box_vs_latlon": (np.linspace(20, 80, 13) * D2R, np.linspace(-30, 40, 15) * D2R, 36, 18) + fg.latlon_corners(36, 18),
+        "single_column_box": (np.array([0.0, 360.0]) * D2R, np.linspace(-90, 90, 10) * D2R, 16, 16, c16[0][1], c16[1][1]),
+    }
+
+
+@pytest.mark.parametrize("name", ["global_box_vs_cubed_equatorial", "global_box_vs_cubed_polar", "shifted_box_vs_tripolar",
+                                  "regional_box_vs_latlon", "single_column_box"])
+@pytest.mark.parametrize("box_is_src,order", [(True, 1), (True, 2), (False, 1), (False, 2)])
+def test_box_variants_oracle_bitwise(fg, name, box_is_src, order):
+    """box_oracle.c against the reference's create_xgrid_1dx2d_order1/2 and create_xgrid_2dx1d_order1/2."""
+    lon_b, lat_b, nxq, nyq, lon_q, lat_q = _box_cases(fg)[name]
+    rng = np.random.default_rng(1)
+    nm = (lon_b.size - 1) * (lat_b.size - 1) if box_is_src else nxq * nyq
+    mask = (rng.uniform(size=nm) > 0.15).astype(np.float64)
+    o = orc.orc_create_xgrid_box(box_is_src, order, lon_b, lat_b, nxq, nyq, lon_q, lat_q, mask)
+    r = orc.ref_create_xgrid_box(box_is_src, order, lon_b, lat_b, nxq, nyq, lon_q, lat_q, mask)
+    assert o["n"] == r["n"] and o["n"] > 0
+    for k in ("i_in", "j_in", "i_out", "j_out"):
+        assert np.array_equal(o[k], r[k]), k
+    for k in ("area",) + (("clon", "clat") if order == 2 else ()):
+        assert np.array_equal(o[k].view(np.uint64), r[k].view(np.uint64)), k
+
+
+def test_box_primitives_bitwise(fg):
+    R, O = orc.ref(), orc.oracle()
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        n = int(rng.integers(3, 7))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        x = np.zeros(50); y = np.zeros(50)
+        x[:n] = 1.0 + 0.4 * np.cos(ang); y[:n] = 0.3 + 0.4 * np.sin(ang)
+        box = [float(v) for v in (0.8 + rng.uniform(-.2, .2), 0.1 + rng.uniform(-.2, .2), 1.3 + rng.uniform(-.2, .2), 0.6 + rng.uniform(-.2, .2))]
+        xo1, yo1, xo2, yo2 = (np.zeros(50) for _ in range(4))
+        n1 = O.orc_clip(orc._dp(x), orc._dp(y), n, *box, orc._dp(xo1), orc._dp(yo1))
+        n2 = R.clip(orc._dp(x), orc._dp(y), n, *box, orc._dp(xo2), orc._dp(yo2))
+        assert n1 == n2
+        assert np.array_equal(xo1[:n1].view(np.uint64), xo2[:n2].view(np.uint64)) and np.array_equal(yo1[:n1].view(np.uint64), yo2[:n2].view(np.uint64))
+        clon = float(rng.uniform(0, 6))
+        assert O.orc_box_ctrlat(*box) == R.box_ctrlat(*box)
+        assert O.orc_box_ctrlon(*box, clon) == R.box_ctrlon(*box, clon)
+    lo, la = fg.latlon_corners(12, 9, -30.0, 90.0, -60.0, 70.0)
+    a1, a2 = np.zeros(108), np.zeros(108)
+    O.orc_get_grid_area_no_adjust(12, 9, orc._dp(orc.f64(lo).ravel()), orc._dp(orc.f64(la).ravel()), orc._dp(a1))
+    R.get_grid_area_no_adjust(C.byref(C.c_int(12)), C.byref(C.c_int(9)), orc._dp(orc.f64(lo).ravel()), orc._dp(orc.f64(la).ravel()), orc._dp(a2))
+    assert np.array_equal(a1.view(np.uint64), a2.view(np.uint64))
