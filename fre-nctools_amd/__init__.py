@@ -167,3 +167,32 @@ def conserve_interp_great_circle(nx_src, ny_src, nx_dst, ny_dst, x_src, y_src, x
     lib().conserve_interp_great_circle(nx_src, ny_src, nx_dst, ny_dst, _dp(x_src), _dp(y_src), _dp(x_dst), _dp(y_dst),
                                        _dp(mask), _dp(data_src), _dp(out))
     return out
+
+
+def create_xgrid_box(box_is_src, order, lon_b, lat_b, nxq, nyq, lon_q, lat_q, mask=None):
+    """create_xgrid_1dx2d_order1/2 (box_is_src: the regular grid with 1-D bounds lon_b/lat_b is the source) or
+    create_xgrid_2dx1d_order1/2 (it is the destination) -- create_xgrid.c:208-591.  mask is on the source cells.
+    Returns (nxgrid, i_in, j_in, i_out, j_out, area[, clon, clat])."""
+    _lib.require_gpu()
+    lon_b, lat_b, lon_q, lat_q = _f64(lon_b).reshape(-1), _f64(lat_b).reshape(-1), _f64(lon_q), _f64(lat_q)
+    nxb, nyb = lon_b.size - 1, lat_b.size - 1
+    assert lon_q.size == (nxq + 1) * (nyq + 1) == lat_q.size
+    nm = nxb * nyb if box_is_src else nxq * nyq
+    mask = _f64(np.ones(nm) if mask is None else mask)
+    assert mask.size == nm
+    cap = get_maxxgrid()
+    i_in, j_in, i_out, j_out = (np.empty(cap, dtype=np.int32) for _ in range(4))
+    area, clon, clat = (np.empty(cap, dtype=np.float64) for _ in range(3))
+    ci = lambda v: C.byref(C.c_int(v))
+    if box_is_src:
+        head = [ci(nxb), ci(nyb), ci(nxq), ci(nyq), _dp(lon_b), _dp(lat_b), _dp(lon_q), _dp(lat_q)]
+        fn = lib().create_xgrid_1dx2d_order1 if order == 1 else lib().create_xgrid_1dx2d_order2
+    else:
+        head = [ci(nxq), ci(nyq), ci(nxb), ci(nyb), _dp(lon_q), _dp(lat_q), _dp(lon_b), _dp(lat_b)]
+        fn = lib().create_xgrid_2dx1d_order1 if order == 1 else lib().create_xgrid_2dx1d_order2
+    args = head + [_dp(mask), _ip(i_in), _ip(j_in), _ip(i_out), _ip(j_out), _dp(area)]
+    if order == 2:
+        args += [_dp(clon), _dp(clat)]
+    n = fn(*args)
+    out = (n, i_in[:n].copy(), j_in[:n].copy(), i_out[:n].copy(), j_out[:n].copy(), area[:n].copy())
+    return out + ((clon[:n].copy(), clat[:n].copy()) if order == 2 else ())

@@ -33,7 +33,10 @@ EXPORTS = [
     "fg_plan_mono_minmax_dev", "fg_plan_mono_copy_minmax", "fg_plan_mono_end",
     "fg_plan_create_great_circle", "fg_plan_create_great_circle_dev", "fg_latlon2xyz", "create_xgrid_great_circle",
     "create_xgrid_great_circle_", "get_grid_great_circle_area", "get_grid_great_circle_area_", "clip_2dx2d_great_circle",
-    "great_circle_area", "fg_gc_clip_batch", "conserve_interp_great_circle", "fg_plan_stream", "fg_plan_sync",
+    "great_circle_area", "fg_gc_clip_batch", "conserve_interp_great_circle",
+    "create_xgrid_1dx2d_order1", "create_xgrid_1dx2d_order2", "create_xgrid_2dx1d_order1", "create_xgrid_2dx1d_order2",
+    "create_xgrid_1dx2d_order1_", "create_xgrid_1dx2d_order2_", "create_xgrid_2dx1d_order1_", "create_xgrid_2dx1d_order2_",
+    "clip", "box_ctrlat", "box_ctrlon", "get_grid_area_no_adjust", "get_grid_area_no_adjust_", "fg_plan_stream", "fg_plan_sync",
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
     "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
     "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
@@ -163,6 +166,20 @@ def lib():
     L.great_circle_area.restype = C.c_double
     L.conserve_interp_great_circle.argtypes = [C.c_int] * 4 + [dp] * 7
     L.conserve_interp_great_circle.restype = None
+    for nm in ("create_xgrid_1dx2d_order1", "create_xgrid_2dx1d_order1"):
+        getattr(L, nm).argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp]
+        getattr(L, nm).restype = C.c_int
+    for nm in ("create_xgrid_1dx2d_order2", "create_xgrid_2dx1d_order2"):
+        getattr(L, nm).argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp] * 3
+        getattr(L, nm).restype = C.c_int
+    L.clip.argtypes = [dp, dp, C.c_int] + [C.c_double] * 4 + [dp, dp]
+    L.clip.restype = C.c_int
+    L.box_ctrlat.argtypes = [C.c_double] * 4
+    L.box_ctrlat.restype = C.c_double
+    L.box_ctrlon.argtypes = [C.c_double] * 5
+    L.box_ctrlon.restype = C.c_double
+    L.get_grid_area_no_adjust.argtypes = [cip, cip, dp, dp, dp]
+    L.get_grid_area_no_adjust.restype = None
     L.fg_gc_clip_batch.argtypes = [C.c_int, dp, dp, dp, ip, dp, C.c_int]
     L.fg_gc_clip_batch.restype = C.c_int
     L.fg_plan_stream.argtypes = [vp]

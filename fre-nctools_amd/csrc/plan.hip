@@ -270,6 +270,9 @@ static DevCounters *pinned_counters()
 // Great-circle plans pass the corner unit vectors instead (gc_in[m] = {x, y, z} device pointers of source tile m,
 // gc_out likewise); d_lon/d_lat are then unused.
 struct GcXyz { const double *x, *y, *z; };
+// 1-D x 2-D variants: the "source" tile of the search is the box grid expanded to corner arrays (d_lon_in[0]/d_lat_in[0]),
+// the "destination" the quads; box holds the 1-D bounds the pair kernel clips against.
+struct BoxMode { FgBox box; const double *mask_quad; int no_adjust; };
 static const char *gc_clip_error(int code)
 {
   switch (code) {
@@ -285,7 +288,8 @@ static const char *gc_clip_error(int code)
 
 static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
-                        double mean_dlat, double mean_dlon, const GcXyz *gc_in = nullptr, const GcXyz *gc_out = nullptr)
+                        double mean_dlat, double mean_dlon, const GcXyz *gc_in = nullptr, const GcXyz *gc_out = nullptr,
+                        const BoxMode *boxm = nullptr)
 {
   const bool gc = gc_in != nullptr;
   pl->great_circle = gc;
@@ -371,6 +375,8 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
     fgd_cell_struct(pl->tiles_dev, pl->ntiles, nsrc, pl->S, dc->err, st);
     fgd_cell_struct(pl->tiles_dev + pl->ntiles, 1, ndst, pl->D, dc->err, st);
   }
+  if (boxm) fgd_box_cell_boxes(boxm->box, pl->S, st);
+  if (boxm && boxm->no_adjust) fgd_box_area_no_adjust(boxm->box, pl->S.area, st);      // create_xgrid.c:239-242
   pt.end();
   pl->have_geom = true;
 
@@ -411,7 +417,12 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pt.end();
 
   // --- clip, area, centroid integrals (+ accepted count per source cell)
-  if (gc) {
+  if (boxm) {
+    pt.begin(PH_CLIP_GENERAL);
+    fgd_clip_box(order, npairs, pair_src, pair_dst, boxm->box, th[pl->ntiles], pl->S, pl->D, pl->mask_dev, boxm->mask_quad,
+                 tmp_area, tmp_clon, tmp_clat, nacc, dc->stats, dc->err, st);
+    pt.end();
+  } else if (gc) {
     pt.begin(PH_CLIP_GENERAL);
     fgd_gc_clip(npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
     pt.end();
@@ -1337,6 +1348,141 @@ extern "C" int clip_2dx2d_great_circle(const double x1_in[], const double y1_in[
   for (int k = 0; k < n_out; k++) { x_out[k] = out[k * 3]; y_out[k] = out[k * 3 + 1]; z_out[k] = out[k * 3 + 2]; }
   return n_out;
 }
+
+// create_xgrid_1dx2d_order1/2 and create_xgrid_2dx1d_order1/2 (create_xgrid.c:208-591) through the shared search pipeline
+static int b1_create_xgrid_box(int box_is_src, int order, int nxb, int nyb, const double *lon_b, const double *lat_b,
+                               int nxq, int nyq, const double *lon_q, const double *lat_q, const double *mask,
+                               int *i_in, int *j_in, int *i_out, int *j_out, double *xgrid_area, double *xgrid_clon, double *xgrid_clat)
+{
+  const int dev = b1_device();
+  if (nxb < 1 || nyb < 1 || nxq < 1 || nyq < 1) fatal("create_xgrid: bad grid sizes");
+  fg_plan *pl = nullptr;
+  if (plan_base(order, 1, &nxb, &nyb, nxq, nyq, dev, &pl)) fatal(fg_last_error());
+  const size_t npb = (size_t)(nxb + 1) * (nyb + 1), npq = (size_t)(nxq + 1) * (nyq + 1);
+  std::vector<double> tx(npb), ty(npb);                                  // the reference's tmpx/tmpy, :229-236
+  for (int j = 0; j <= nyb; j++) for (int i = 0; i <= nxb; i++) { tx[(size_t)j * (nxb + 1) + i] = lon_b[i]; ty[(size_t)j * (nxb + 1) + i] = lat_b[j]; }
+  const size_t nmask = box_is_src ? (size_t)nxb * nyb : (size_t)nxq * nyq;
+  double *d = pl->alloc<double>(2 * npb + 2 * npq + (nxb + 1) + (nyb + 1) + nmask);
+  if (!d) fatal("out of device memory");
+  double *d_tx = d, *d_ty = d_tx + npb, *d_lq = d_ty + npb, *d_aq = d_lq + npq, *d_lb = d_aq + npq, *d_ab = d_lb + (nxb + 1), *d_mask = d_ab + (nyb + 1);
+  bool ok = hipMemcpy(d_tx, tx.data(), npb * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(d_ty, ty.data(), npb * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(d_lq, lon_q, npq * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(d_aq, lat_q, npq * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(d_lb, lon_b, (nxb + 1) * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(d_ab, lat_b, (nyb + 1) * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(d_mask, mask, nmask * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) fatal("grid upload failed");
+  BoxMode bm;
+  bm.box = FgBox{d_lb, d_ab, nxb, nyb};
+  bm.mask_quad = box_is_src ? nullptr : d_mask;
+  bm.no_adjust = (box_is_src && order == 1 && !(nxb > 1)) ? 1 : 0;
+  const double *lons[1] = {d_tx}, *lats[1] = {d_ty}, *masks[1] = {box_is_src ? d_mask : nullptr};
+  double mdlat, mdlon;
+  sample_extents(nxq, nyq, lon_q, lat_q, &mdlat, &mdlon);
+  long nx = plan_search(pl, lons, lats, box_is_src ? masks : nullptr, d_lq, d_aq, mdlat, mdlon, nullptr, nullptr, &bm);
+  if (nx < 0) fatal(fg_last_error());
+  if (nx > (long)MAXXGRID) fatal("nxgrid is greater than MAXXGRID, increase MAXXGRID");
+  std::vector<int> bi(nx), bj(nx), qi(nx), qj(nx);
+  if (fg_plan_get_xgrid(pl, nullptr, bi.data(), bj.data(), qi.data(), qj.data(), xgrid_area, order == 2 ? xgrid_clon : nullptr,
+                        order == 2 ? xgrid_clat : nullptr)) fatal(fg_last_error());
+  for (long k = 0; k < nx; k++) {
+    if (box_is_src) { i_in[k] = bi[k]; j_in[k] = bj[k]; i_out[k] = qi[k]; j_out[k] = qj[k]; }
+    else { i_in[k] = qi[k]; j_in[k] = qj[k]; i_out[k] = bi[k]; j_out[k] = bj[k]; }
+  }
+  fg_plan_destroy(pl);
+  return (int)nx;
+}
+
+// clip / box_ctrlat / box_ctrlon / get_grid_area_no_adjust (create_xgrid.h:37-45)
+extern "C" int clip(const double lon_in[], const double lat_in[], int n_in, double ll_lon, double ll_lat, double ur_lon, double ur_lat,
+                    double lon_out[], double lat_out[])
+{
+  if (n_in < 1 || n_in > 12) fatal("clip (HIP): 1 <= n_in <= 12");
+  const int dev = b1_device();
+  if (hipSetDevice(dev) != hipSuccess) fatal("no HIP device visible: libfregrid_hip needs an MI355X-class GPU");
+  double *d = (double *)g_pool.get(dev, (4 * 16 + 2) * sizeof(double));
+  if (!d) fatal("out of device memory");
+  int *dn = (int *)(d + 64);
+  int n = 0;
+  bool ok = hipMemcpy(d, lon_in, n_in * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(d + 16, lat_in, n_in * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    fgd_clip_single(d, d + 16, n_in, ll_lon, ll_lat, ur_lon, ur_lat, d + 32, d + 48, dn, nullptr);
+    ok = hipMemcpy(&n, dn, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && n > 0) ok = hipMemcpy(lon_out, d + 32, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+                          hipMemcpy(lat_out, d + 48, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  g_pool.put(d);
+  if (!ok) fatal("clip: HIP copy/launch failed");
+  if (n < 0) fatal("clip (HIP): clipped polygon exceeds 16 vertices");
+  return n;
+}
+
+static void b1_box_ctr(double ll_lon, double ll_lat, double ur_lon, double ur_lat, double clon, double out[2])
+{
+  const int dev = b1_device();
+  if (hipSetDevice(dev) != hipSuccess) fatal("no HIP device visible: libfregrid_hip needs an MI355X-class GPU");
+  double *d = (double *)g_pool.get(dev, 2 * sizeof(double));
+  if (!d) fatal("out of device memory");
+  fgd_box_ctr(ll_lon, ll_lat, ur_lon, ur_lat, clon, d, nullptr);
+  bool ok = hipMemcpy(out, d, 2 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  g_pool.put(d);
+  if (!ok) fatal("box_ctr: HIP copy/launch failed");
+}
+extern "C" double box_ctrlat(double ll_lon, double ll_lat, double ur_lon, double ur_lat)
+{
+  double o[2]; b1_box_ctr(ll_lon, ll_lat, ur_lon, ur_lat, 0.0, o); return o[0];
+}
+extern "C" double box_ctrlon(double ll_lon, double ll_lat, double ur_lon, double ur_lat, double clon)
+{
+  double o[2]; b1_box_ctr(ll_lon, ll_lat, ur_lon, ur_lat, clon, o); return o[1];
+}
+
+extern "C" void get_grid_area_no_adjust(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area)
+{
+  const int nx = *nlon, ny = *nlat, dev = b1_device();
+  if (nx < 1 || ny < 1) fatal("get_grid_area_no_adjust: bad grid sizes");
+  if (hipSetDevice(dev) != hipSuccess) fatal("no HIP device visible: libfregrid_hip needs an MI355X-class GPU");
+  const size_t np = (size_t)(nx + 1) * (ny + 1), nc = (size_t)nx * ny;
+  double *d = (double *)g_pool.get(dev, (2 * np + nc) * sizeof(double));
+  if (!d) fatal("out of device memory");
+  bool ok = hipMemcpy(d, lon, np * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(d + np, lat, np * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    fgd_grid_area_no_adjust(nx, ny, d, d + np, d + 2 * np, nullptr);
+    ok = hipMemcpy(area, d + 2 * np, nc * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  g_pool.put(d);
+  if (!ok) fatal("get_grid_area_no_adjust: HIP copy/launch failed");
+}
+extern "C" void get_grid_area_no_adjust_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area)
+{
+  get_grid_area_no_adjust(nlon, nlat, lon, lat, area);
+}
+
+#define B1_BOX_FN(NAME, BOXSRC, ORDER)                                                                                          \
+  extern "C" int NAME(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out, const double *lon_in, \
+                      const double *lat_in, const double *lon_out, const double *lat_out, const double *mask_in, int *i_in,     \
+                      int *j_in, int *i_out, int *j_out, double *xgrid_area B1_BOX_EXTRA_##ORDER)                              \
+  {                                                                                                                             \
+    return (BOXSRC) ? b1_create_xgrid_box(1, ORDER, *nlon_in, *nlat_in, lon_in, lat_in, *nlon_out, *nlat_out, lon_out, lat_out, \
+                                          mask_in, i_in, j_in, i_out, j_out, xgrid_area, B1_BOX_ARGS_##ORDER)                   \
+                    : b1_create_xgrid_box(0, ORDER, *nlon_out, *nlat_out, lon_out, lat_out, *nlon_in, *nlat_in, lon_in, lat_in, \
+                                          mask_in, i_in, j_in, i_out, j_out, xgrid_area, B1_BOX_ARGS_##ORDER);                  \
+  }
+#define B1_BOX_EXTRA_1
+#define B1_BOX_EXTRA_2 , double *xgrid_clon, double *xgrid_clat
+#define B1_BOX_ARGS_1 nullptr, nullptr
+#define B1_BOX_ARGS_2 xgrid_clon, xgrid_clat
+B1_BOX_FN(create_xgrid_1dx2d_order1, 1, 1)
+B1_BOX_FN(create_xgrid_1dx2d_order1_, 1, 1)
+B1_BOX_FN(create_xgrid_1dx2d_order2, 1, 2)
+B1_BOX_FN(create_xgrid_1dx2d_order2_, 1, 2)
+B1_BOX_FN(create_xgrid_2dx1d_order1, 0, 1)
+B1_BOX_FN(create_xgrid_2dx1d_order1_, 0, 1)
+B1_BOX_FN(create_xgrid_2dx1d_order2, 0, 2)
+B1_BOX_FN(create_xgrid_2dx1d_order2_, 0, 2)
 
 static int b1_create_xgrid(int order, const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out,
                            const double *lon_in, const double *lat_in, const double *lon_out, const double *lat_out,

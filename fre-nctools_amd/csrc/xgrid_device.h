@@ -133,6 +133,18 @@ void fgd_mono_xdata(long nx, FgCsr csr, const double *f, const double *gx, const
 void fgd_mono_limit(long nx, FgCsr csr, const double *f, double missing, const double *fbmax, const double *fbmin,
                     const double *fmax, const double *fmin, double *xdata, int *err, hipStream_t st);
 
+// ---- 1-D x 2-D variants (box_kernels.hip): the regular grid given by its 1-D bounds (device pointers)
+struct FgBox { const double *lon, *lat; int nx, ny; };
+void fgd_clip_box(int order, int npairs, const int *pair_src, int *pair_dst, FgBox box, FgTile quad, FgCells S, FgCells D,
+                  const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
+                  unsigned long long *stats, unsigned *err, hipStream_t st);
+void fgd_box_area_no_adjust(FgBox box, double *area, hipStream_t st);
+void fgd_box_cell_boxes(FgBox box, FgCells c, hipStream_t st);
+void fgd_clip_single(const double *lon_in, const double *lat_in, int n_in, double ll_lon, double ll_lat, double ur_lon, double ur_lat,
+                     double *lon_out, double *lat_out, int *n_out, hipStream_t st);
+void fgd_box_ctr(double ll_lon, double ll_lat, double ur_lon, double ur_lat, double clon, double *out, hipStream_t st);
+void fgd_grid_area_no_adjust(int nx, int ny, const double *lon, const double *lat, double *area, hipStream_t st);
+
 // ---- great-circle path (gc_kernels.hip)
 void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st);
 void fgd_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,

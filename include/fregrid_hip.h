@@ -388,6 +388,38 @@ double great_circle_area(int n, const double *x, const double *y, const double *
  * Host pointers. */
 int fg_gc_clip_batch(int npairs, const double *a, const double *b, double *out, int *n_out, double *area, int device);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * The 1-D x 2-D exchange-grid variants and box primitives of libfrencutils (create_xgrid.h:37-64), same prototypes.
+ * create_xgrid_1dx2d_*: the SOURCE grid is regular and given by its 1-D bounds lon_in[nlon_in+1], lat_in[nlat_in+1];
+ * create_xgrid_2dx1d_*: the DESTINATION grid is (lon_out[nlon_out+1], lat_out[nlat_out+1]).  mask_in is on the source
+ * cells in both.  Callers in the reference: make_coupler_mosaic, make_topog, river tools (not fregrid). */
+int create_xgrid_1dx2d_order1(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out, const double *lon_in,
+                              const double *lat_in, const double *lon_out, const double *lat_out, const double *mask_in,
+                              int *i_in, int *j_in, int *i_out, int *j_out, double *xgrid_area);
+int create_xgrid_1dx2d_order2(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out, const double *lon_in,
+                              const double *lat_in, const double *lon_out, const double *lat_out, const double *mask_in,
+                              int *i_in, int *j_in, int *i_out, int *j_out, double *xgrid_area, double *xgrid_clon, double *xgrid_clat);
+int create_xgrid_2dx1d_order1(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out, const double *lon_in,
+                              const double *lat_in, const double *lon_out, const double *lat_out, const double *mask_in,
+                              int *i_in, int *j_in, int *i_out, int *j_out, double *xgrid_area);
+int create_xgrid_2dx1d_order2(const int *nlon_in, const int *nlat_in, const int *nlon_out, const int *nlat_out, const double *lon_in,
+                              const double *lat_in, const double *lon_out, const double *lat_out, const double *mask_in,
+                              int *i_in, int *j_in, int *i_out, int *j_out, double *xgrid_area, double *xgrid_clon, double *xgrid_clat);
+int create_xgrid_1dx2d_order1_(const int *, const int *, const int *, const int *, const double *, const double *, const double *,
+                               const double *, const double *, int *, int *, int *, int *, double *);
+int create_xgrid_1dx2d_order2_(const int *, const int *, const int *, const int *, const double *, const double *, const double *,
+                               const double *, const double *, int *, int *, int *, int *, double *, double *, double *);
+int create_xgrid_2dx1d_order1_(const int *, const int *, const int *, const int *, const double *, const double *, const double *,
+                               const double *, const double *, int *, int *, int *, int *, double *);
+int create_xgrid_2dx1d_order2_(const int *, const int *, const int *, const int *, const double *, const double *, const double *,
+                               const double *, const double *, int *, int *, int *, int *, double *, double *, double *);
+int clip(const double lon_in[], const double lat_in[], int n_in, double ll_lon, double ll_lat, double ur_lon, double ur_lat,
+         double lon_out[], double lat_out[]);
+double box_ctrlat(double ll_lon, double ll_lat, double ur_lon, double ur_lat);
+double box_ctrlon(double ll_lon, double ll_lat, double ur_lon, double ur_lat, double clon);
+void get_grid_area_no_adjust(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
+void get_grid_area_no_adjust_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
+
 /* Tripolar ocean grid (make_hgrid --grid_type tripolar_grid, uniform bounds, Murray bipolar cap north of lat_join):
  * nlon x nlat model cells, bounds in degrees, lonc/latc[(nlat+1)*(nlon+1)] radians.  Input synthesis only (see grid_gen.c). */
 int fg_tripolar_corners(int nlon, int nlat, double xbnd0, double xbnd1, double ybnd0, double ybnd1, double lat_join,
