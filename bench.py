@@ -201,15 +201,21 @@ def main():
     dtb = time.perf_counter() - tb
     apply_kernel_ms = p.phase_ms()["apply"]
     gsum_out = p.apply(data_t, out_t, nz=1, grad_x_t=gx_t, grad_y_t=gy_t, want_gsum=True)
+    # the same flux from this rank's exchange cells on the host: sum_x (f + gx*di + gy*dj)[src(x)] * area(x) -- what the
+    # sweep must reproduce to rounding (conservation of the remap itself, independent of the geometric closure of the grids)
+    xg = p.get_xgrid()
+    s_idx = xg["t_in"].astype(np.int64) * ni * ni + xg["j_in"].astype(np.int64) * ni + xg["i_in"]
+    f0 = src_h[0][s_idx] + gx_t[0].cpu().numpy()[s_idx] * xg["c1"] + gy_t[0].cpu().numpy()[s_idx] * xg["c2"]
+    gsum_xgrid = float(np.sum(f0 * xg["area"]))
 
     # ---- reductions over ranks
     red = torch.tensor([dt, dta, dtb], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(nx_local), float(gsum_out)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(nx_local), float(gsum_out), gsum_xgrid], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt, dta, dtb = float(red[0]), float(red[1]), float(red[2])
-    nx_total, gsum_out = int(tot[0].item()), float(tot[1].item())
+    nx_total, gsum_out, gsum_xgrid = int(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if rank == 0:
         value = args.steps * nx_total / dt
@@ -260,6 +266,10 @@ def main():
             "apply_device_ms_per_call": apply_call_ms,
             "remapped_points_per_s_interleaved": apply_steps * ndst * nb / dtb,
             "mass_rel_err": abs(gsum_out - gsum_in) / abs(gsum_in),
+            "mass_rel_err_note": "reference definition (conserve_interp.c:874-907): input flux uses get_grid_area cell areas, so it "
+                                 "carries the geometric closure of the exchange grid itself, 9.6e-10 for these grids in the reference too "
+                                 "(BASELINE.md); mass_rel_err_xgrid is the remap's own conservation over the exchange cells",
+            "mass_rel_err_xgrid": abs(gsum_out - gsum_xgrid) / abs(gsum_xgrid),
             "prep_ms_per_call": dtp * 1e3, "prep_cells_per_s": ncell_in * nz / dtp,
             "prep_note": "halo update + grad_c2l for nz levels of all 6 tiles (device), feeds the order-2 sweep",
             "phase_ms": phases, "search_stats": stats,
