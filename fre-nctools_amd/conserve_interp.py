@@ -240,9 +240,9 @@ class XgridPlan:
         check(lib().fg_plan_copy_cell_sums(self._h, C.c_void_p(dst_t.data_ptr())))
 
     def stats(self):
-        s = (C.c_long * 8)()
-        check(lib().fg_plan_stats(self._h, s, 8))
-        names = ["pairs", "nonempty", "nxgrid", "borderline", "bins", "bin_entries", "deferred", "heavy"]
+        s = (C.c_long * 10)()
+        check(lib().fg_plan_stats(self._h, s, 10))
+        names = ["pairs", "nonempty", "nxgrid", "borderline", "bins", "bin_entries", "deferred", "heavy", "below", "exact_mode"]
         return dict(zip(names, [int(v) for v in s]))
 
     PHASES = ["cell_struct", "bins", "candidates", "clip_quad", "clip_general", "compact", "cell_sums",

@@ -68,9 +68,11 @@ __device__ int d_clip_box(const double *lon_in, const double *lat_in, int n_in, 
 template <int ORDER>
 __global__ __launch_bounds__(128) void k_clip_box(int npairs, const int *pair_src, int *pair_dst, FgBox box, FgTile quad, FgCells S, FgCells D,
                                                    const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon,
-                                                   double *tmp_clat, int *nacc, unsigned long long *stats, unsigned *err)
+                                                   double *tmp_clat, int *nacc, unsigned long long *stats, unsigned *err,
+                                                   const unsigned long long *np_dev)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (np_dev) { const unsigned long long nd = *np_dev; if (nd < (unsigned long long)npairs) npairs = (int)nd; }
   if (p >= npairs) return;
   const int s = pair_src[p], d = pair_dst[p];
   const int ib = s % box.nx, jb = s / box.nx, iq = d % quad.nx, jq = d / quad.nx, nxqp = quad.nx + 1;
@@ -144,11 +146,11 @@ static inline int box_nblk(long n, int t) { return (int)((n + t - 1) / t); }
 
 void fgd_clip_box(int order, int npairs, const int *pair_src, int *pair_dst, FgBox box, FgTile quad, FgCells S, FgCells D,
                   const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
-                  unsigned long long *stats, unsigned *err, hipStream_t st)
+                  unsigned long long *stats, unsigned *err, const unsigned long long *np_dev, hipStream_t st)
 {
   if (npairs <= 0) return;
-  if (order == 2) k_clip_box<2><<<box_nblk(npairs, 128), 128, 0, st>>>(npairs, pair_src, pair_dst, box, quad, S, D, mask_box, mask_quad, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
-  else k_clip_box<1><<<box_nblk(npairs, 128), 128, 0, st>>>(npairs, pair_src, pair_dst, box, quad, S, D, mask_box, mask_quad, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
+  if (order == 2) k_clip_box<2><<<box_nblk(npairs, 128), 128, 0, st>>>(npairs, pair_src, pair_dst, box, quad, S, D, mask_box, mask_quad, tmp_area, tmp_clon, tmp_clat, nacc, stats, err, np_dev);
+  else k_clip_box<1><<<box_nblk(npairs, 128), 128, 0, st>>>(npairs, pair_src, pair_dst, box, quad, S, D, mask_box, mask_quad, tmp_area, tmp_clon, tmp_clat, nacc, stats, err, np_dev);
 }
 
 void fgd_box_area_no_adjust(FgBox box, double *area, hipStream_t st)

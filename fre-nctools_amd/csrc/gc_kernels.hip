@@ -800,9 +800,10 @@ __device__ void gc_finish(int p, int s, int n_out, const double *poly, double m,
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_WAVES_PER_EU, GC_WAVES_PER_EU)))
 void k_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D, double *tmp_area, int *nacc,
-               int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err)
+               int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, const unsigned long long *np_dev)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (np_dev) { const unsigned long long nd = *np_dev; if (nd < (unsigned long long)npairs) npairs = (int)nd; }
   if (p >= npairs) return;
   const int s = pair_src[p], d = pair_dst[p];
   const double *a = S.verts + (size_t)s * 16, *b = D.verts + (size_t)d * 16;
@@ -838,10 +839,11 @@ void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCe
 }
 
 void fgd_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
-                 double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st)
+                 double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err,
+                 const unsigned long long *np_dev, hipStream_t st)
 {
   if (npairs <= 0) return;
-  k_gc_clip<<<gc_nblk(npairs, 64), 64, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, nacc, defer_list, defer_cnt, stats, err);
+  k_gc_clip<<<gc_nblk(npairs, 64), 64, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, nacc, defer_list, defer_cnt, stats, err, np_dev);
   k_gc_clip_slow<<<64, 64, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, nacc, stats, err);
 }
 

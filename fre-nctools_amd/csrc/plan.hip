@@ -104,6 +104,48 @@ static int g_profiling = 0;
 extern "C" void fg_set_profiling(int on) { g_profiling = on ? 1 : 0; }
 enum { PH_CELL_STRUCT = 0, PH_BINS, PH_CANDIDATES, PH_CLIP_QUAD, PH_CLIP_GENERAL, PH_COMPACT, PH_CELL_SUMS,
        PH_SEARCH_TOTAL, PH_FINALIZE, PH_APPLY, PH_COUNT };
+// Streams and events are cached per process: creating and destroying a stream costs ~0.1 ms each on this runtime, which
+// was a quarter of a millisecond per plan (scripts/host_time.py).
+struct HandleCache {
+  std::mutex mu;
+  std::map<int, std::vector<hipStream_t>> streams;
+  std::vector<hipEvent_t> events;
+  hipStream_t get_stream(int dev)
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto &v = streams[dev];
+      if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return s;
+  }
+  void put_stream(int dev, hipStream_t s)
+  {
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(mu);
+    streams[dev].push_back(s);
+  }
+  hipEvent_t get_event()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!events.empty()) { hipEvent_t e = events.back(); events.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void put_event(hipEvent_t e)
+  {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(mu);
+    events.push_back(e);
+  }
+};
+static HandleCache g_handles;
+
 struct PhaseTimer {
   bool on = false;
   hipStream_t st = nullptr;
@@ -113,12 +155,12 @@ struct PhaseTimer {
   void begin(int ph)
   {
     if (!on) return;
-    (void)hipEventCreate(&open_ev); (void)hipEventRecord(open_ev, st); open_ph = ph;
+    open_ev = g_handles.get_event(); (void)hipEventRecord(open_ev, st); open_ph = ph;
   }
   void end()
   {
     if (!on || open_ph < 0) return;
-    hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, st);
+    hipEvent_t e = g_handles.get_event(); (void)hipEventRecord(e, st);
     spans.push_back({open_ph, {open_ev, e}}); open_ph = -1;
   }
   // call after the stream has been synchronised; accumulates into ms[]
@@ -127,7 +169,7 @@ struct PhaseTimer {
     for (auto &sp : spans) {
       float t = 0; (void)hipEventElapsedTime(&t, sp.second.first, sp.second.second);
       ms[sp.first] += t;
-      (void)hipEventDestroy(sp.second.first); (void)hipEventDestroy(sp.second.second);
+      g_handles.put_event(sp.second.first); g_handles.put_event(sp.second.second);
     }
     spans.clear();
   }
@@ -219,8 +261,8 @@ static int plan_base(int order, int ntiles_in, const int *nx_in, const int *ny_i
   if (off > 2000000000L || (long)nx_out * ny_out > 2000000000L) { delete pl; return fail(FG_ERR_ARG, "grid too large for 32-bit cell indices"); }
   pl->nsrc = (int)off; pl->f_stride = foff;
   pl->nx_out = nx_out; pl->ny_out = ny_out; pl->ndst = nx_out * ny_out;
-  hipError_t e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete pl; return fail(FG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  pl->stream = g_handles.get_stream(device);
+  if (!pl->stream) { delete pl; return fail(FG_ERR_HIP, "hipStreamCreate failed"); }
   *out = pl;
   return 0;
 }
@@ -230,7 +272,7 @@ extern "C" void fg_plan_destroy(fg_plan *pl)
   if (!pl) return;
   (void)hipSetDevice(pl->device);
   if (pl->stream || !pl->own_stream) (void)hipStreamSynchronize(pl->stream);
-  if (pl->stream && pl->own_stream) (void)hipStreamDestroy(pl->stream);
+  if (pl->stream && pl->own_stream) g_handles.put_stream(pl->device, pl->stream);
   { float junk[PH_COUNT] = {0}; pl->apply_pt.collect(junk); }
   for (void *p : pl->owned) g_pool.put(p);
   delete pl;
@@ -286,11 +328,15 @@ static const char *gc_clip_error(int code)
   }
 }
 
-static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
+#define FG_RETRY_EXACT (-1000L)
+static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
-                        double mean_dlat, double mean_dlon, const GcXyz *gc_in = nullptr, const GcXyz *gc_out = nullptr,
-                        const BoxMode *boxm = nullptr)
+                        double mean_dlat, double mean_dlon, const GcXyz *gc_in, const GcXyz *gc_out,
+                        const BoxMode *boxm, bool fast)
 {
+  // fast: buffers are sized by capacity (bin entries 2*ndst, candidate pairs / exchange cells 8*max(nsrc, ndst)), the
+  // kernels read the true counts from device memory, and the host synchronises ONCE, at the end.  If a capacity turns
+  // out too small the caller repeats the search in exact mode (three readbacks that size every buffer exactly).
   const bool gc = gc_in != nullptr;
   pl->great_circle = gc;
   hipStream_t st = pl->stream;
@@ -380,30 +426,40 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pt.end();
   pl->have_geom = true;
 
+  const long big = std::max((long)nsrc, (long)ndst);
+  const unsigned long long cap_entries = 2ull * (unsigned long long)ndst + 4096ull;
+  const unsigned long long cap_pairs = std::min<unsigned long long>(8ull * (unsigned long long)big + 65536ull, 2000000000ull);
   pt.begin(PH_BINS);
-  fgd_bin_build(false, ndst, pl->D, bins, bin_cnt, nullptr, nullptr, st);
+  fgd_bin_build(false, ndst, pl->D, bins, bin_cnt, nullptr, nullptr, 0, st);
   fgd_exclusive_scan(bin_cnt, nslots, bin_start, scan_ws, &dc->total[0], st);
   pt.end();
-  if (readback()) return FG_ERR_HIP;
-  if (hc->err[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
-  if (hc->err[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
-  const unsigned long long nentries = hc->total[0];
-  if (nentries > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
+  unsigned long long nentries = cap_entries;
+  if (!fast) {
+    if (readback()) return FG_ERR_HIP;
+    if (hc->err[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
+    if (hc->err[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
+    nentries = hc->total[0];
+    if (nentries > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
+  }
   FgBinEntry *bin_entries = pl->alloc<FgBinEntry>(nentries ? nentries : 1);
   if (!bin_entries) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_BINS);
-  fgd_bin_build(true, ndst, pl->D, bins, bin_fill, bin_start, bin_entries, st);
+  fgd_bin_build(true, ndst, pl->D, bins, bin_fill, bin_start, bin_entries, (int)std::min<unsigned long long>(nentries, 2147483647ull), st);
   pt.end();
 
   // --- candidate pairs
   pt.begin(PH_CANDIDATES);
-  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, &dc->heavy_cnt, st);
+  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, &dc->heavy_cnt, 0, st);
   fgd_exclusive_scan(cand_cnt, ncand, cand_off, scan_ws, &dc->total[1], st);
   pt.end();
-  if (readback()) return FG_ERR_HIP;
-  const unsigned long long npairs64 = hc->total[1];
-  if (npairs64 > 2000000000ull) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
-  const int npairs = (int)npairs64;
+  unsigned long long npairs64 = cap_pairs;
+  if (!fast) {
+    if (readback()) return FG_ERR_HIP;
+    npairs64 = hc->total[1];
+    if (npairs64 > 2000000000ull) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
+  }
+  const int npairs = (int)npairs64;                                 // exact count, or the capacity the kernels are launched for
+  const unsigned long long *np_dev = fast ? &dc->total[1] : nullptr;
 
   int *pair_src = pl->alloc<int>(npairs + 1), *pair_dst = pl->alloc<int>(npairs + 1);
   double *tmp_area = pl->alloc<double>(npairs + 1);
@@ -413,23 +469,23 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   if (!pair_src || !pair_dst || !tmp_area || !defer_list || (order == 2 && (!tmp_clon || !tmp_clat)))
     return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_CANDIDATES);
-  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, &dc->heavy_cnt, st);
+  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, &dc->heavy_cnt, npairs, st);
   pt.end();
 
   // --- clip, area, centroid integrals (+ accepted count per source cell)
   if (boxm) {
     pt.begin(PH_CLIP_GENERAL);
     fgd_clip_box(order, npairs, pair_src, pair_dst, boxm->box, th[pl->ntiles], pl->S, pl->D, pl->mask_dev, boxm->mask_quad,
-                 tmp_area, tmp_clon, tmp_clat, nacc, dc->stats, dc->err, st);
+                 tmp_area, tmp_clon, tmp_clat, nacc, dc->stats, dc->err, np_dev, st);
     pt.end();
   } else if (gc) {
     pt.begin(PH_CLIP_GENERAL);
-    fgd_gc_clip(npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
+    fgd_gc_clip(npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, np_dev, st);
     pt.end();
   } else {
     pt.begin(PH_CLIP_QUAD);
     fgd_clip_quad(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-                  nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
+                  nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, np_dev, st);
     pt.end();
     pt.begin(PH_CLIP_GENERAL);
     fgd_clip_general(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
@@ -441,32 +497,34 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   pt.begin(PH_COMPACT);
   fgd_exclusive_scan(nacc, nsrc, pl->xoff, scan_ws, &dc->total[2], st);
   pt.end();
-  if (readback()) return FG_ERR_HIP;
-  if (hc->err[0] & 2u) return fail(FG_ERR_PARALLEL, "the line between <x1_0,y1_0> and  <x1_1,y1_1> should not parallel to "
-                                                    "the line between <x2_0,y2_0> and  <x2_1,y2_1>");
-  if (hc->err[0] & 4u) return fail(FG_ERR_MAXV, "clipped polygon exceeds 16 vertices");
-  if (hc->err[0] & G_ERRBIT_GC_CONVEX1) return fail(FG_ERR_PARALLEL, "create_xgrid.c(clip_2dx2d_great_circle): grid box 1 is not convex");
-  if (hc->err[0] & G_ERRBIT_GC_CONVEX2) return fail(FG_ERR_PARALLEL, "create_xgrid.c(clip_2dx2d_great_circle): grid box 2 is not convex");
-  if (hc->err[0] & G_ERRBIT_GC_CLIP) return fail(FG_ERR_PARALLEL, "%s", gc_clip_error((int)hc->err[1]));
-  pl->nx = (long)hc->total[2];
-  pl->stats[FG_STAT_PAIRS] = npairs;
-  pl->stats[FG_STAT_NONEMPTY] = (long)(hc->total[2] + hc->stats[FG_STAT_BELOW]);
-  pl->stats[FG_STAT_NXGRID] = pl->nx;
-  pl->stats[FG_STAT_BORDERLINE] = (long)hc->stats[FG_STAT_BORDERLINE];
-  pl->stats[FG_STAT_BINS] = nbins;
-  pl->stats[FG_STAT_BIN_ENTRIES] = (long)nentries;
-  pl->stats[FG_STAT_DEFERRED] = hc->defer_cnt;
-  pl->stats[FG_STAT_HEAVY] = hc->heavy_cnt;
-  pl->x_src = pl->alloc<int>(pl->nx + 1); pl->x_dst = pl->alloc<int>(pl->nx + 1);
-  pl->x_area = pl->alloc<double>(pl->nx + 1);
-  if (order == 2) { pl->x_c1 = pl->alloc<double>(pl->nx + 1); pl->x_c2 = pl->alloc<double>(pl->nx + 1); }
+  auto check_errors = [&]() -> int {
+    if (hc->err[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
+    if (hc->err[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
+    if (hc->err[0] & 2u) return fail(FG_ERR_PARALLEL, "the line between <x1_0,y1_0> and  <x1_1,y1_1> should not parallel to "
+                                                      "the line between <x2_0,y2_0> and  <x2_1,y2_1>");
+    if (hc->err[0] & 4u) return fail(FG_ERR_MAXV, "clipped polygon exceeds 16 vertices");
+    if (hc->err[0] & G_ERRBIT_GC_CONVEX1) return fail(FG_ERR_GEOM, "create_xgrid.c(clip_2dx2d_great_circle): grid box 1 is not convex");
+    if (hc->err[0] & G_ERRBIT_GC_CONVEX2) return fail(FG_ERR_GEOM, "create_xgrid.c(clip_2dx2d_great_circle): grid box 2 is not convex");
+    if (hc->err[0] & G_ERRBIT_GC_CLIP) return fail(FG_ERR_GEOM, "%s", gc_clip_error((int)hc->err[1]));
+    return 0;
+  };
+  long nx_alloc = (long)npairs;                                     // fast: nxgrid <= candidate pairs <= capacity
+  if (!fast) {
+    if (readback()) return FG_ERR_HIP;
+    { int rc = check_errors(); if (rc) return rc; }
+    pl->nx = (long)hc->total[2];
+    nx_alloc = pl->nx;
+  }
+  pl->x_src = pl->alloc<int>(nx_alloc + 1); pl->x_dst = pl->alloc<int>(nx_alloc + 1);
+  pl->x_area = pl->alloc<double>(nx_alloc + 1);
+  if (order == 2) { pl->x_c1 = pl->alloc<double>(nx_alloc + 1); pl->x_c2 = pl->alloc<double>(nx_alloc + 1); }
   if (!pl->x_src || !pl->x_dst || !pl->x_area || (order == 2 && (!pl->x_c1 || !pl->x_c2))) return fail(FG_ERR_HIP, "out of device memory");
   pl->row_cnt = pl->alloc<int>(2 * ((size_t)ndst + 1));
   if (!pl->row_cnt) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_COMPACT);
   HIPCHK(hipMemsetAsync(pl->row_cnt, 0, 2 * ((size_t)ndst + 1) * sizeof(int), st));
   fgd_scatter_xcells(order, npairs, pair_src, pair_dst, cand_off, pl->xoff, tmp_area, tmp_clon, tmp_clat,
-                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, pl->row_cnt, st);
+                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, pl->row_cnt, np_dev, st);
   pt.end();
   if (order == 2) {
     pl->sums = pl->alloc<double>(3 * (size_t)nsrc);
@@ -476,9 +534,25 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
     pt.end();
   }
   ptot.end();
-  HIPCHK(hipStreamSynchronize(st));
+  if (fast) {
+    if (readback()) return FG_ERR_HIP;                             // the one synchronisation of the fast path
+    if (hc->total[0] > cap_entries || hc->total[1] > cap_pairs) return FG_RETRY_EXACT;
+    { int rc = check_errors(); if (rc) return rc; }
+    pl->nx = (long)hc->total[2];
+  } else
+    HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
   pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms);
+  pl->stats[FG_STAT_PAIRS] = (long)hc->total[1];
+  pl->stats[FG_STAT_NONEMPTY] = (long)(hc->total[2] + hc->stats[FG_STAT_BELOW]);
+  pl->stats[FG_STAT_NXGRID] = pl->nx;
+  pl->stats[FG_STAT_BORDERLINE] = (long)hc->stats[FG_STAT_BORDERLINE];
+  pl->stats[FG_STAT_BINS] = nbins;
+  pl->stats[FG_STAT_BIN_ENTRIES] = (long)hc->total[0];
+  pl->stats[FG_STAT_DEFERRED] = hc->defer_cnt;
+  pl->stats[FG_STAT_HEAVY] = hc->heavy_cnt;
+  pl->stats[FG_STAT_BELOW] = (long)hc->stats[FG_STAT_BELOW];
+  pl->stats[FG_STAT_EXACT] = fast ? 0 : 1;
 
   // scratch no longer needed
   void *scratch[] = {zero_blk, bin_start, scan_ws, bin_entries, heavy_list, cand_cnt, cand_off, pair_src, pair_dst,
@@ -486,6 +560,29 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   for (void *p : scratch) pl->release(p);
   pl->searched = true;
   return pl->nx;
+}
+
+// Fast path first; if one of its capacities was too small (coarse -> very fine grids: a source cell with thousands of
+// candidates), drop everything the attempt allocated and search again with exactly sized buffers.
+static int g_search_exact = 0;                       // FREGRID_HIP_EXACT_SEARCH=1 / fg_set_search_mode(1): always use exact mode
+extern "C" void fg_set_search_mode(int exact) { g_search_exact = exact; }
+static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
+                        const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
+                        double mean_dlat, double mean_dlon, const GcXyz *gc_in = nullptr, const GcXyz *gc_out = nullptr,
+                        const BoxMode *boxm = nullptr)
+{
+  static const bool env_exact = getenv("FREGRID_HIP_EXACT_SEARCH") && atoi(getenv("FREGRID_HIP_EXACT_SEARCH")) != 0;
+  if (!g_search_exact && !env_exact) {
+    const size_t keep = pl->owned.size();            // blocks the caller staged before the search stay
+    long rc = plan_search_core(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon, gc_in, gc_out, boxm, true);
+    if (rc != FG_RETRY_EXACT) return rc;
+    (void)hipStreamSynchronize(pl->stream);
+    while (pl->owned.size() > keep) { void *p = pl->owned.back(); pl->owned.pop_back(); g_pool.put(p); }
+    pl->tiles_dev = nullptr; pl->mask_dev = nullptr; pl->S = FgCells{}; pl->D = FgCells{};
+    pl->x_src = pl->x_dst = nullptr; pl->x_area = pl->x_c1 = pl->x_c2 = nullptr; pl->xoff = nullptr; pl->row_cnt = nullptr; pl->sums = nullptr;
+    pl->have_geom = false;
+  }
+  return plan_search_core(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon, gc_in, gc_out, boxm, false);
 }
 
 // mean cell extents from a strided sample of corner arrays (host or device-copied-to-host)
@@ -568,7 +665,7 @@ extern "C" long fg_plan_create_dev(int order, int ntiles_in, const int *nx_in, c
   int rc = plan_base(order, ntiles_in, nx_in, ny_in, nx_out, ny_out, device, &pl);
   if (rc) return rc;
   if (use_caller_stream) {
-    (void)hipStreamDestroy(pl->stream);
+    g_handles.put_stream(pl->device, pl->stream);
     pl->stream = (hipStream_t)stream; pl->own_stream = false;
   }
   if (!(mean_dlat > 0) || !(mean_dlon > 0)) {
@@ -622,7 +719,7 @@ extern "C" long fg_plan_create_great_circle_dev(int ntiles_in, const int *nx_in,
   int rc = plan_base(FG_CONSERVE_ORDER1, ntiles_in, nx_in, ny_in, nx_out, ny_out, device, &pl);
   if (rc) return rc;
   if (use_caller_stream) {
-    (void)hipStreamDestroy(pl->stream);
+    g_handles.put_stream(pl->device, pl->stream);
     pl->stream = (hipStream_t)stream; pl->own_stream = false;
   }
   if (!(mean_dlat > 0) || !(mean_dlon > 0)) {
@@ -701,7 +798,7 @@ extern "C" int fg_plan_set_stream(fg_plan *pl, void *stream)
   if (!pl) return fail(FG_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(pl->device));
   HIPCHK(hipStreamSynchronize(pl->stream));
-  if (pl->own_stream && pl->stream) (void)hipStreamDestroy(pl->stream);
+  if (pl->own_stream && pl->stream) g_handles.put_stream(pl->device, pl->stream);
   pl->stream = (hipStream_t)stream; pl->own_stream = false;
   return 0;
 }
@@ -1695,6 +1792,7 @@ extern "C" int fg_halo_map(int ntiles, const int *nx, const int *ny, int ncontac
 struct fg_c2l {
   int device = 0, ntiles = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = true;
   long ncells = 0, F = 0;
   std::vector<int> nx, ny;
   std::vector<void *> owned;
@@ -1710,6 +1808,7 @@ extern "C" void fg_c2l_destroy(fg_c2l *h)
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->own_stream) g_handles.put_stream(h->device, h->stream);
   for (void *p : h->owned) g_pool.put(p);
   delete h;
 }
@@ -1762,8 +1861,8 @@ extern "C" int fg_c2l_create(int ntiles, const int *nx, const int *ny, const dou
                           ene.data() + 3 * dy_off[t], vlon.data() + 3 * cell_off[t], vlat.data() + 3 * cell_off[t]);
     if (rc) { delete h; return fail(rc, "fg_c2l_grid_info failed"); }
   }
-  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete h; return fail(FG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  h->stream = g_handles.get_stream(device);
+  if (!h->stream) { delete h; return fail(FG_ERR_HIP, "hipStreamCreate failed"); }
   std::vector<char> th(fgd_c2l_tile_size() * ntiles);
   for (int t = 0; t < ntiles; t++) fgd_c2l_tile_fill(th.data(), t, nx[t], ny[t], cell_off[t], f_off[t], dx_off[t], dy_off[t], ew_off[t], es_off[t]);
   const std::vector<double> *src[11] = {&dx, &dy, &area, &ew, &ee, &es, &en, &enn, &ene, &vlon, &vlat};
@@ -1787,8 +1886,8 @@ extern "C" int fg_c2l_set_stream(fg_c2l *h, void *stream)
   if (!h) return fail(FG_ERR_ARG, "null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
-  (void)hipStreamDestroy(h->stream);
-  h->stream = (hipStream_t)stream;
+  if (h->own_stream) g_handles.put_stream(h->device, h->stream);
+  h->stream = (hipStream_t)stream; h->own_stream = false;
   return 0;
 }
 extern "C" int fg_c2l_sync(fg_c2l *h)

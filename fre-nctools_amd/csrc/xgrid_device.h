@@ -52,6 +52,7 @@ enum {
   FG_STAT_DEFERRED = 6,   // pairs handled by the general (non quad x quad) kernel
   FG_STAT_HEAVY = 7,      // source cells whose candidate scan got a whole wave
   FG_STAT_BELOW = 8,      // non-empty clips rejected by the 1e-6 area ratio
+  FG_STAT_EXACT = 9,      // 1 if the plan was built by the exactly sized (three-readback) search, 0 by the single-sync one
   FG_NSTATS = 10
 };
 
@@ -61,21 +62,22 @@ int  fgd_exclusive_scan(const int *in, long n, int *out, unsigned long long *bsu
 long fgd_scan_ws_elems(long n);
 
 void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c, unsigned *err, hipStream_t st);
-void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start, FgBinEntry *entries, hipStream_t st);
+void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start, FgBinEntry *entries, int cap,
+                   hipStream_t st);
 void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start,
                     const FgBinEntry *entries, int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                    int *heavy_list, int *heavy_cnt, hipStream_t st);
+                    int *heavy_list, int *heavy_cnt, int cap, hipStream_t st);
 void fgd_clip_general(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);
 void fgd_clip_quad(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-              unsigned long long *stats, unsigned *err, hipStream_t st);
+              unsigned long long *stats, unsigned *err, const unsigned long long *np_dev, hipStream_t st);
 int  fgd_cand_group(void);   // lanes per source cell in the candidate scan: cand_cnt/cand_off hold nsrc*group (+1) entries
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
                         const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                        int *row_cnt, hipStream_t st);
+                        int *row_cnt, const unsigned long long *np_dev, hipStream_t st);
 void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
                    const double *x_c2, double *sums, hipStream_t st);
 void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st);
@@ -137,7 +139,7 @@ void fgd_mono_limit(long nx, FgCsr csr, const double *f, double missing, const d
 struct FgBox { const double *lon, *lat; int nx, ny; };
 void fgd_clip_box(int order, int npairs, const int *pair_src, int *pair_dst, FgBox box, FgTile quad, FgCells S, FgCells D,
                   const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
-                  unsigned long long *stats, unsigned *err, hipStream_t st);
+                  unsigned long long *stats, unsigned *err, const unsigned long long *np_dev, hipStream_t st);
 void fgd_box_area_no_adjust(FgBox box, double *area, hipStream_t st);
 void fgd_box_cell_boxes(FgBox box, FgCells c, hipStream_t st);
 void fgd_clip_single(const double *lon_in, const double *lat_in, int n_in, double ll_lon, double ll_lat, double ur_lon, double ur_lat,
@@ -148,7 +150,8 @@ void fgd_grid_area_no_adjust(int nx, int ny, const double *lon, const double *la
 // ---- great-circle path (gc_kernels.hip)
 void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st);
 void fgd_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
-                 double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st);
+                 double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err,
+                 const unsigned long long *np_dev, hipStream_t st);
 #define FG_GC_POLY_CAP 16
 void fgd_gc_clip_batch(int n, const double *a, const double *b, double *out, int *n_out, double *area, hipStream_t st);
 void fgd_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *n, double *area, hipStream_t st);

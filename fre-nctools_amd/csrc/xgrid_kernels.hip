@@ -217,7 +217,7 @@ __device__ __forceinline__ int d_colmod(long long l, int nb) { return (int)(((l 
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin_build(int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start,
-                                                    FgBinEntry *entries)
+                                                    FgBinEntry *entries, int cap)
 {
   int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= ncells) return;
@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256) void k_bin_build(int ncells, FgCells c, FgBins
   if (r1 - r0 <= 1 && l1 - l0 <= 1) {
     int slot = r0 * b.nblon + d_colmod(l0, b.nblon);
     int pos = atomicAdd(&slot_cnt[slot], 1);
-    if (FILL) entries[slot_start[slot] + pos] = E;
+    if (FILL) { const int at = slot_start[slot] + pos; if (at < cap) entries[at] = E; }
   } else {
     for (int r = r0; r <= r1; r++) {
       int pos = atomicAdd(&slot_cnt[nbins + r], 1);
-      if (FILL) entries[slot_start[nbins + r] + pos] = E;
+      if (FILL) { const int at = slot_start[nbins + r] + pos; if (at < cap) entries[at] = E; }
     }
   }
 }
@@ -301,7 +301,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const double *mask, FgBins b,
                                                      const int *slot_start, const FgBinEntry *entries,
                                                      int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                                                     int *heavy_list, int *heavy_cnt)
+                                                     int *heavy_list, int *heavy_cnt, int cap)
 {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int s = (int)(t / CAND_G), sub = (int)(t % CAND_G);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
         for (int e = e0; e < e1; e++) {
           const FgBinEntry E = entries[e];
           if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
-          if (FILL) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = E.d; }
+          if (FILL && wbase + cnt < cap) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = E.d; }
           cnt++;
         }
       }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
         const FgBinEntry E = entries[e];
         if (r != max(q.r0, E.row0)) continue;          // a wide cell sits in every row it spans
         if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
-        if (FILL) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = E.d; }
+        if (FILL && wbase + cnt < cap) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = E.d; }
         cnt++;
       }
     }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_candidates_heavy(FgCells S, FgBins b, const int *slot_start, const FgBinEntry *entries,
                                                           int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                                                          const int *heavy_list, const int *heavy_cnt)
+                                                          const int *heavy_list, const int *heavy_cnt, int cap)
 {
   const int lane = threadIdx.x;
   const int nheavy = *heavy_cnt;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64) void k_candidates_heavy(FgCells S, FgBins b, co
         unsigned long long m = __ballot(pass);
         if (FILL && pass) {
           int pos = wbase + cnt + __popcll(m & ((1ull << lane) - 1ull));
-          pair_src[pos] = s; pair_dst[pos] = dcell;
+          if (pos < cap) { pair_src[pos] = s; pair_dst[pos] = dcell; }
         }
         cnt += __popcll(m);
       }
@@ -534,11 +534,12 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const in
                                                             FgCells S, const double *mask, FgCells D,
                                                             double *tmp_area, double *tmp_clon, double *tmp_clat,
                                                             int *nacc, int *defer_list, int *defer_cnt,
-                                                            unsigned long long *stats, unsigned *err)
+                                                            unsigned long long *stats, unsigned *err, const unsigned long long *np_dev)
 {
   __shared__ double2 sh_poly[8][CLIP_THREADS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int p = blockIdx.x * CLIP_THREADS + tid;
+  if (np_dev) { const unsigned long long nd = *np_dev; if (nd < (unsigned long long)npairs) npairs = (int)nd; }   // launched for the capacity
   int s = -1;
   bool acc = false;
   if (p < npairs) {
@@ -674,9 +675,10 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
                                                          const int *cand_off, const int *xoff,
                                                          const double *tmp_area, const double *tmp_clon, const double *tmp_clat,
                                                          int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                                                         int *row_cnt)
+                                                         int *row_cnt, const unsigned long long *np_dev)
 {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (np_dev) { const unsigned long long nd = *np_dev; if (nd < (unsigned long long)npairs) npairs = (int)nd; }
   if (p >= npairs) return;
   const int d = pair_dst[p];                        // -1: rejected by the clip kernels
   if (d < 0) return;
@@ -751,37 +753,38 @@ void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c,
   if (ncells > 0) k_cell_struct<<<nblk(ncells, 256), 256, 0, st>>>(tiles_dev, ntiles, ncells, c, err);
 }
 
-void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start, FgBinEntry *entries, hipStream_t st)
+void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start, FgBinEntry *entries, int cap,
+                   hipStream_t st)
 {
   if (ncells <= 0) return;
-  if (fill) k_bin_build<true><<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, slot_cnt, slot_start, entries);
-  else      k_bin_build<false><<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, slot_cnt, slot_start, entries);
+  if (fill) k_bin_build<true><<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, slot_cnt, slot_start, entries, cap);
+  else      k_bin_build<false><<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, slot_cnt, slot_start, entries, cap);
 }
 
 void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start,
                     const FgBinEntry *entries, int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                    int *heavy_list, int *heavy_cnt, hipStream_t st)
+                    int *heavy_list, int *heavy_cnt, int cap, hipStream_t st)
 {
   if (nsrc <= 0) return;
   int hgrid = nblk(nsrc, 64); if (hgrid > 2048) hgrid = 2048;
   if (fill) {
-    k_candidates<true><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
-    k_candidates_heavy<true><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
+    k_candidates<true><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap);
+    k_candidates_heavy<true><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap);
   } else {
-    k_candidates<false><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
-    k_candidates_heavy<false><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt);
+    k_candidates<false><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap);
+    k_candidates_heavy<false><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap);
   }
 }
 
 void fgd_clip_quad(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
                    double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-                   unsigned long long *stats, unsigned *err, hipStream_t st)
+                   unsigned long long *stats, unsigned *err, const unsigned long long *np_dev, hipStream_t st)
 {
   if (npairs <= 0) return;
   if (order == 2)
-    k_clip_quad<2><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err);
+    k_clip_quad<2><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err, np_dev);
   else
-    k_clip_quad<1><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err);
+    k_clip_quad<1><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err, np_dev);
 }
 
 void fgd_clip_general(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
@@ -801,11 +804,11 @@ int fgd_cand_group(void) { return CAND_G; }
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
                         const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                        int *row_cnt, hipStream_t st)
+                        int *row_cnt, const unsigned long long *np_dev, hipStream_t st)
 {
   if (npairs <= 0) return;
-  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt);
-  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt);
+  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, np_dev);
+  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, np_dev);
 }
 
 void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,

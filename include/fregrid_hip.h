@@ -265,6 +265,11 @@ int  fg_plan_phase_ms(fg_plan *plan, float *ms, int n);   /* [9] = mean over the
  * [2]=nxgrid, [3]=pairs whose area ratio is within 1e-9 (relative) of the 1e-6 threshold,
  * [4]=bins, [5]=bin entries.  n = capacity of stats. */
 int fg_plan_stats(const fg_plan *plan, long *stats, int n);
+/* Search buffer sizing.  Default (0): single-synchronisation search -- buffers sized by capacity (bin entries 2*ndst,
+ * candidate pairs and exchange cells 8*max(nsrc, ndst)), counts stay on the device, one readback at the end; a search
+ * that overflows a capacity is repeated transparently in exact mode.  1: always size every buffer exactly (three
+ * readbacks; smaller plans).  Also selectable with the environment variable FREGRID_HIP_EXACT_SEARCH=1. */
+void fg_set_search_mode(int exact);
 
 /* Batched polygon primitives on the device.  Polygons are rows of host arrays [npoly][24];
  * inputs have at most 12 vertices (8 for fix_lon).  fg_clip_2dx2d_batch: n_out[p] = vertex count,

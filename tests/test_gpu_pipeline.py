@@ -260,12 +260,12 @@ def test_end_to_end_mirror_api_and_conservation(fg, gpu_ok, capsys):
     assert abs(gsum_out - gs_ref) / abs(gs_ref) < 1e-11
 
 
-def _plan_vs_oracle(fg, order, gin, gout):
+def _plan_vs_oracle(fg, order, gin, gout, capacity=None):
     grids = [fg.GridConfig(nx, ny, x, y) for (nx, ny, x, y) in gin]
     plan = fg.XgridPlan.create(order, grids, fg.GridConfig(*gout))
     plan.finalize()
     x = plan.get_xgrid()
-    o = orc.orc_setup(order, gin, [gout])
+    o = orc.orc_setup(order, gin, [gout], capacity=capacity)
     check_xgrid(x, o, order, True)
     st = plan.stats()
     plan.destroy()
@@ -330,6 +330,29 @@ def test_coarse_to_fine_and_fine_to_coarse(fg, gpu_ok):
     lo, la = fg.latlon_corners(12, 6)
     n2, _ = _plan_vs_oracle(fg, 2, [(64, 64, lon[t], lat[t]) for t in (1, 5)], (12, 6, lo, la))
     assert n1 > 0 and n2 > 0
+
+
+def test_fast_search_overflow_falls_back_to_exact_mode(fg, gpu_ok):
+    """The single-sync search sizes its pair buffers at 8*max(nsrc, ndst)+65536; 300 meridional strips against 300 zonal
+    bands make 90 000 pairs from 300 + 300 cells, so the attempt overflows and is repeated with exact sizes -- same
+    exchange cells either way, and equal to forcing exact mode from the start."""
+    lo1, la1 = fg.latlon_corners(300, 1, 0.0, 170.0, -60.0, 60.0)       # cells narrower than pi: fix_lon folds wider ones
+    lo2, la2 = fg.latlon_corners(1, 300, 10.0, 160.0, -50.0, 50.0)
+    gin, gout = [(300, 1, lo1, la1)], (1, 300, lo2, la2)
+    n, st = _plan_vs_oracle(fg, 2, gin, gout, capacity=200000)
+    assert n > 70000 and st["exact_mode"] == 1 and st["pairs"] >= n
+    # an ordinary case stays on the fast path; forcing exact mode gives the same plan
+    lon, lat = fg.gnomonic_ed_corners(16)
+    lo, la = fg.latlon_corners(48, 24)
+    gin, gout = [(16, 16, lon[t], lat[t]) for t in range(6)], (48, 24, lo, la)
+    n1, st1 = _plan_vs_oracle(fg, 2, gin, gout)
+    assert st1["exact_mode"] == 0
+    fg.lib().fg_set_search_mode(1)
+    try:
+        n2, st2 = _plan_vs_oracle(fg, 2, gin, gout)
+    finally:
+        fg.lib().fg_set_search_mode(0)
+    assert st2["exact_mode"] == 1 and n1 == n2 and st1["pairs"] == st2["pairs"]
 
 
 def test_degenerate_sizes_and_empty_overlap(fg, gpu_ok):
