@@ -272,7 +272,7 @@ template <> struct __attribute__((aligned(16))) VecD<4> { double v[4]; };
 
 template <int ORDER, int NB, int V>
 __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const double *f, const double *px, const double *py,
-                                                   double missing, double *out, double *row_sum)
+                                                   double missing, double *out, double *row_sum, long out_ld, int nb_valid)
 {
   constexpr int LPR = NB / V;                        // lanes per row
   constexpr int ROWS = 256 / LPR;                    // rows per block
@@ -329,7 +329,13 @@ __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const dou
     else r.v[k] = missing;
   }
   if (row_sum) *reinterpret_cast<VecD<V> *>(row_sum + (size_t)d * NB + lev) = rs;
-  *reinterpret_cast<VecD<V> *>(out + (size_t)d * NB + lev) = r;
+  if (out_ld > 0) {
+    // level-major output out[level][d] (fg_plan_apply): lanes of one level group hold consecutive rows, so each store
+    // instruction writes 16 consecutive doubles per level -- the separate de-interleave pass is not needed
+#pragma unroll
+    for (int k = 0; k < V; k++) if (lev + k < nb_valid) out[(size_t)(lev + k) * out_ld + d] = r.v[k];
+  } else
+    *reinterpret_cast<VecD<V> *>(out + (size_t)d * NB + lev) = r;
 }
 
 // [nb][n] (level-major, row stride ld) <-> [n][NB] interleaved
@@ -354,6 +360,34 @@ __global__ __launch_bounds__(256) void k_deinterleave(long n, const double *in, 
   for (int k = 0; k < NB; k++) v[k] = in[(size_t)c * NB + k];
 #pragma unroll
   for (int k = 0; k < NB; k++) if (k < nb) out[(size_t)k * ld + c] = v[k];
+}
+
+// Up to three level-major arrays -> interleaved in one launch (blockIdx.y picks the array), transposed through LDS so
+// both the global reads ([level][cell], consecutive cells per level) and the global writes ([cell][NB], consecutive
+// addresses across the block) are fully coalesced.  The per-thread version above wrote 64-byte strided chunks and reached
+// only ~0.5 TB/s.
+struct FgIl3 { const double *in[3]; double *out[3]; long n[3]; long ld[3]; };
+template <int NB>
+__global__ __launch_bounds__(256) void k_interleave3(FgIl3 a, int nb)
+{
+  __shared__ double tile[256 * (NB + 1)];
+  const int w = blockIdx.y;
+  const long n = a.n[w];
+  const long c0 = (long)blockIdx.x * 256;
+  if (c0 >= n) return;
+  const double *in = a.in[w];
+  double *out = a.out[w];
+  const long ld = a.ld[w];
+  const long c = c0 + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < NB; k++) tile[threadIdx.x * (NB + 1) + k] = (k < nb && c < n) ? in[(size_t)k * ld + c] : 0.0;
+  __syncthreads();
+  const long cnt = ((n - c0) < 256 ? (n - c0) : 256) * NB;       // doubles this block writes
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const long e = (long)i * 256 + threadIdx.x;                  // consecutive threads -> consecutive addresses
+    if (e < cnt) out[(size_t)c0 * NB + e] = tile[(e / NB) * (NB + 1) + (e % NB)];
+  }
 }
 
 // interp.c:262-305 (conserve_interp): weights are xarea / (sum of xarea in the destination cell)
@@ -434,22 +468,23 @@ void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *g
 
 template <int NB, int V>
 static void apply_il_nb(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
-                        double *out, double *row_sum, hipStream_t st)
+                        double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st)
 {
   int grid = nblk(ndst, 256 / (NB / V));
-  if (order == 2) k_apply_il<2, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum);
-  else            k_apply_il<1, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum);
+  if (order == 2) k_apply_il<2, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid);
+  else            k_apply_il<1, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid);
 }
-// nb in {2, 4, 8, 16}: interleaved fields [cell][nb]
+// nb in {2, 4, 8, 16}: interleaved fields [cell][nb]; out_ld > 0: write out level-major, out[level][cell] with row stride
+// out_ld for the first nb_valid levels (else interleaved [cell][nb])
 int g_apply_vec = 0;   // levels per lane: 0 = auto (4 for nb = 16, else 2; measured best on MI355X), or force 1 / 2 / 4
 void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
-                  double *out, double *row_sum, hipStream_t st)
+                  double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st)
 {
   if (ndst <= 0) return;
   const int v = g_apply_vec ? g_apply_vec : (nb >= 16 ? 4 : 2);
-#define AP(NB_) do { if (v >= 4 && NB_ >= 4) apply_il_nb<NB_, (NB_ >= 4 ? 4 : 2)>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st); \
-                     else if (v >= 2) apply_il_nb<NB_, 2>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st); \
-                     else apply_il_nb<NB_, 1>(order, ndst, csr, f, gx, gy, missing, out, row_sum, st); } while (0)
+#define AP(NB_) do { if (v >= 4 && NB_ >= 4) apply_il_nb<NB_, (NB_ >= 4 ? 4 : 2)>(order, ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, st); \
+                     else if (v >= 2) apply_il_nb<NB_, 2>(order, ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, st); \
+                     else apply_il_nb<NB_, 1>(order, ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, st); } while (0)
   if (nb == 16) AP(16);
   else if (nb == 8) AP(8);
   else if (nb == 4) AP(4);
@@ -464,6 +499,24 @@ void fgd_interleave(int nb_pad, long n, const double *in, long ld, int nb_valid,
   else if (nb_pad == 8) k_interleave<8><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
   else if (nb_pad == 4) k_interleave<4><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
   else k_interleave<2><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
+}
+// three arrays at once (f, grad_x, grad_y of one chunk of levels); narr = 1 or 3
+void fgd_interleave3(int nb_pad, int narr, const double *const *in, const long *ld, const long *n, double *const *out, int nb_valid,
+                     hipStream_t st)
+{
+  FgIl3 a;
+  long nmax = 0;
+  for (int w = 0; w < 3; w++) {
+    a.in[w] = (w < narr) ? in[w] : nullptr; a.out[w] = (w < narr) ? out[w] : nullptr;
+    a.n[w] = (w < narr) ? n[w] : 0; a.ld[w] = (w < narr) ? ld[w] : 0;
+    if (a.n[w] > nmax) nmax = a.n[w];
+  }
+  if (nmax <= 0) return;
+  dim3 grid(nblk(nmax, 256), narr);
+  if (nb_pad == 16) k_interleave3<16><<<grid, 256, 0, st>>>(a, nb_valid);
+  else if (nb_pad == 8) k_interleave3<8><<<grid, 256, 0, st>>>(a, nb_valid);
+  else if (nb_pad == 4) k_interleave3<4><<<grid, 256, 0, st>>>(a, nb_valid);
+  else k_interleave3<2><<<grid, 256, 0, st>>>(a, nb_valid);
 }
 void fgd_deinterleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st)
 {

@@ -1100,14 +1100,14 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
       if (gsum_out) fgd_reduce_sum(pl->row_sum, ndst, pl->red_partial, pl->red_result + nred++, st);
     } else {
       const int nbp = nbv > 4 ? 8 : (nbv > 2 ? 4 : 2);
-      fgd_interleave(nbp, pl->f_stride, f, pl->f_stride, nbv, pl->il_f, st);
-      if (pl->order == 2) {
-        fgd_interleave(nbp, pl->nsrc, gx, pl->nsrc, nbv, pl->il_gx, st);
-        fgd_interleave(nbp, pl->nsrc, gy, pl->nsrc, nbv, pl->il_gy, st);
+      {
+        const double *ins[3] = {f, gx, gy};
+        double *outs[3] = {pl->il_f, pl->il_gx, pl->il_gy};
+        const long lds[3] = {pl->f_stride, pl->nsrc, pl->nsrc}, ns[3] = {pl->f_stride, pl->nsrc, pl->nsrc};
+        fgd_interleave3(nbp, pl->order == 2 ? 3 : 1, ins, lds, ns, outs, nbv, st);
       }
-      fgd_apply_il(pl->order, nbp, ndst, pl->csr, pl->il_f, pl->il_gx, pl->il_gy, miss, pl->il_out,
-                   gsum_out ? pl->il_rs : nullptr, st);
-      fgd_deinterleave(nbp, ndst, pl->il_out, ndst, nbv, o, st);
+      fgd_apply_il(pl->order, nbp, ndst, pl->csr, pl->il_f, pl->il_gx, pl->il_gy, miss, o,
+                   gsum_out ? pl->il_rs : nullptr, (long)ndst, nbv, st);            // writes level-major directly
       if (gsum_out) fgd_reduce_sum(pl->il_rs, (long)ndst * nbp, pl->red_partial, pl->red_result + nred++, st);
     }
   }
@@ -1288,7 +1288,7 @@ extern "C" int fg_plan_apply_interleaved(fg_plan *pl, int nb, const double *data
   pl->apply_pt.start(g_profiling != 0, pl->stream);
   pl->apply_pt.begin(PH_APPLY);
   fgd_apply_il(pl->order, nb, pl->ndst, pl->csr, data_il, grad_x_il, grad_y_il, -1.e20, out_il,
-               gsum_out ? pl->il_rs : nullptr, pl->stream);
+               gsum_out ? pl->il_rs : nullptr, 0, nb, pl->stream);
   pl->apply_pt.end();
   if (pl->apply_pt.on) pl->apply_spans++;
   if (gsum_out) {
