@@ -42,6 +42,24 @@ def test_no_gpu_fails_loudly(fg):
         fg.create_xgrid_2dx2d_order1(4, 4, 8, 4, lon[0], lat[0], lo, la)
     with pytest.raises(fg.FregridHipError):
         fg.XgridPlan.create(1, [fg.GridConfig(4, 4, lon[0], lat[0])], fg.GridConfig(8, 4, lo, la))
+    with pytest.raises(fg.FregridHipError):
+        fg.create_xgrid_great_circle(4, 4, 8, 4, lon[0], lat[0], lo, la)
+    with pytest.raises(fg.FregridHipError):
+        fg.XgridPlan.create_great_circle([fg.GridConfig(4, 4, lon[0], lat[0])], fg.GridConfig(8, 4, lo, la))
+    with pytest.raises(fg.FregridHipError):
+        fg.create_xgrid_box(True, 1, np.linspace(0, 1, 5), np.linspace(0, 1, 3), 4, 4, lon[0], lat[0])
+    with pytest.raises(fg.FregridHipError):
+        fg.gc_clip_batch(np.zeros((1, 4, 3)), np.zeros((1, 4, 3)))
+    # the plan-level C entry points report the missing device through their return code (no exit, no CPU path)
+    import ctypes as C
+    h = C.c_void_p()
+    nx = (C.c_int * 1)(4)
+    dpt = C.POINTER(C.c_double)
+    a = np.ascontiguousarray(lon[0]).ravel(); b = np.ascontiguousarray(lat[0]).ravel()
+    lo1 = np.ascontiguousarray(lo).ravel(); la1 = np.ascontiguousarray(la).ravel()
+    lonp = (dpt * 1)(a.ctypes.data_as(dpt)); latp = (dpt * 1)(b.ctypes.data_as(dpt))
+    rc = fg.lib().fg_plan_create_great_circle(1, nx, nx, lonp, latp, None, 8, 4, lo1.ctypes.data_as(dpt), la1.ctypes.data_as(dpt), 0, C.byref(h))
+    assert rc == -2 and b"device" in fg.lib().fg_last_error()          # FG_ERR_HIP
 
 
 def test_grid_generator_golden(fg):
