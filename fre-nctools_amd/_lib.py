@@ -33,7 +33,7 @@ EXPORTS = [
     "fg_plan_mono_minmax_dev", "fg_plan_mono_copy_minmax", "fg_plan_mono_end",
     "fg_plan_create_great_circle", "fg_plan_create_great_circle_dev", "fg_latlon2xyz", "create_xgrid_great_circle",
     "create_xgrid_great_circle_", "get_grid_great_circle_area", "get_grid_great_circle_area_", "clip_2dx2d_great_circle",
-    "great_circle_area", "fg_gc_clip_batch", "conserve_interp_great_circle",
+    "great_circle_area", "fg_gc_clip_batch", "conserve_interp_great_circle", "fg_sincos_batch",
     "create_xgrid_1dx2d_order1", "create_xgrid_1dx2d_order2", "create_xgrid_2dx1d_order1", "create_xgrid_2dx1d_order2",
     "create_xgrid_1dx2d_order1_", "create_xgrid_1dx2d_order2_", "create_xgrid_2dx1d_order1_", "create_xgrid_2dx1d_order2_",
     "clip", "box_ctrlat", "box_ctrlon", "get_grid_area_no_adjust", "get_grid_area_no_adjust_", "fg_plan_stream", "fg_plan_sync",
@@ -180,6 +180,8 @@ def lib():
     L.box_ctrlon.restype = C.c_double
     L.get_grid_area_no_adjust.argtypes = [cip, cip, dp, dp, dp]
     L.get_grid_area_no_adjust.restype = None
+    L.fg_sincos_batch.argtypes = [C.c_long, dp, dp, dp, C.c_int]
+    L.fg_sincos_batch.restype = C.c_int
     L.fg_gc_clip_batch.argtypes = [C.c_int, dp, dp, dp, ip, dp, C.c_int]
     L.fg_gc_clip_batch.restype = C.c_int
     L.fg_plan_stream.argtypes = [vp]

@@ -186,7 +186,10 @@ __global__ void k_box_ctr(double ll_lon, double ll_lat, double ur_lon, double ur
     double dphi = ur_lon - ll_lon;
     if (dphi > G_PI) dphi = dphi - 2.0 * G_PI;
     if (dphi < -G_PI) dphi = dphi + 2.0 * G_PI;
-    const double ctrlat = dphi * (d_cos_lat(ur_lat) + ur_lat * d_sin_lat(ur_lat) - (d_cos_lat(ll_lat) + ll_lat * d_sin_lat(ll_lat)));
+    double su, cu, sl, cl;                                   // two sincos() calls in the reference's object code
+    d_sincos_lat(ur_lat, &su, &cu);
+    d_sincos_lat(ll_lat, &sl, &cl);
+    const double ctrlat = dphi * (cu + ur_lat * su - (cl + ll_lat * sl));
     out[0] = ctrlat * G_RADIUS * G_RADIUS;
   }
   double ctrlon = 0.0;
@@ -195,8 +198,10 @@ __global__ void k_box_ctr(double ll_lon, double ll_lat, double ur_lon, double ur
     if (i == 0) { phi1 = ur_lon; phi2 = ll_lon; lat1 = lat2 = ll_lat; }
     else { phi1 = ll_lon; phi2 = ur_lon; lat1 = lat2 = ur_lat; }
     double dphi = phi1 - phi2;
-    const double f1 = 0.5 * (d_cos_lat(lat1) * d_sin_lat(lat1) + lat1);
-    const double f2 = 0.5 * (d_cos_lat(lat2) * d_sin_lat(lat2) + lat2);
+    double s1, c1;                                           // lat1 == lat2: one sincos() per pass in the reference
+    d_sincos_lat(lat1, &s1, &c1);
+    const double f1 = 0.5 * (c1 * s1 + lat1);
+    const double f2 = 0.5 * (c1 * s1 + lat2);
     if (dphi > G_PI) dphi = dphi - 2.0 * G_PI;
     if (dphi < -G_PI) dphi = dphi + 2.0 * G_PI;
     double dphi1 = phi1 - clon;

@@ -34,57 +34,19 @@
 #define G_ERRBIT_BADLAT   8u
 
 // ---------------------------------------------------------------------------------------
-// sin/cos for latitude-like arguments (|x| <= pi/2 in practice; valid to 3pi/4 -- grids with a
-// latitude outside [-pi/2, pi/2] are rejected by k_cell_struct, and clip vertices stay inside the
-// bounding boxes of their parents).  The generic double-precision sincos carries a Payne-Hanek /
-// Cody-Waite range reduction the hot kernels never need; here |x| <= pi/4 goes straight to the
-// minimax kernels and pi/4 < |x| uses the complement pi/2 - |x| (two-term pi/2).  Kernel polynomials
-// are the classic fdlibm k_sin/k_cos coefficients (error < 2^-58 on [-pi/4, pi/4]); measured <= 1 ulp
-// against glibc over [-pi/2, pi/2].  Areas and centroids only need 1e-10 relative; the
-// membership decisions never depend on these values except through the tracked 1e-6 area ratio.
+// sin/cos for latitude-like arguments: the host libm's own operation sequence (sincos_glibc.h -- glibc 2.35 do_sin /
+// do_cos over the 1/128 table, checked bit for bit against libm on the host by tests/test_sincos_host.py), so that
+// poly_area, poly_ctrlon and poly_ctrlat -- whose other operations are plain IEEE add/mul/div in the reference's
+// order -- produce the reference's BITS on the device, not just its value to an ulp.  Valid for |x| < 2.426; grids with a
+// latitude outside [-pi/2, pi/2] are rejected by k_cell_struct and clip vertices stay inside their parents' boxes.
+// (An earlier fdlibm-coefficient kernel differed from libm in the last place for 6 % of sines and 14 % of cosines; the
+// cancellation in poly_area turned that into up to 1.3e-10 relative on the thinnest exchange cells at C768.)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double d_ksin(double x)
-{
-  const double z = x * x;
-  double r = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  r = fma(z, r, 2.75573137070700676789e-06);
-  r = fma(z, r, -1.98412698298579493134e-04);
-  r = fma(z, r, 8.33333333332248946124e-03);
-  const double v = z * x;
-  return fma(v, fma(z, r, -1.66666666666666324348e-01), x);
-}
-__device__ __forceinline__ double d_kcos(double x)
-{
-  const double z = x * x;
-  double r = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  r = fma(z, r, -2.75573143513906633035e-07);
-  r = fma(z, r, 2.48015872894767294178e-05);
-  r = fma(z, r, -1.38888888888741095749e-03);
-  r = fma(z, r, 4.16666666666666019037e-02);
-  const double hz = 0.5 * z;
-  const double w = 1.0 - hz;
-  return w + (((1.0 - w) - hz) + (z * (z * r)));
-}
-__device__ __forceinline__ void d_sincos_lat(double x, double *s, double *c)
-{
-  const double ax = fabs(x);                           // callers guarantee |x| <= 3pi/4 (k_cell_struct validates latitudes)
-  const bool big = ax > 0.78539816339744828;
-  const double y = big ? (1.57079632679489655800e+00 - ax) + 6.12323399573676603587e-17 : ax;
-  const double sk = d_ksin(y), ck = d_kcos(y);
-  const double sn = big ? ck : sk;
-  *c = big ? sk : ck;
-  *s = (x < 0) ? -sn : sn;
-}
-__device__ __forceinline__ double d_sin_lat(double x)
-{
-  if (fabs(x) <= 0.78539816339744828) return d_ksin(x);
-  double s, c; d_sincos_lat(x, &s, &c); return s;
-}
-__device__ __forceinline__ double d_cos_lat(double x)
-{
-  if (fabs(x) <= 0.78539816339744828) return d_kcos(x);
-  double s, c; d_sincos_lat(x, &s, &c); return c;
-}
+#include "sincos_glibc.h"
+__device__ __forceinline__ double d_sin_lat(double x) { return fgs_sin(x); }
+__device__ __forceinline__ double d_cos_lat(double x) { return fgs_cos(x); }
+// libm sincos(): what gcc -O2 emits in the reference for sin(a) and cos(a) of one argument in one expression
+__device__ __forceinline__ void d_sincos_lat(double x, double *s, double *c) { fgs_sincos(x, s, c); }
 
 __device__ __forceinline__ bool d_is_pole(double lat) { return fabs(lat) >= G_HPI - G_POLETOL; }
 
@@ -177,6 +139,9 @@ __device__ inline double d_poly_area(const double *x, const double *y, int n)
   return area * G_RADIUS * G_RADIUS;
 }
 
+// Which libm entry each term goes through follows the reference's gcc -O2 object code (oracle/_ref, objdump):
+// cos(lat1) is a plain cos() hoisted above the branch; the flat branch calls cos(avg_y) and sin(avg_y) separately;
+// the general branch calls sincos(avg_y) and sin(hdy).
 template <int S>
 __device__ inline double d_poly_ctrlat(const double *x, const double *y, int n)
 {
@@ -191,10 +156,14 @@ __device__ inline double d_poly_ctrlat(const double *x, const double *y, int n)
     if (dx == 0.0) continue;
     if (dx > G_PI)   dx = dx - 2.0 * G_PI;
     if (dx <= -G_PI) dx = dx + 2.0 * G_PI;
+    const double cl1 = d_cos_lat(lat1);
     if (fabs(hdy) < G_SMALL)
-      ctrlat -= dx * (2 * d_cos_lat(avg_y) + lat2 * d_sin_lat(avg_y) - d_cos_lat(lat1));
-    else
-      ctrlat -= dx * ((d_sin_lat(hdy) / hdy) * (2 * d_cos_lat(avg_y) + lat2 * d_sin_lat(avg_y)) - d_cos_lat(lat1));
+      ctrlat -= dx * (2 * d_cos_lat(avg_y) + lat2 * d_sin_lat(avg_y) - cl1);
+    else {
+      double sa, ca;
+      d_sincos_lat(avg_y, &sa, &ca);
+      ctrlat -= dx * ((d_sin_lat(hdy) / hdy) * (2 * ca + lat2 * sa) - cl1);
+    }
   }
   return (ctrlat * G_RADIUS * G_RADIUS);
 }
@@ -209,8 +178,11 @@ __device__ inline double d_poly_ctrlon(const double *x, const double *y, int n, 
     double lat1 = y[ip * S], lat2 = y[i * S];
     double dphi = phi1 - phi2;
     if (dphi == 0.0) continue;
-    double f1 = 0.5 * (d_cos_lat(lat1) * d_sin_lat(lat1) + lat1);
-    double f2 = 0.5 * (d_cos_lat(lat2) * d_sin_lat(lat2) + lat2);
+    double sl1, cl1, sl2, cl2;                        // cos(lat)*sin(lat) is one sincos() call in the reference's object code
+    d_sincos_lat(lat1, &sl1, &cl1);
+    d_sincos_lat(lat2, &sl2, &cl2);
+    double f1 = 0.5 * (cl1 * sl1 + lat1);
+    double f2 = 0.5 * (cl2 * sl2 + lat2);
     if (dphi > G_PI)  dphi = dphi - 2.0 * G_PI;
     if (dphi < -G_PI) dphi = dphi + 2.0 * G_PI;
     double dphi1 = phi1 - clon;
@@ -240,21 +212,21 @@ __device__ inline void d_poly_area_ctr(const double *x, const double *y, int n, 
                                        double *area_out, double *ctrlon_out, double *ctrlat_out)
 {
   double area = 0.0, ctrlat = 0.0, ctrlon = 0.0;
-  // vertex i is (phi2, lat2); vertex ip is (phi1, lat1)
+  // vertex i is (phi2, lat2); vertex ip is (phi1, lat1).  Per vertex: sincos() for poly_ctrlon's f, plain cos() for
+  // poly_ctrlat's cos(lat1) -- the libm entries the reference's object code goes through (see d_poly_ctrlat above).
   double s2, c2;
   d_sincos_lat(y[0], &s2, &c2);
-  const double s_first = s2, c_first = c2;
+  const double s_first = s2, c_first = c2, cp_first = d_cos_lat(y[0]);
   for (int i = 0; i < n; i++) {
     const bool last = (i + 1 == n);
     int ip = last ? 0 : i + 1;
     double phi1 = x[ip * S], phi2 = x[i * S];
     double lat1 = y[ip * S], lat2 = y[i * S];
-    double s1, c1;
-    if (last) { s1 = s_first; c1 = c_first; } else d_sincos_lat(lat1, &s1, &c1);
+    double s1, c1, cp1;
+    if (last) { s1 = s_first; c1 = c_first; cp1 = cp_first; } else { d_sincos_lat(lat1, &s1, &c1); cp1 = d_cos_lat(lat1); }
     double dx0 = phi1 - phi2;               // x[ip]-x[i]
     double avg_y = (lat1 + lat2) * 0.5;      // == 0.5*(lat1+lat2)
-    double savg, cavg;
-    d_sincos_lat(avg_y, &savg, &cavg);
+    const double savg = d_sin_lat(avg_y);    // poly_area: plain sin()
     double dyh = 0.5 * (lat1 - lat2);        // poly_area's dy; ctrlat's hdy == -dyh
     // poly_area tests |lat1-lat2| < 1e-10, poly_ctrlat tests |(lat2-lat1)/2| < 1e-10; the
     // first implies the second, so d_sin_lat(dyh)/dyh is needed exactly when the first fails.
@@ -278,9 +250,13 @@ __device__ inline void d_poly_area_ctr(const double *x, const double *y, int n, 
       if (dx <= -G_PI) dx = dx + 2.0 * G_PI;
       double hdy = (lat2 - lat1) * 0.5;
       if (fabs(hdy) < G_SMALL)
-        ctrlat -= dx * (2 * cavg + lat2 * savg - c1);
-      else
-        ctrlat -= dx * (dat * (2 * cavg + lat2 * savg) - c1);
+        ctrlat -= dx * (2 * d_cos_lat(avg_y) + lat2 * savg - cp1);          // flat branch: separate cos() and sin()
+      else {
+        double sa, ca;
+        d_sincos_lat(avg_y, &sa, &ca);                                      // general branch: sincos(avg_y)
+        const double datc = flat ? d_sin_lat(dyh) / dyh : dat;              // (|hdy| >= 1e-10 > |lat1-lat2| cannot happen)
+        ctrlat -= dx * (datc * (2 * ca + lat2 * sa) - cp1);
+      }
     }
     // ---- poly_ctrlon (create_xgrid.c:2176-2214)
     if (dx0 != 0.0) {

@@ -1426,6 +1426,28 @@ extern "C" double great_circle_area(int n, const double *x, const double *y, con
   return area;
 }
 
+// sin / cos of n host values with the device's latitude trig (sincos_glibc.h): parity probe for the tests
+extern "C" int fg_sincos_batch(long n, const double *x, double *s, double *c, int device)
+{
+  if (n < 0 || !x || !s || !c) return fail(FG_ERR_ARG, "null argument");
+  if (n == 0) return 0;
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(FG_ERR_HIP, "no HIP device visible: libfregrid_hip needs an MI355X-class GPU");
+  HIPCHK(hipSetDevice(device));
+  double *d = (double *)g_pool.get(device, 3 * (size_t)n * sizeof(double));
+  if (!d) return fail(FG_ERR_HIP, "out of device memory");
+  bool ok = hipMemcpy(d, x, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    fgd_sincos_probe(n, d, d + n, d + 2 * n, nullptr);
+    ok = hipMemcpy(s, d + n, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(c, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  g_pool.put(d);
+  if (!ok) return fail(FG_ERR_HIP, "fg_sincos_batch: HIP copy/launch failed");
+  return 0;
+}
+
 // clip_2dx2d_great_circle / great_circle_area, one polygon pair per call (create_xgrid.h / mosaic_util.h prototypes)
 extern "C" int clip_2dx2d_great_circle(const double x1_in[], const double y1_in[], const double z1_in[], int n1_in,
                                        const double x2_in[], const double y2_in[], const double z2_in[], int n2_in,

@@ -112,3 +112,15 @@ void fgd_poly_op(int op, int npoly, double *lon, double *lat, int *n, const doub
 {
   if (npoly > 0) k_poly_op<<<(npoly + 63) / 64, 64, 0, st>>>(op, npoly, lon, lat, n, clon, result);
 }
+
+// sin/cos of an array with the device's latitude trig (parity probe: must equal the host libm bit for bit)
+__global__ __launch_bounds__(256) void k_sincos_probe(long n, const double *x, double *s, double *c)
+{
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  s[i] = d_sin_lat(x[i]); c[i] = d_cos_lat(x[i]);
+}
+void fgd_sincos_probe(long n, const double *x, double *s, double *c, hipStream_t st)
+{
+  if (n > 0) k_sincos_probe<<<(int)((n + 255) / 256), 256, 0, st>>>(n, x, s, c);
+}

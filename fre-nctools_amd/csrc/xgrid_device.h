@@ -163,6 +163,7 @@ void fgd_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *
 void fgd_poly_clip(int npoly, const double *lon1, const double *lat1, const int *n1, const double *lon2, const double *lat2,
                    const int *n2, double *lon_out, double *lat_out, int *n_out, hipStream_t st);
 void fgd_poly_op(int op, int npoly, double *lon, double *lat, int *n, const double *clon, double *result, hipStream_t st);
+void fgd_sincos_probe(long n, const double *x, double *s, double *c, hipStream_t st);
 
 // ---- order-2 input preparation (c2l_kernels.hip)
 void fgd_pack_interior(const void *tiles, int ntiles, long ncells, long F, int nz, const double *src, double *dst, hipStream_t st);

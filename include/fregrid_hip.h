@@ -425,6 +425,10 @@ double box_ctrlon(double ll_lon, double ll_lat, double ur_lon, double ur_lat, do
 void get_grid_area_no_adjust(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
 void get_grid_area_no_adjust_(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);
 
+/* sin and cos of n host values as the device kernels evaluate them for latitudes (|x| < 2.426): a parity probe --
+ * the results must equal the host libm's bit for bit (tests/test_gpu_xgrid.py). */
+int fg_sincos_batch(long n, const double *x, double *s, double *c, int device);
+
 /* Tripolar ocean grid (make_hgrid --grid_type tripolar_grid, uniform bounds, Murray bipolar cap north of lat_join):
  * nlon x nlat model cells, bounds in degrees, lonc/latc[(nlat+1)*(nlon+1)] radians.  Input synthesis only (see grid_gen.c). */
 int fg_tripolar_corners(int nlon, int nlat, double xbnd0, double xbnd1, double ybnd0, double ybnd1, double lat_join,

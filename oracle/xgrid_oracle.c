@@ -942,3 +942,9 @@ double orc_gsum_in_ex(int order, int ntiles_in, const int *nx_in, const int *ny_
   }
   return g;
 }
+
+/* libm's sin / cos on an array (the device's latitude trig must equal these bit for bit, tests/test_gpu_xgrid.py) */
+void orc_sincos(long n, const double *x, double *s, double *c)
+{
+  for (long i = 0; i < n; i++) { s[i] = sin(x[i]); c[i] = cos(x[i]); }
+}

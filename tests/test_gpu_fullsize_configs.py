@@ -2,6 +2,7 @@
 parity on sampled source rows (the brute-force oracle cannot finish these sizes):
   config 4a  C768 -> 2880x1440, great-circle clip, first order, write the remap file (order 2 + great circle is rejected
              by the reference itself, fregrid.c:763 -- SURVEY §8d)
+  config 4b  C768 -> 2880x1440, legacy clip, second order (the order-2 half of config 4)
   config 5   tripolar 1440x1080 -> C384 mosaic (six destination tiles), first order, cached remap files read back,
              3-D field sweep through the READ-branch plans"""
 import os
@@ -128,3 +129,46 @@ def test_config5_tripolar_to_c384_cached_remap_and_3d_sweep(fg, gpu_ok, tmp_path
     assert abs(gsum_out - gsum_in) < 2e-6 * abs(gsum_in)
     for ic in interp + interp_r:
         ic.plan.destroy()
+
+
+def test_config4b_c768_legacy_order2_full_size(fg, gpu_ok):
+    import torch
+    ni, nlon, nlat = 768, 2880, 1440
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    plan = fg.XgridPlan.create(2, grids, fg.GridConfig(nlon, nlat, lo, la))
+    st = plan.stats()
+    assert st["borderline"] == 0 and st["exact_mode"] == 0
+    plan.finalize()
+    x = plan.get_xgrid()
+    n = plan.nxgrid
+    assert 16_000_000 < n < 17_500_000
+    s = x["t_in"].astype(np.int64) * ni * ni + x["j_in"].astype(np.int64) * ni + x["i_in"]
+    d = x["j_out"].astype(np.int64) * nlon + x["i_out"]
+    assert np.all(np.diff(s * (nlon * nlat) + d) > 0)
+    assert abs(x["area"].sum() / (4 * np.pi * R * R) - 1) < 5e-9
+    a_in, a_out = plan.get_cell_area(nlon * nlat)
+    cov = np.bincount(d, weights=x["area"], minlength=nlon * nlat)
+    assert np.max(np.abs(cov - a_out) / a_out) < 1e-4                  # conserve_interp.c:479 bound
+    for arr in (x["c1"], x["c2"]):                                     # centroid distances balance per source cell
+        tot = np.bincount(s, weights=arr * x["area"], minlength=6 * ni * ni)
+        assert np.max(np.abs(tot)) < 1e-9 * np.max(a_in)
+    # oracle parity on one polar source row (brute force over the 4.1 M destination cells)
+    o = orc.orc_create_xgrid(2, ni, ni, nlon, nlat, lon[2], lat[2], lo, la, j1_beg=0, j1_end=1, capacity=200000)
+    sel = (x["t_in"] == 2) & (x["j_in"] == 0)
+    assert sel.sum() == o["n"] > 0
+    for k in ("i_in", "i_out", "j_out"):
+        assert np.array_equal(x[k][sel], o[k]), k
+    assert np.max(np.abs(x["area"][sel] - o["area"]) / o["area"]) < 1e-10
+    # sweep: constants preserved on 4 levels
+    dev = "cuda:0"
+    F, ncell = 6 * (ni + 2) ** 2, 6 * ni * ni
+    data = torch.full((4, F), 2.5, dtype=torch.float64, device=dev)
+    z = torch.zeros(4, ncell, dtype=torch.float64, device=dev)
+    out = torch.empty(4, nlon * nlat, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    plan.apply(data, out, nz=4, grad_x_t=z, grad_y_t=z)
+    plan.sync()
+    assert float((out - 2.5).abs().max()) < 1e-13
+    plan.destroy()
