@@ -68,6 +68,28 @@ def test_create_xgrid_c48(fg, gpu_ok, c48, order, nlon, nlat, tile, nexp):
         # clon/clat are integrals that can cancel to ~0: compare against the area scale
         for a, k in ((r[6], "clon"), (r[7], "clat")):
             assert np.max(np.abs(a - o[k])) <= RTOL * np.max(np.abs(o[k])), k
+    # stronger than the bar: bit-identical (libm-sequence sin/cos on the device, csrc/sincos_glibc.h)
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+    assert np.array_equal(bits(r[5]), bits(o["area"]))
+    if order == 2:
+        assert np.array_equal(bits(r[6]), bits(o["clon"])) and np.array_equal(bits(r[7]), bits(o["clat"]))
+
+
+def test_device_sincos_equals_host_libm(fg, gpu_ok):
+    """The device's latitude trig against the oracle's libm calls on 3 M arguments: plain sin/cos bit for bit."""
+    import ctypes as C
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-np.pi / 2, np.pi / 2, 2000000), rng.uniform(-0.126, 0.126, 500000),
+                        rng.uniform(-1, 1, 500000) * 2.0 ** (-rng.integers(0, 40, 500000))])
+    s, c, rs, rc = (np.empty_like(x) for _ in range(4))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert fg.lib().fg_sincos_batch(x.size, dp(x), dp(s), dp(c), 0) == 0
+    O = orc.oracle()
+    O.orc_sincos.argtypes = [C.c_long] + [C.POINTER(C.c_double)] * 3
+    O.orc_sincos.restype = None
+    O.orc_sincos(x.size, dp(x), dp(rs), dp(rc))
+    assert np.array_equal(bits(s), bits(rs)) and np.array_equal(bits(c), bits(rc))
 
 
 def test_create_xgrid_masked(fg, gpu_ok, c48):
