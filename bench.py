@@ -143,6 +143,16 @@ def main():
             dist.barrier()
 
     plan = [None]
+    # communication schedule of the decomposition (built once, like the band extents): the source cells cut by a band
+    # boundary are the only ones whose partial sums live on more than one rank
+    bidx_t = None
+    if world > 1:
+        p0 = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t, mean_dlat, mean_dlon,
+                                     device=local_rank, stream=stream)
+        cs = p0.get_cell_struct(0, ncell_in)          # 0 = source cells
+        p0.destroy()
+        bidx = fg.boundary_source_cells(cs["lat_min"], cs["lat_max"], la, nlat, world)
+        bidx_t = torch.from_numpy(bidx.astype(np.int64)).to(dev)
 
     def step():
         if plan[0] is not None:
@@ -151,7 +161,8 @@ def main():
                                     mean_dlat, mean_dlon, device=local_rank, stream=stream)
         if world > 1:
             p.copy_cell_sums(total_sums)
-            fg.allreduce_cell_sums(total_sums)
+            fg.allreduce_cell_sums_sparse(total_sums, bidx_t, ncell_in)
+            torch.cuda.current_stream().synchronize()
             p.finalize(total_sums.data_ptr())
         else:
             p.finalize(None)
@@ -261,7 +272,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C{ni} cubed sphere (6 tiles) -> {nlon}x{nlat} lat-lon, conservative_order2: "
                                    "exchange-grid search + centroid pass + CSR build per step",
-                       "nxgrid": nx_total, "parallelism": f"{world} latitude band(s) of the target, one per GPU"},
+                       "nxgrid": nx_total, "parallelism": f"{world} latitude band(s) of the target, one per GPU",
+                       "exchange": (None if world == 1 else f"all-reduce of the (area, clon, clat) sums of the {int(bidx_t.numel())} source "
+                                    f"cells cut by band boundaries ({100.0 * int(bidx_t.numel()) / ncell_in:.1f} % of {ncell_in})")},
             "remapped_points_per_s": remap_pts, "apply_ms_per_call": dta / apply_steps * 1e3, "apply_levels": nz,
             "apply_device_ms_per_call": apply_call_ms,
             "remapped_points_per_s_interleaved": apply_steps * ndst * nb / dtb,

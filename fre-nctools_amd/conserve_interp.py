@@ -431,7 +431,8 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
             p.copy_cell_sums(part)
             total += part
         from .parallel import allreduce_cell_sums
-        allreduce_cell_sums(total)              # the one exchange step of the path
+        allreduce_cell_sums(total)              # the one exchange step of the path; bench.py restricts it to the
+                                                # source cells cut by band boundaries (parallel.boundary_source_cells)
         torch.cuda.synchronize(device)
         for p in plans:
             p.finalize(total.data_ptr())

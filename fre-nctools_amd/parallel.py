@@ -48,3 +48,38 @@ def allreduce_minmax(fmin, fmax):
         dist.all_reduce(fmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(fmax, op=dist.ReduceOp.MAX)
     return fmin, fmax
+
+
+def boundary_source_cells(lat_min, lat_max, lat_out, nlat, nranks):
+    """Indices of the source cells whose latitude range meets a boundary between two destination bands.
+
+    Only these cells can have exchange cells on more than one rank, so only their (area, clon, clat) partial sums need
+    the exchange of conserve_interp.c:203-221; every other cell's sums are complete on the one rank whose band holds it
+    (and zero elsewhere).  `lat_min/lat_max` [ncells_in] are the per-cell latitude ranges (fg_plan_get_cell_struct);
+    `lat_out` [nlat+1, nlon+1] the destination corner latitudes.  A boundary is the corner row between two bands; its
+    latitude interval is the min/max over that row (a single value for a lat-lon grid), widened by 1e-9 rad.  The list
+    depends only on the grids and the decomposition and is identical on every rank."""
+    import numpy as np
+    flag = np.zeros(lat_min.shape, dtype=bool)
+    for r in range(nranks - 1):
+        j1 = band_rows(nlat, nranks, r)[1]
+        row = np.asarray(lat_out)[j1]
+        bmin, bmax = float(row.min()) - 1e-9, float(row.max()) + 1e-9
+        flag |= (lat_min <= bmax) & (lat_max >= bmin)
+    return np.flatnonzero(flag)
+
+
+def allreduce_cell_sums_sparse(total, idx_t, ncells):
+    """Sum over ranks of the [3*ncells] tensor restricted to the cells `idx_t` (device int64 tensor from
+    boundary_source_cells); the other entries keep their local values.  Equivalent to allreduce_cell_sums when every cell
+    outside idx has contributions from at most one rank, at a fraction of the message size (2 % of the cells for C384 on 8
+    bands)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return total
+    v = total.view(3, ncells)
+    part = v[:, idx_t].contiguous()
+    dist.all_reduce(part)
+    v[:, idx_t] = part
+    return total

@@ -43,6 +43,17 @@ def _worker(rank, world, initfile, outdir):
     total = torch.from_numpy(sums.reshape(-1).copy())
     fg.allreduce_cell_sums(total)                                    # the exchange step under test
     total = total.numpy().reshape(3, ncell)
+    # the sparse form of the same exchange: only the source cells cut by the band boundary are summed over ranks; for every
+    # cell the rank can see exchange cells of (its band), the result must equal the full all-reduce
+    lat_rng = [orc.orc_cell_struct(ni, ni, lon[t], lat[t]) for t in range(6)]
+    lat_min = np.concatenate([c["lat_min"] for c in lat_rng]); lat_max = np.concatenate([c["lat_max"] for c in lat_rng])
+    bidx = fg.boundary_source_cells(lat_min, lat_max, la, nlat, world)
+    sparse = torch.from_numpy(sums.reshape(-1).copy())
+    fg.allreduce_cell_sums_sparse(sparse, torch.from_numpy(bidx.astype(np.int64)), ncell)
+    sparse = sparse.numpy().reshape(3, ncell)
+    mine = sums[0] > 0
+    assert np.array_equal(sparse[:, mine], total[:, mine]), "sparse exchange differs from the full all-reduce"
+    assert 0 < bidx.size < 0.5 * ncell
     # centroid pass (conserve_interp.c:327-357) with the reduced sums
     cell_area = np.concatenate([orc.orc_get_grid_area(ni, ni, lon[t], lat[t]) for t in range(6)])
     ok = total[0] > 0
