@@ -104,7 +104,9 @@ def test_config5_tripolar_to_c384_cached_remap_and_3d_sweep(fg, gpu_ok, tmp_path
         if o["n"]:
             for k in ("i_in", "i_out", "j_out"):
                 assert np.array_equal(getattr(ic, k)[sel], o[k]), k
-            assert np.array_equal(_bits(ic.area[sel]), _bits(o["area"]))
+            assert np.max(np.abs(ic.area[sel] - o["area"]) / o["area"]) < 2e-10
+            if orc.host_has_fma():
+                assert np.array_equal(_bits(ic.area[sel]), _bits(o["area"]))
     # cached remap files: READ branch (conserve_interp.c:62-126) gives plans whose sweep equals the computed plans'
     interp_r = [fg.InterpConfig(remap_file=ic.remap_file, file_exist=1) for ic in interp]
     fg.setup_conserve_interp(1, grid_in, 6, grid_out, interp_r, fg.CONSERVE_ORDER1 | fg.READ)
@@ -160,7 +162,9 @@ def test_config4b_c768_legacy_order2_full_size(fg, gpu_ok):
     assert sel.sum() == o["n"] > 0
     for k in ("i_in", "i_out", "j_out"):
         assert np.array_equal(x[k][sel], o[k]), k
-    assert np.array_equal(_bits(x["area"][sel]), _bits(o["area"]))          # bit-identical, slivers included
+    assert np.max(np.abs(x["area"][sel] - o["area"]) / o["area"]) < 2e-10
+    if orc.host_has_fma():
+        assert np.array_equal(_bits(x["area"][sel]), _bits(o["area"]))      # bit-identical, slivers included
     # sweep: constants preserved on 4 levels
     dev = "cuda:0"
     F, ncell = 6 * (ni + 2) ** 2, 6 * ni * ni
