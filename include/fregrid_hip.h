@@ -11,7 +11,13 @@
  *         create_xgrid_2dx2d_order1  tools/libfrencutils/create_xgrid.c:621   (create_xgrid.h:65)
  *         create_xgrid_2dx2d_order2  tools/libfrencutils/create_xgrid.c:893   (create_xgrid.h:69)
  *         conserve_interp            tools/libfrencutils/interp.c:262         (interp.h)
- *         + trailing-underscore Fortran aliases (create_xgrid.c:60,608,881)
+ *         create_xgrid_great_circle  tools/libfrencutils/create_xgrid.c:1366  (create_xgrid.h:77)
+ *         get_grid_great_circle_area create_xgrid.c:98, clip_2dx2d_great_circle :1479, great_circle_area mosaic_util.c:763,
+ *         conserve_interp_great_circle interp.c:312
+ *         create_xgrid_1dx2d_order1/2 create_xgrid.c:208/311, create_xgrid_2dx1d_order1/2 :414/509, clip :1159,
+ *         box_ctrlat/box_ctrlon :2223/:2238, get_grid_area_no_adjust :166
+ *         clip_2dx2d :1266, poly_area mosaic_util.c:474, poly_ctrlon/poly_ctrlat create_xgrid.c:2170/2096, fix_lon, pimod
+ *         + trailing-underscore Fortran aliases (create_xgrid.c:60,91,196,301,396,491,608,881,1353)
  *
  *  (B2) device-resident "plan" API that replaces the pair
  *         setup_conserve_interp      tools/fregrid/conserve_interp.c:42   (compute branch :127-358)
@@ -20,6 +26,10 @@
  *       INTEGRATION.md shows the conserve_interp_hip.c a maintainer links in place of
  *       conserve_interp.o (the same swap the reference's own fregrid_gpu makes,
  *       tools/fregrid_gpu/Makefile.am:28-41).
+ *
+ *  (F)  the callers either side of the path: fg_c2l_* (halo update + grad_c2l on the device,
+ *       fregrid_util.c:2168-2216, gradient_c2l.c:58-118), fg_remap_* (fregrid's remap file without libnetcdf,
+ *       conserve_interp.c:368-445 / :62-126).
  *
  *  (G)  host grid generators used to synthesise inputs without make_hgrid files.
  *
