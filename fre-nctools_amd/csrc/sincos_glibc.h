@@ -60,12 +60,16 @@ FG_HD double fgs_taylor_sin(double xx, double x, double dx)
   return x + t;
 }
 
-template <bool FMA>
+/* ZDX: the caller passes dx = 0 (arguments below 0.855): `0 + t`, `x*0 + v`, `fma(m, P, 0)`, `fma(x, 0, v)` and `xr + 0` are the
+ * identity on the values that occur (xr >= +0 by construction, a - a = +0; the one sign-of-zero case, t = -0 with x = 0,
+ * still sums to +0), so they are dropped -- which also lets the compiler share xx, the polynomials and c between the sine
+ * and the cosine of one argument.  Checked bit for bit against libm like everything else in this file. */
+template <bool FMA, bool ZDX>
 FG_HD double fgs_do_sin(double x, double dx)
 {
   const double xold = x;
-  if (fabs(x) < 0.126) return fgs_taylor_sin<FMA>(x * x, x, dx);
-  if (x <= 0) dx = -dx;
+  if (fabs(x) < 0.126) return fgs_taylor_sin<FMA>(x * x, x, ZDX ? 0.0 : dx);
+  if (!ZDX && x <= 0) dx = -dx;
   const double u = FGS_BIG + fabs(x);
   x = fabs(x) - (u - FGS_BIG);
   const double xx = x * x;
@@ -73,23 +77,25 @@ FG_HD double fgs_do_sin(double x, double dx)
   const double sn = FG_SINCOS_TAB[k][0], ssn = FG_SINCOS_TAB[k][1], cs = FG_SINCOS_TAB[k][2], ccs = FG_SINCOS_TAB[k][3];
   double s, c, cor;
   if (FMA) {
-    s = x + fma(x * xx, fma(xx, FGS_SN5, FGS_SN3), dx);
-    c = fma(x, dx, xx * fma(xx, fma(xx, FGS_CS6, FGS_CS4), FGS_CS2));
+    const double P = fma(xx, FGS_SN5, FGS_SN3), Q = fma(xx, fma(xx, FGS_CS6, FGS_CS4), FGS_CS2);
+    s = ZDX ? x + (x * xx) * P : x + fma(x * xx, P, dx);
+    c = ZDX ? xx * Q : fma(x, dx, xx * Q);
     cor = fma(cs, s, fma(-sn, c, fma(s, ccs, ssn)));
   } else {
-    s = x + (dx + x * xx * (FGS_SN3 + xx * FGS_SN5));
-    c = x * dx + xx * (FGS_CS2 + xx * (FGS_CS4 + xx * FGS_CS6));
+    const double P = FGS_SN3 + xx * FGS_SN5, Q = FGS_CS2 + xx * (FGS_CS4 + xx * FGS_CS6);
+    s = ZDX ? x + x * xx * P : x + (dx + x * xx * P);
+    c = ZDX ? xx * Q : x * dx + xx * Q;
     cor = (ssn + s * ccs - sn * c) + cs * s;
   }
   return copysign(sn + cor, xold);
 }
 
-template <bool FMA>
+template <bool FMA, bool ZDX>
 FG_HD double fgs_do_cos(double x, double dx)
 {
-  if (x < 0) dx = -dx;
+  if (!ZDX && x < 0) dx = -dx;
   const double u = FGS_BIG + fabs(x);
-  x = fabs(x) - (u - FGS_BIG) + dx;
+  x = ZDX ? fabs(x) - (u - FGS_BIG) : fabs(x) - (u - FGS_BIG) + dx;
   const double xx = x * x;
   const int k = fgs_index(u);
   const double sn = FG_SINCOS_TAB[k][0], ssn = FG_SINCOS_TAB[k][1], cs = FG_SINCOS_TAB[k][2], ccs = FG_SINCOS_TAB[k][3];
@@ -111,29 +117,29 @@ FG_HD double fgs_sin(double x)
 {
   const double ax = fabs(x);
   if (ax < 0x1p-26) return x;
-  if (ax < 0.85546875) return fgs_do_sin<true>(x, 0);
+  if (ax < 0.85546875) return fgs_do_sin<true, true>(x, 0);
   const double t = FGS_HP0 - ax;
-  return copysign(fgs_do_cos<true>(t, FGS_HP1), x);
+  return copysign(fgs_do_cos<true, false>(t, FGS_HP1), x);
 }
 FG_HD double fgs_cos(double x)
 {
   const double ax = fabs(x);
   if (ax < 0x1p-27) return 1.0;
-  if (ax < 0.85546875) return fgs_do_cos<true>(x, 0);
+  if (ax < 0.85546875) return fgs_do_cos<true, true>(x, 0);
   const double y = FGS_HP0 - ax;
   const double a = y + FGS_HP1;
   const double da = (y - a) + FGS_HP1;
-  return fgs_do_sin<true>(a, da);
+  return fgs_do_sin<true, false>(a, da);
 }
 /* libm sincos() (s_sincos.c): uncontracted; beyond 0.855 both results come from the (a, da) reduction */
 FG_HD void fgs_sincos(double x, double *sinx, double *cosx)
 {
   const double ax = fabs(x);
   if (ax < 0x1p-27) { *sinx = x; *cosx = 1.0; return; }
-  if (ax < 0.85546875) { *sinx = fgs_do_sin<false>(x, 0); *cosx = fgs_do_cos<false>(x, 0); return; }
+  if (ax < 0.85546875) { *sinx = fgs_do_sin<false, true>(x, 0); *cosx = fgs_do_cos<false, true>(x, 0); return; }
   const double y = FGS_HP0 - ax;
   const double a = y + FGS_HP1;
   const double da = (y - a) + FGS_HP1;
-  *sinx = copysign(fgs_do_cos<false>(a, da), x);
-  *cosx = fgs_do_sin<false>(a, da);
+  *sinx = copysign(fgs_do_cos<false, false>(a, da), x);
+  *cosx = fgs_do_sin<false, false>(a, da);
 }
