@@ -132,25 +132,35 @@ FG_HD x80 x80_add(x80 a, x80 b)
 
 FG_HD x80 x80_sub(x80 a, x80 b) { return x80_add(a, x80_neg(b)); }
 
-// a / b, correctly rounded (restoring division on the significands)
+// 128 / 64 -> 64-bit quotient and remainder (u1 < v, v normalised): two 64 / 32 steps (Knuth D, Hacker's Delight divlu)
+FG_HD uint64_t x80_divlu(uint64_t u1, uint64_t u0, uint64_t v, uint64_t *r)
+{
+  const uint64_t b = 4294967296ULL;
+  const uint64_t vn1 = v >> 32, vn0 = v & 0xFFFFFFFFULL, un1 = u0 >> 32, un0 = u0 & 0xFFFFFFFFULL;
+  uint64_t q1 = u1 / vn1, rhat = u1 - q1 * vn1;
+  while (q1 >= b || q1 * vn0 > b * rhat + un1) { q1--; rhat += vn1; if (rhat >= b) break; }
+  const uint64_t un21 = u1 * b + un1 - q1 * v;
+  uint64_t q0 = un21 / vn1;
+  rhat = un21 - q0 * vn1;
+  while (q0 >= b || q0 * vn0 > b * rhat + un0) { q0--; rhat += vn1; if (rhat >= b) break; }
+  *r = un21 * b + un0 - q0 * v;
+  return q1 * b + q0;
+}
+
+// a / b, correctly rounded
 FG_HDN x80 x80_div(x80 a, x80 b)
 {
   int s = a.s ^ b.s;
   if (a.m == 0) return x80_zero(s);
   int e = a.e - b.e;
-  // remainder kept in 65 bits (rh = bit 64, r = low 64)
-  uint64_t r = a.m, q = 0;
-  int rh = 0;
-  if (r < b.m) { e--; rh = (int)(r >> 63); r <<= 1; }          // make the first quotient bit a one
-  for (int i = 0; i < 64; i++) {
-    q <<= 1;
-    if (rh || r >= b.m) { r -= b.m; rh = 0; q |= 1; }
-    rh = (int)(r >> 63); r <<= 1;
-  }
-  // remaining fraction = (rh:r)/ (2*b.m) relative to one ulp of q: compare (rh:r) with b.m
+  uint64_t q, r;
+  if (a.m >= b.m) q = x80_divlu(a.m >> 1, (a.m & 1) << 63, b.m, &r);      // a.m * 2^63 / b.m  in [2^63, 2^64)
+  else { q = x80_divlu(a.m, 0, b.m, &r); e--; }                           // a.m * 2^64 / b.m  in (2^63, 2^64)
+  // remaining fraction r / b.m against one half: compare r with b.m - r (2r may not fit)
+  const uint64_t rem2 = b.m - r;
   uint64_t rest; int sticky;
-  if (rh || r > b.m) { rest = 0x8000000000000001ULL; sticky = 1; }
-  else if (r == b.m) { rest = 0x8000000000000000ULL; sticky = 0; }
+  if (r > rem2) { rest = 0x8000000000000001ULL; sticky = 1; }
+  else if (r == rem2) { rest = 0x8000000000000000ULL; sticky = 0; }
   else { rest = (r != 0); sticky = (r != 0); }
   return x80_round(s, e, q, rest, sticky);
 }
