@@ -53,7 +53,34 @@ def cpu_baseline(fg, lon, lat, lo, la, ni, nlon, nlat, rows):
         r = orc.orc_create_xgrid(2, ni, rows, nlon, nlat, sub_lon, sub_lat, lo, la)
         kind = "port"
     dt = time.time() - t0
-    return {"value": r["n"] / dt, "unit": "exchange-cells/s", "cores": 1, "kind": kind,
+    omp = None
+    omp_path = os.path.join(ROOT, "oracle", "_ref", "libfrenc_ref_omp.so")
+    if os.path.exists(omp_path):
+        # the reference's own OpenMP build of the same sources (gcc -fopenmp, oracle/Makefile), all host cores, same sample
+        import ctypes as C
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count()
+        os.environ.setdefault("OMP_NUM_THREADS", str(ncores))           # read by libgomp when the library is loaded
+        ncores = int(os.environ["OMP_NUM_THREADS"])
+        L = C.CDLL(omp_path)
+        dp, ip, cip = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)
+        L.create_xgrid_2dx2d_order2.argtypes = [cip] * 4 + [dp] * 5 + [ip] * 4 + [dp] * 3
+        L.create_xgrid_2dx2d_order2.restype = C.c_int
+        cap = 5000000
+        ints = [np.empty(cap, dtype=np.int32) for _ in range(4)]
+        dbl = [np.empty(cap) for _ in range(3)]
+        f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64).ravel()
+        arrs = [f64(sub_lon), f64(sub_lat), f64(lo), f64(la), np.ones(ni * rows)]
+        t1 = time.time()
+        n_omp = L.create_xgrid_2dx2d_order2(C.byref(C.c_int(ni)), C.byref(C.c_int(rows)), C.byref(C.c_int(nlon)), C.byref(C.c_int(nlat)),
+                                            *[a.ctypes.data_as(dp) for a in arrs], *[a.ctypes.data_as(ip) for a in ints],
+                                            *[a.ctypes.data_as(dp) for a in dbl])
+        dto = time.time() - t1
+        omp = {"value": n_omp / dto, "unit": "exchange-cells/s", "cores": ncores, "kind": "reference (OpenMP build)",
+               "seconds": dto, "nxgrid": int(n_omp)}
+    return {"value": r["n"] / dt, "unit": "exchange-cells/s", "cores": 1, "kind": kind, "all_cores": omp,
             "sample": f"create_xgrid_2dx2d_order2, C{ni} tile 1 rows {j0}..{j0 + rows - 1} ({rows}x{ni} source cells) "
                       f"x full {nlon}x{nlat} target: {r['n']} exchange cells in {dt:.2f} s",
             "seconds": dt}, r, j0
