@@ -390,6 +390,25 @@ __global__ __launch_bounds__(256) void k_interleave3(FgIl3 a, int nb)
   }
 }
 
+// flattened source / destination cell numbers -> (tile, i, j) and (i, j) for fg_plan_get_xgrid
+__global__ __launch_bounds__(256) void k_xgrid_indices(long nx, const int *x_src, const int *x_dst, const FgTile *tiles, int ntiles,
+                                                        int nx_out, int *t_in, int *i_in, int *j_in, int *i_out, int *j_out)
+{
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nx) return;
+  const int s = x_src[k], d = x_dst[k];
+  int m = 0;
+  while (m + 1 < ntiles && s >= tiles[m + 1].cell_off) m++;
+  const int loc = s - tiles[m].cell_off, nxt = tiles[m].nx;
+  t_in[k] = m; i_in[k] = loc % nxt; j_in[k] = loc / nxt;
+  i_out[k] = d % nx_out; j_out[k] = d / nx_out;
+}
+void fgd_xgrid_indices(long nx, const int *x_src, const int *x_dst, const FgTile *tiles_dev, int ntiles, int nx_out,
+                       int *t_in, int *i_in, int *j_in, int *i_out, int *j_out, hipStream_t st)
+{
+  if (nx > 0) k_xgrid_indices<<<nblk(nx, 256), 256, 0, st>>>(nx, x_src, x_dst, tiles_dev, ntiles, nx_out, t_in, i_in, j_in, i_out, j_out);
+}
+
 // interp.c:262-305 (conserve_interp): weights are xarea / (sum of xarea in the destination cell)
 __global__ __launch_bounds__(256) void k_apply_frac(int ndst, FgCsr csr, const double *data, double *out)
 {

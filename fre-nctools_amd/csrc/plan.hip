@@ -935,27 +935,19 @@ extern "C" int fg_plan_get_xgrid(const fg_plan *pl, int *t_in, int *i_in, int *j
   HIPCHK(hipStreamSynchronize(pl->stream));
   const long nx = pl->nx;
   if (nx == 0) return 0;
-  if (t_in || i_in || j_in) {
-    std::vector<int> s(nx);
-    HIPCHK(hipMemcpy(s.data(), pl->x_src, nx * sizeof(int), hipMemcpyDeviceToHost));
-    int m = 0;
-    for (long k = 0; k < nx; k++) {
-      int sv = s[k];
-      while (m + 1 < pl->ntiles && sv >= pl->cell_off[m + 1]) m++;
-      while (m > 0 && sv < pl->cell_off[m]) m--;
-      int loc = sv - pl->cell_off[m];
-      if (t_in) t_in[k] = m;
-      if (i_in) i_in[k] = loc % pl->nx_in[m];
-      if (j_in) j_in[k] = loc / pl->nx_in[m];
-    }
-  }
-  if (i_out || j_out) {
-    std::vector<int> d(nx);
-    HIPCHK(hipMemcpy(d.data(), pl->x_dst, nx * sizeof(int), hipMemcpyDeviceToHost));
-    for (long k = 0; k < nx; k++) {
-      if (i_out) i_out[k] = d[k] % pl->nx_out;
-      if (j_out) j_out[k] = d[k] / pl->nx_out;
-    }
+  if (t_in || i_in || j_in || i_out || j_out) {
+    // index decomposition on the device, then plain copies (the host loop with two divisions per exchange cell took longer
+    // than the transfer)
+    int *idx = (int *)g_pool.get(pl->device, 5 * (size_t)nx * sizeof(int));
+    if (!idx) return fail(FG_ERR_HIP, "out of device memory");
+    fgd_xgrid_indices(nx, pl->x_src, pl->x_dst, pl->tiles_dev, pl->ntiles, pl->nx_out, idx, idx + nx, idx + 2 * nx, idx + 3 * nx,
+                      idx + 4 * nx, pl->stream);
+    hipError_t e = hipStreamSynchronize(pl->stream);
+    int *dst[5] = {t_in, i_in, j_in, i_out, j_out};
+    for (int q = 0; q < 5 && e == hipSuccess; q++)
+      if (dst[q]) e = hipMemcpy(dst[q], idx + (size_t)q * nx, nx * sizeof(int), hipMemcpyDeviceToHost);
+    g_pool.put(idx);
+    if (e != hipSuccess) return fail(FG_ERR_HIP, "fg_plan_get_xgrid: %s", hipGetErrorString(e));
   }
   if (area) HIPCHK(hipMemcpy(area, pl->x_area, nx * sizeof(double), hipMemcpyDeviceToHost));
   if (pl->order == 2) {

@@ -111,6 +111,8 @@ void fgd_interleave3(int nb_pad, int narr, const double *const *in, const long *
 void fgd_deinterleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st);
 void fgd_apply_frac(int ndst, FgCsr csr, const double *data, double *out, hipStream_t st);
 void fgd_reduce_sum(const double *v, long n, double *partial, double *result, hipStream_t st);
+void fgd_xgrid_indices(long nx, const int *x_src, const int *x_dst, const FgTile *tiles_dev, int ntiles, int nx_out,
+                       int *t_in, int *i_in, int *j_in, int *i_out, int *j_out, hipStream_t st);
 
 // ---- the sweep with every do_scalar_conserve_interp option (conserve_interp.c:507-910), one level per launch
 struct FgApplyEx {
