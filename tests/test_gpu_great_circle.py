@@ -139,3 +139,33 @@ def test_conserve_interp_great_circle_b1(fg, gpu_ok):
         ref[d[k]] += data[o["j_in"][k] * ni + o["i_in"][k]] * (o["area"][k] / dst_area[d[k]])
     assert np.max(np.abs(got - ref)) < 1e-12 * np.max(np.abs(ref))
     assert np.count_nonzero(got) == np.count_nonzero(ref) > 0
+
+
+def test_great_circle_degenerate_cases(fg, gpu_ok):
+    """Edge cases against the oracle: identical grids (every edge pair coincident: u snapped to 0/1 everywhere), disjoint
+    regional grids (no exchange cells), single cells, and a masked-out source."""
+    lo, la = fg.latlon_corners(24, 12)
+    o = orc.orc_create_xgrid_gc(24, 12, 24, 12, lo, la, lo, la)
+    r = fg.create_xgrid_great_circle(24, 12, 24, 12, lo, la, lo, la)
+    assert r[0] == o["n"] and np.array_equal(r[1], o["i_in"]) and np.array_equal(r[3], o["i_out"]) and np.array_equal(r[4], o["j_out"])
+    assert np.max(np.abs(r[5] - o["area"]) / o["area"]) < RTOL
+    assert r[0] >= 24 * 12                              # every cell at least meets itself
+    lon, lat = fg.gnomonic_ed_corners(8)
+    o = orc.orc_create_xgrid_gc(8, 8, 8, 8, lon[3], lat[3], lon[3], lat[3])
+    r = fg.create_xgrid_great_circle(8, 8, 8, 8, lon[3], lat[3], lon[3], lat[3])
+    assert r[0] == o["n"] and np.array_equal(r[3], o["i_out"]) and np.array_equal(r[4], o["j_out"])
+    assert np.max(np.abs(r[5] - o["area"]) / o["area"]) < RTOL
+    # disjoint regions
+    lo1, la1 = fg.latlon_corners(6, 6, 10.0, 40.0, 10.0, 40.0)
+    lo2, la2 = fg.latlon_corners(5, 5, 100.0, 140.0, -40.0, -10.0)
+    assert orc.orc_create_xgrid_gc(6, 6, 5, 5, lo1, la1, lo2, la2)["n"] == 0
+    assert fg.create_xgrid_great_circle(6, 6, 5, 5, lo1, la1, lo2, la2)[0] == 0
+    # single cells, partial overlap
+    lo3, la3 = fg.latlon_corners(1, 1, 10.0, 20.0, 10.0, 20.0)
+    lo4, la4 = fg.latlon_corners(1, 1, 15.0, 30.0, 5.0, 15.0)
+    o = orc.orc_create_xgrid_gc(1, 1, 1, 1, lo3, la3, lo4, la4)
+    r = fg.create_xgrid_great_circle(1, 1, 1, 1, lo3, la3, lo4, la4)
+    assert r[0] == o["n"] == 1 and abs(r[5][0] - o["area"][0]) < RTOL * o["area"][0]
+    # fully masked source
+    r = fg.create_xgrid_great_circle(6, 6, 6, 6, lo1, la1, lo1, la1, mask_in=np.zeros(36))
+    assert r[0] == 0
