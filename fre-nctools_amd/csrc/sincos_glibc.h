@@ -28,10 +28,11 @@
 #define FGS_HP0 1.5707963267948966           /* pi/2 high */
 #define FGS_HP1 6.123233995736766e-17        /* pi/2 low  */
 
-FG_HD int fgs_index(double u)               /* low word of big + |x| */
+FG_HD int fgs_index(double u)               /* low word of big + |x|: the table node, 0..110 for every supported argument */
 {
   union { double d; uint64_t b; } c; c.d = u;
-  return (int)(uint32_t)c.b;
+  const uint32_t k = (uint32_t)c.b;
+  return (int)(k > 111u ? 111u : k);        /* out-of-range or NaN input (rejected elsewhere) must not index past the table */
 }
 
 #define FGS_SN3 (-1.66666666666664880952546298448555E-01)
