@@ -361,6 +361,22 @@ def test_fast_search_overflow_falls_back_to_exact_mode(fg, gpu_ok):
     assert st2["exact_mode"] == 1 and n1 == n2 and st1["pairs"] == st2["pairs"]
 
 
+def test_bad_inputs_are_reported_not_crashed(fg, gpu_ok):
+    """Corner arrays in degrees (a common caller mistake) or with NaNs: the plan call returns FG_ERR_ARG with a message; the
+    kernels that already ran on the garbage stay inside their tables."""
+    lon, lat = fg.gnomonic_ed_corners(8)
+    lo, la = fg.latlon_corners(24, 12)
+    grids = [fg.GridConfig(8, 8, np.degrees(lon[0]), np.degrees(lat[0]))]
+    with pytest.raises(fg.FregridHipError, match="radians expected"):
+        fg.XgridPlan.create(2, grids, fg.GridConfig(24, 12, lo, la))
+    bad = la.copy(); bad[3, 5] = np.nan
+    with pytest.raises(fg.FregridHipError, match="radians expected"):
+        fg.XgridPlan.create(1, [fg.GridConfig(8, 8, lon[0], lat[0])], fg.GridConfig(24, 12, lo, bad))
+    # and the library is still healthy afterwards
+    n, _ = _plan_vs_oracle(fg, 1, [(8, 8, lon[0], lat[0])], (24, 12, lo, la))
+    assert n > 0
+
+
 def test_degenerate_sizes_and_empty_overlap(fg, gpu_ok):
     lo1, la1 = fg.latlon_corners(1, 1, 10.0, 20.0, 10.0, 20.0)
     lo2, la2 = fg.latlon_corners(1, 1, 15.0, 30.0, 5.0, 15.0)
