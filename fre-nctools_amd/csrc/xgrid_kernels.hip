@@ -14,13 +14,14 @@
 //                      clip (create_xgrid.c:1266-1341) with the polygon staged in LDS
 //                      [vertex][lane], then area / centroid integrals and the 1e-6 area test
 //   k_clip_general     same for pairs with pole-fixed cells (5..8 vertices) or fast-path overflow
-//   k_count_accepted / k_scatter_xcells
-//                      compaction into the reference's canonical order (source cell ascending,
-//                      destination cell index ascending) via per-source-cell rank
+//   (accepted pairs are counted per source cell inside the clip kernels: wave-segmented ballot, one atomic per run)
+//   k_scatter_xcells   compaction into the reference's canonical order (source cell ascending,
+//                      destination cell index ascending) via per-source-cell rank; counts the CSR row sizes
 //   k_cell_sums, k_centroids, k_distances     order-2 centroid pass (conserve_interp.c:216-221,319-358)
 //
-// No MFMA: this is FP64 VALU + irregular gather work.  All decisions that define the
-// exchange-cell set use the reference's expression trees (see geom.hip.h).
+// No MFMA: this is FP64 VALU + irregular gather work.  Every floating-point operation uses the reference's expression
+// trees, sin/cos included (geom.hip.h, sincos_glibc.h): lists, areas and centroid integrals are the reference's bits.
+// Launched either for exact sizes or for fixed capacities with the true counts read from device memory (np_dev, cap).
 #include "xgrid_device.h"
 #include "geom.hip.h"
 
