@@ -24,6 +24,11 @@
 #endif
 #endif
 
+/* table access: a translation unit may redirect it (e.g. to a copy in LDS) by defining FGS_TAB before including this header */
+#ifndef FGS_TAB
+#define FGS_TAB(k, j) FG_SINCOS_TAB[k][j]
+#endif
+
 #define FGS_BIG 0x1.8p45                     /* ulp = 1/128: big + |x| rounds |x| to a table node */
 #define FGS_HP0 1.5707963267948966           /* pi/2 high */
 #define FGS_HP1 6.123233995736766e-17        /* pi/2 low  */
@@ -75,7 +80,7 @@ FG_HD double fgs_do_sin(double x, double dx)
   x = fabs(x) - (u - FGS_BIG);
   const double xx = x * x;
   const int k = fgs_index(u);
-  const double sn = FG_SINCOS_TAB[k][0], ssn = FG_SINCOS_TAB[k][1], cs = FG_SINCOS_TAB[k][2], ccs = FG_SINCOS_TAB[k][3];
+  const double sn = FGS_TAB(k, 0), ssn = FGS_TAB(k, 1), cs = FGS_TAB(k, 2), ccs = FGS_TAB(k, 3);
   double s, c, cor;
   if (FMA) {
     const double P = fma(xx, FGS_SN5, FGS_SN3), Q = fma(xx, fma(xx, FGS_CS6, FGS_CS4), FGS_CS2);
@@ -99,7 +104,7 @@ FG_HD double fgs_do_cos(double x, double dx)
   x = ZDX ? fabs(x) - (u - FGS_BIG) : fabs(x) - (u - FGS_BIG) + dx;
   const double xx = x * x;
   const int k = fgs_index(u);
-  const double sn = FG_SINCOS_TAB[k][0], ssn = FG_SINCOS_TAB[k][1], cs = FG_SINCOS_TAB[k][2], ccs = FG_SINCOS_TAB[k][3];
+  const double sn = FGS_TAB(k, 0), ssn = FGS_TAB(k, 1), cs = FGS_TAB(k, 2), ccs = FGS_TAB(k, 3);
   double s, c, cor;
   if (FMA) {
     s = fma(x * xx, fma(xx, FGS_SN5, FGS_SN3), x);
