@@ -713,11 +713,32 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
 __global__ __launch_bounds__(256) void k_cell_sums(int nsrc, const int *xoff, const double *x_area,
                                                     const double *x_c1, const double *x_c2, double *sums)
 {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  // The xcells of a block's 256 consecutive source cells are one contiguous
+  // range: stage it through LDS with coalesced loads, then each thread adds
+  // its own cell's entries in canonical order (same order, same sums, as the
+  // direct loop kept below for ranges that do not fit).
+  constexpr int CAP = 2048;
+  __shared__ double sh[3][CAP];
+  int b0 = blockIdx.x * blockDim.x;
+  int b1 = min(b0 + (int)blockDim.x, nsrc);
+  int e0 = xoff[b0], n = xoff[b1] - e0;
+  int s = b0 + threadIdx.x;
+  bool staged = n <= CAP;
+  if (staged) {
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+      sh[0][k] = x_area[e0 + k]; sh[1][k] = x_c1[e0 + k]; sh[2][k] = x_c2[e0 + k];
+    }
+    __syncthreads();
+  }
   if (s >= nsrc) return;
   double a = 0, l = 0, t = 0;
   int o = xoff[s], c = xoff[s + 1] - o;
-  for (int k = 0; k < c; k++) { a += x_area[o + k]; l += x_c1[o + k]; t += x_c2[o + k]; }
+  if (staged) {
+    int q = o - e0;
+    for (int k = 0; k < c; k++) { a += sh[0][q + k]; l += sh[1][q + k]; t += sh[2][q + k]; }
+  } else {
+    for (int k = 0; k < c; k++) { a += x_area[o + k]; l += x_c1[o + k]; t += x_c2[o + k]; }
+  }
   sums[s] = a; sums[nsrc + s] = l; sums[2 * (size_t)nsrc + s] = t;
 }
 
