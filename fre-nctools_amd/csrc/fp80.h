@@ -132,19 +132,36 @@ FG_HD x80 x80_add(x80 a, x80 b)
 
 FG_HD x80 x80_sub(x80 a, x80 b) { return x80_add(a, x80_neg(b)); }
 
-// 128 / 64 -> 64-bit quotient and remainder (u1 < v, v normalised): two 64 / 32 steps (Knuth D, Hacker's Delight divlu)
+// signed 128-bit -> double without a runtime-library call (magnitudes here are < 2^80; the low word's rounding is
+// irrelevant to the estimates it feeds)
+FG_HD double x80_i128_to_double(__int128 v)
+{
+  const int64_t h = (int64_t)(v >> 64);
+  const uint64_t l = (uint64_t)v;
+  return (double)h * 18446744073709551616.0 + (double)l;
+}
+
+// 128 / 64 -> 64-bit quotient and remainder (u1 < v, v normalised).  A double-precision estimate of the quotient
+// (good to ~2^-52 relative) is corrected twice with the exact 128-bit remainder: once by a double estimate of the
+// remaining quotient (|.| < 2^13), then by +-1 steps until 0 <= rem < v.  Integer-exact; ~5x fewer instructions on
+// gfx950 than two emulated 64/32 divisions.
 FG_HD uint64_t x80_divlu(uint64_t u1, uint64_t u0, uint64_t v, uint64_t *r)
 {
-  const uint64_t b = 4294967296ULL;
-  const uint64_t vn1 = v >> 32, vn0 = v & 0xFFFFFFFFULL, un1 = u0 >> 32, un0 = u0 & 0xFFFFFFFFULL;
-  uint64_t q1 = u1 / vn1, rhat = u1 - q1 * vn1;
-  while (q1 >= b || q1 * vn0 > b * rhat + un1) { q1--; rhat += vn1; if (rhat >= b) break; }
-  const uint64_t un21 = u1 * b + un1 - q1 * v;
-  uint64_t q0 = un21 / vn1;
-  rhat = un21 - q0 * vn1;
-  while (q0 >= b || q0 * vn0 > b * rhat + un0) { q0--; rhat += vn1; if (rhat >= b) break; }
-  *r = un21 * b + un0 - q0 * v;
-  return q1 * b + q0;
+  typedef unsigned __int128 u128;
+  typedef __int128 i128;
+  const u128 N = ((u128)u1 << 64) | u0;
+  const double vd = (double)v;
+  const double qd = ((double)u1 * 18446744073709551616.0 + (double)u0) / vd;
+  uint64_t q = (qd >= 18446744073709549568.0) ? 0xFFFFFFFFFFFFF800ULL : (uint64_t)qd;
+  i128 rem = (i128)(N - (u128)q * v);                        // |rem| < 2^13 * v (wrapping subtraction, small result)
+  const double cd = x80_i128_to_double(rem) / vd;
+  const int64_t c = (int64_t)cd;                             // truncation: the +-1 steps below finish the job
+  q += (uint64_t)c;
+  rem -= (i128)c * (i128)v;
+  while (rem < 0) { q--; rem += v; }
+  while (rem >= (i128)v) { q++; rem -= v; }
+  *r = (uint64_t)rem;
+  return q;
 }
 
 // a / b, correctly rounded
@@ -174,19 +191,21 @@ FG_HDN x80 x80_sqrt(x80 a)
   uint64_t hi, lo;
   if (ex & 1) { hi = a.m; lo = 0; ex -= 1; }             // rad = m * 2^64 * ... (odd exponent: one more factor of two)
   else { hi = a.m >> 1; lo = a.m << 63; }
-  // root of (hi:lo) as a 128-bit integer in [2^126, 2^128): 64-bit result
-  uint64_t root = 0, remh = 0, reml = 0;                  // classic digit-by-digit, two radicand bits per step
-  for (int i = 0; i < 64; i++) {
-    // rem = rem*4 + next two bits
-    uint64_t top2 = hi >> 62;
-    hi = (hi << 2) | (lo >> 62); lo <<= 2;
-    remh = (remh << 2) | (reml >> 62); reml = (reml << 2) | top2;
-    // trial = 4*root + 1  (as 128-bit: root < 2^64, so trial fits in 66 bits)
-    uint64_t th = root >> 62, tl = (root << 2) | 1;
-    root <<= 1;
-    bool ge = (remh > th) || (remh == th && reml >= tl);
-    if (ge) { uint64_t br = reml < tl; reml -= tl; remh = remh - th - br; root |= 1; }
-  }
+  // root of (hi:lo) as a 128-bit integer in [2^126, 2^128): 64-bit result.  Double-precision estimate (53 good
+  // bits), one Newton correction from the exact 128-bit remainder, then +-1 steps until root^2 <= rad < (root+1)^2.
+  typedef unsigned __int128 u128;
+  typedef __int128 i128;
+  const u128 rad = ((u128)hi << 64) | lo;
+  const double rd = sqrt((double)hi * 18446744073709551616.0 + (double)lo);
+  uint64_t root = (rd >= 18446744073709549568.0) ? 0xFFFFFFFFFFFFF800ULL : (uint64_t)rd;
+  i128 rem = (i128)(rad - (u128)root * root);                // |rem| < 2^13 * 2 * root (wrapping subtraction, small result)
+  const int64_t c = (int64_t)(x80_i128_to_double(rem) / (2.0 * (double)root));
+  // (root + c)^2 = root^2 + 2 root c + c^2
+  rem -= (i128)c * (i128)(2 * (u128)root) + (i128)c * (i128)c;
+  root += (uint64_t)c;
+  while (rem < 0) { root--; rem += (i128)(2 * (u128)root + 1); }
+  while (rem > (i128)(2 * (u128)root)) { rem -= (i128)(2 * (u128)root + 1); root++; }
+  const uint64_t remh = (uint64_t)((u128)rem >> 64), reml = (uint64_t)rem;
   // value = root * 2^((ex - 63 - 63)/2 ...): rad = m*2^(63 or 64) = root^2 + rem; sqrt(value) = root * 2^(ex/2 - 63)
   // remainder vs root decides rounding: exact if rem == 0; above half iff rem > root
   uint64_t rest; int sticky;

@@ -70,3 +70,44 @@ extern "C" long fp80_check_acosl(long n, long *ulp1)
   }
   return bad;
 }
+// crafted significands for the estimate-and-correct divide and square root: extreme, exact and just-off-exact cases
+static long double to_ld(x80 a)
+{
+  long double v = 0; uint16_t se = (uint16_t)((a.e + 16383) | (a.s << 15));
+  if (a.m == 0) se = (uint16_t)(a.s << 15);
+  memcpy(&v, &a.m, 8); memcpy((char *)&v + 8, &se, 2);
+  return v;
+}
+extern "C" long fp80_check_edges(long n, long *fails)
+{
+  srand48(4242);
+  long bad = 0; fails[0] = fails[1] = 0;
+  const uint64_t special[] = {0x8000000000000000ULL, 0x8000000000000001ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFEULL,
+                              0xFFFFFFFF00000000ULL, 0x80000000FFFFFFFFULL, 0xC000000000000000ULL, 0xB504F333F9DE6484ULL,
+                              0xB504F333F9DE6485ULL, 0xAAAAAAAAAAAAAAABULL, 0xFFFFFFFFFFFFF800ULL, 0xFFFFFFFFFFFFFC00ULL};
+  const int nsp = sizeof(special) / sizeof(special[0]);
+  for (long i = 0; i < n; i++) {
+    x80 a, b;
+    a.s = 0; b.s = (int)(i & 1);
+    a.e = (int)(lrand48() % 41) - 20; b.e = (int)(lrand48() % 41) - 20;
+    uint64_t ra = ((uint64_t)lrand48() << 33) ^ ((uint64_t)lrand48() << 11) ^ (uint64_t)lrand48();
+    uint64_t rb = ((uint64_t)lrand48() << 33) ^ ((uint64_t)lrand48() << 11) ^ (uint64_t)lrand48();
+    a.m = ra | 0x8000000000000000ULL; b.m = rb | 0x8000000000000000ULL;
+    switch (i % 8) {
+      case 0: a.m = special[(i / 8) % nsp]; break;
+      case 1: b.m = special[(i / 8) % nsp]; break;
+      case 2: a.m = special[(i / 8) % nsp]; b.m = special[(i / 96) % nsp]; break;
+      case 3: { uint64_t r = (rb >> 32) | 0x80000000ULL; a.m = r * r; if (!(a.m >> 63)) a.m <<= 1; } break;       // squares
+      case 4: { uint64_t r = (rb >> 32) | 0x80000000ULL; a.m = r * r + ((i & 8) ? 1 : -1); if (!(a.m >> 63)) a.m <<= 1; } break;
+      case 5: { uint64_t q = (ra >> 32) | 0x80000000ULL, d = (rb >> 32) | 0x80000000ULL; a.m = q * d; b.m = d << 32; if (!(a.m >> 63)) a.m <<= 1; } break; // exact quotients
+      case 6: a.m = b.m; break;
+      default: break;
+    }
+    volatile long double A = to_ld(a), B = to_ld(b);
+    { volatile long double Q = A / B; if (!same(x80_div(a, b), Q)) { fails[0]++; bad++; } }
+    { volatile long double R = sqrtl(A); if (!same(x80_sqrt(a), R)) { fails[1]++; bad++; } }
+    a.e += 1;
+    { volatile long double A2 = to_ld(a); volatile long double R = sqrtl(A2); if (!same(x80_sqrt(a), R)) { fails[1]++; bad++; } }
+  }
+  return bad;
+}

@@ -23,7 +23,17 @@ def chk():
     L.fp80_check_ops.restype = C.c_long
     L.fp80_check_acosl.argtypes = [C.c_long, C.POINTER(C.c_long)]
     L.fp80_check_acosl.restype = C.c_long
+    L.fp80_check_edges.argtypes = [C.c_long, C.POINTER(C.c_long)]
+    L.fp80_check_edges.restype = C.c_long
     return L
+
+
+def test_divide_and_sqrt_on_crafted_significands(chk):
+    """extreme / exact / just-off-exact significands, both exponent parities, for the estimate-and-correct
+    x80_div and x80_sqrt"""
+    fails = (C.c_long * 2)()
+    bad = chk.fp80_check_edges(2000000, fails)
+    assert bad == 0, list(fails)      # [div, sqrt]
 
 
 @pytest.mark.parametrize("spread", [4, 40, 600])
