@@ -270,8 +270,8 @@ def main():
                 "achieved": (alg_search / 1e9) / (clip_ms / 1e3) if clip_ms > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "algorithmic_bytes_per_launch": alg_search, "kernel_ms": clip_ms,
-                "note": "FP64-VALU bound polygon clipping, not HBM bound (SURVEY.md §8d): 2.06e8 wave VALU instructions x 4 issue "
-                        "cycles = 71 % of the SIMD cycles of the launch (profiles/r01_summary.md); "
+                "note": "FP64-VALU bound polygon clipping, not HBM bound (SURVEY.md §8d): 2.03e8 wave VALU instructions x 4 issue "
+                        "cycles = 77 % of the SIMD cycles of the launch (profiles/r01_summary.md); "
                         "the HBM-bound kernel of the path is the sweep, see roofline_apply"}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
         # sweep: weights streamed once per launch of nz levels + per level the source fields and the output

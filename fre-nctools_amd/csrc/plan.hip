@@ -109,7 +109,8 @@ enum { PH_CELL_STRUCT = 0, PH_BINS, PH_CANDIDATES, PH_CLIP_QUAD, PH_CLIP_GENERAL
 struct HandleCache {
   std::mutex mu;
   std::map<int, std::vector<hipStream_t>> streams;
-  std::vector<hipEvent_t> events;
+  std::map<int, std::vector<hipEvent_t>> events;        // per device, like the streams: an event belongs to its device
+  static int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
   hipStream_t get_stream(int dev)
   {
     {
@@ -131,7 +132,8 @@ struct HandleCache {
   {
     {
       std::lock_guard<std::mutex> lk(mu);
-      if (!events.empty()) { hipEvent_t e = events.back(); events.pop_back(); return e; }
+      auto &v = events[current_device()];
+      if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
     }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
@@ -141,7 +143,7 @@ struct HandleCache {
   {
     if (!e) return;
     std::lock_guard<std::mutex> lk(mu);
-    events.push_back(e);
+    events[current_device()].push_back(e);
   }
 };
 static HandleCache g_handles;
