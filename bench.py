@@ -287,6 +287,10 @@ def main():
                 tr = json.load(open(pmc))
                 roof["traffic"] = tr.get("k_clip_quad")
                 roof_a["traffic"] = tr.get("k_apply")
+                # the clip kernel's own bound: wave VALU instructions (PMC) x 4 issue cycles on SIMD16, over the SIMD
+                # cycles of the live launch duration (1024 SIMDs at 2.4 GHz)
+                if tr.get("k_clip_quad_valu_insts") and clip_ms > 0:
+                    roof["valu_issue_frac"] = 4.0 * tr["k_clip_quad_valu_insts"] / (clip_ms * 1e-3 * 2.4e9 * 1024)
             except Exception:
                 pass
         # mass conservation (conserve_interp.c:874-907): input flux uses get_grid_area cell areas

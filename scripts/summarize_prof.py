@@ -71,6 +71,8 @@ traffic = {}
 for key, kname in (("k_clip_quad", "k_clip_quad<2>"), ("k_apply", "k_apply_il<2, 8, 2>")):
     if kname in m and "FETCH_SIZE" in m[kname] and "WRITE_SIZE" in m[kname]:
         traffic[key] = (2 * m[kname]["FETCH_SIZE"] + m[kname]["WRITE_SIZE"]) * 1024.0
+if "k_clip_quad<2>" in m and "SQ_INSTS_VALU" in m["k_clip_quad<2>"]:
+    traffic["k_clip_quad_valu_insts"] = m["k_clip_quad<2>"]["SQ_INSTS_VALU"]      # wave instructions per launch
 if mg.get("k_gc_clip"):
     traffic["k_gc_clip"] = (2 * mg["k_gc_clip"].get("FETCH_SIZE", 0) + mg["k_gc_clip"].get("WRITE_SIZE", 0)) * 1024.0
 traffic["_note"] = ("HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, KB->bytes), C384->1440x720, "
