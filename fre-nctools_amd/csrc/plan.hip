@@ -210,7 +210,8 @@ struct fg_plan {
   int *src_idx_f = nullptr;
   double *row_sum = nullptr, *red_partial = nullptr, *red_result = nullptr;
   long row_sum_cap = 0;
-  double *il_f = nullptr, *il_gx = nullptr, *il_gy = nullptr, *il_out = nullptr, *il_rs = nullptr;   // [cell][8] scratch
+  double *il_f = nullptr, *il_out = nullptr, *il_rs = nullptr;   // [cell][8] scratch (order 1 field, output, row sums)
+  double *il_m = nullptr;                                        // order 2: merged records [source cell][3][8] (k_merge3)
   long stats[FG_NSTATS] = {0};
   // monotone limiter scratch (fg_plan_mono_*): limited values per CSR entry, per-source-cell bounds, error word
   double *mono_x = nullptr, *mono_b = nullptr;     // mono_b: [4][nsrc] = f_bar_max | f_bar_min | f_max | f_min
@@ -1044,11 +1045,11 @@ extern "C" void fg_set_apply_vec(int v) { g_apply_vec = (v >= 4) ? 4 : (v >= 2 ?
 
 static int ensure_il_scratch(fg_plan *pl, bool want_rs)
 {
-  if (!pl->il_f) {
-    pl->il_f = pl->alloc<double>((size_t)pl->f_stride * 8);
+  if (!pl->il_out) {
     pl->il_out = pl->alloc<double>((size_t)pl->ndst * 8);
-    if (pl->order == 2) { pl->il_gx = pl->alloc<double>((size_t)pl->nsrc * 8); pl->il_gy = pl->alloc<double>((size_t)pl->nsrc * 8); }
-    if (!pl->il_f || !pl->il_out || (pl->order == 2 && (!pl->il_gx || !pl->il_gy))) return fail(FG_ERR_HIP, "out of device memory");
+    if (pl->order == 2) pl->il_m = pl->alloc<double>((size_t)pl->nsrc * 24);
+    else pl->il_f = pl->alloc<double>((size_t)pl->f_stride * 8);
+    if (!pl->il_out || (pl->order == 2 ? !pl->il_m : !pl->il_f)) return fail(FG_ERR_HIP, "out of device memory");
   }
   if (want_rs && !pl->il_rs) {
     pl->il_rs = pl->alloc<double>((size_t)pl->ndst * 16);
@@ -1094,14 +1095,18 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
       if (gsum_out) fgd_reduce_sum(pl->row_sum, ndst, pl->red_partial, pl->red_result + nred++, st);
     } else {
       const int nbp = nbv > 4 ? 8 : (nbv > 2 ? 4 : 2);
-      {
-        const double *ins[3] = {f, gx, gy};
-        double *outs[3] = {pl->il_f, pl->il_gx, pl->il_gy};
-        const long lds[3] = {pl->f_stride, pl->nsrc, pl->nsrc}, ns[3] = {pl->f_stride, pl->nsrc, pl->nsrc};
-        fgd_interleave3(nbp, pl->order == 2 ? 3 : 1, ins, lds, ns, outs, nbv, st);
+      double *rs = gsum_out ? pl->il_rs : nullptr;
+      if (pl->order == 2) {
+        // field + gradients of the chunk -> one record per source cell, then the sweep writes level-major directly
+        fgd_merge3(nbp, pl->nsrc, pl->src_idx_f, f, pl->f_stride, gx, gy, pl->nsrc, nbv, pl->il_m, st);
+        fgd_apply_il_merged(nbp, ndst, pl->csr, pl->il_m, miss, o, rs, (long)ndst, nbv, st);
+      } else {
+        const double *ins[3] = {f, nullptr, nullptr};
+        double *outs[3] = {pl->il_f, nullptr, nullptr};
+        const long lds[3] = {pl->f_stride, 0, 0}, ns[3] = {pl->f_stride, 0, 0};
+        fgd_interleave3(nbp, 1, ins, lds, ns, outs, nbv, st);
+        fgd_apply_il(1, nbp, ndst, pl->csr, pl->il_f, nullptr, nullptr, miss, o, rs, (long)ndst, nbv, st);
       }
-      fgd_apply_il(pl->order, nbp, ndst, pl->csr, pl->il_f, pl->il_gx, pl->il_gy, miss, o,
-                   gsum_out ? pl->il_rs : nullptr, (long)ndst, nbv, st);            // writes level-major directly
       if (gsum_out) fgd_reduce_sum(pl->il_rs, (long)ndst * nbp, pl->red_partial, pl->red_result + nred++, st);
     }
   }
