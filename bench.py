@@ -238,6 +238,33 @@ def main():
     torch.cuda.synchronize(); barrier()
     dtb = time.perf_counter() - tb
     apply_kernel_ms = p.phase_ms()["apply"]
+    # ---- per-chunk pipeline of an order-2 variable: halo update + grad_c2l + sweep of nz levels, (a) through the reference's
+    # level-major gradient arrays, (b) fused: gradients written straight into the sweep's records (fg_c2l_gradient_records +
+    # fg_plan_apply_records) -- bit-identical outputs (tests/test_gpu_c2l.py)
+    dtl = dtf = 0.0
+    if nz <= 8:
+        rec_t = torch.empty(ncell_in, 3, fg.C2lPrep.records_nb(nz), dtype=torch.float64, device=dev)
+
+        def pipe_level_major():
+            prepare()
+            p.apply(data_t, out_t, nz=nz, grad_x_t=gx_t, grad_y_t=gy_t)
+
+        def pipe_fused():
+            prep.fill_halo(src_t, data_t, nz)
+            prep.gradient_records(data_t, nz, rec_t)
+            p.apply_records(nz, rec_t, out_t)
+
+        times = []
+        for fn in (pipe_level_major, pipe_fused):
+            for _ in range(3):
+                fn()
+            barrier(); torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(apply_steps):
+                fn()
+            torch.cuda.synchronize(); barrier()
+            times.append((time.perf_counter() - tq) / apply_steps)
+        dtl, dtf = times
     gsum_out = p.apply(data_t, out_t, nz=1, grad_x_t=gx_t, grad_y_t=gy_t, want_gsum=True)
     # the same flux from this rank's exchange cells on the host: sum_x (f + gx*di + gy*dj)[src(x)] * area(x) -- what the
     # sweep must reproduce to rounding (conservation of the remap itself, independent of the geometric closure of the grids)
@@ -247,12 +274,12 @@ def main():
     gsum_xgrid = float(np.sum(f0 * xg["area"]))
 
     # ---- reductions over ranks
-    red = torch.tensor([dt, dta, dtb], dtype=torch.float64, device=dev)
+    red = torch.tensor([dt, dta, dtb, dtl, dtf], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(nx_local), float(gsum_out), gsum_xgrid], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt, dta, dtb = float(red[0]), float(red[1]), float(red[2])
+    dt, dta, dtb, dtl, dtf = (float(red[k]) for k in range(5))
     nx_total, gsum_out, gsum_xgrid = int(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if rank == 0:
@@ -316,6 +343,11 @@ def main():
             "mass_rel_err_xgrid": abs(gsum_out - gsum_xgrid) / abs(gsum_xgrid),
             "prep_ms_per_call": dtp * 1e3, "prep_cells_per_s": ncell_in * nz / dtp,
             "prep_note": "halo update + grad_c2l for nz levels of all 6 tiles (device), feeds the order-2 sweep",
+            "pipeline": None if dtf <= 0 else {
+                "levels": nz, "level_major_ms_per_call": dtl * 1e3, "fused_ms_per_call": dtf * 1e3,
+                "fused_remapped_points_per_s": ndst * nz / dtf,
+                "note": "halo update + grad_c2l + order-2 sweep of one chunk of levels; fused = gradients written straight into "
+                        "the sweep's [cell][field,grad_x,grad_y][level] records (no level-major gradient arrays, no merge pass)"},
             "phase_ms": phases, "search_stats": stats,
             "roofline": roof, "roofline_apply": roof_a,
         }

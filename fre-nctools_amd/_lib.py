@@ -29,7 +29,7 @@ EXPORTS = [
     "fg_last_error", "fg_device_count", "fg_plan_create", "fg_plan_create_dev", "fg_plan_create_empty",
     "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
     "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
-    "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_apply_ex", "fg_plan_mono_begin",
+    "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_apply_records", "fg_plan_apply_ex", "fg_plan_mono_begin",
     "fg_plan_mono_minmax_dev", "fg_plan_mono_copy_minmax", "fg_plan_mono_end",
     "fg_plan_create_great_circle", "fg_plan_create_great_circle_dev", "fg_latlon2xyz", "create_xgrid_great_circle",
     "create_xgrid_great_circle_", "get_grid_great_circle_area", "get_grid_great_circle_area_", "clip_2dx2d_great_circle",
@@ -38,7 +38,7 @@ EXPORTS = [
     "create_xgrid_1dx2d_order1_", "create_xgrid_1dx2d_order2_", "create_xgrid_2dx1d_order1_", "create_xgrid_2dx1d_order2_",
     "clip", "box_ctrlat", "box_ctrlon", "get_grid_area_no_adjust", "get_grid_area_no_adjust_", "fg_plan_stream", "fg_plan_sync",
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
-    "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
+    "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_gradient_records", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
     "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
     "fg_plan_stats", "fg_set_search_mode", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
@@ -136,6 +136,8 @@ def lib():
     L.fg_plan_apply.restype = C.c_int
     L.fg_plan_apply_interleaved.argtypes = [vp, C.c_int, vp, vp, vp, vp, dp]
     L.fg_plan_apply_interleaved.restype = C.c_int
+    L.fg_plan_apply_records.argtypes = [vp, C.c_int, vp, vp, dp]
+    L.fg_plan_apply_records.restype = C.c_int
     ao = C.POINTER(ApplyOpts)
     L.fg_plan_apply_ex.argtypes = [vp, ao, vp, vp, vp, vp, C.c_int, vp, dp]
     L.fg_plan_apply_ex.restype = C.c_int
@@ -215,6 +217,8 @@ def lib():
     L.fg_c2l_fill_halo.restype = C.c_int
     L.fg_c2l_gradient.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp]
     L.fg_c2l_gradient.restype = C.c_int
+    L.fg_c2l_gradient_records.argtypes = [vp, vp, C.c_int, vp]
+    L.fg_c2l_gradient_records.restype = C.c_int
     L.fg_c2l_grid_info.argtypes = [C.c_int, C.c_int] + [dp] * 15
     L.fg_c2l_grid_info.restype = C.c_int
     L.fg_find_contacts.argtypes = [C.c_int, ip, ip, dpp, dpp, C.c_int] + [ip] * 10

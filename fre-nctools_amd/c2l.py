@@ -113,3 +113,13 @@ class C2lPrep:
         check(lib().fg_c2l_gradient(self._h, C.c_void_p(halo_t.data_ptr()), nz, 1 if has_missing else 0, float(missing),
                                     C.c_void_p(grad_x_t.data_ptr()), C.c_void_p(grad_y_t.data_ptr()),
                                     C.c_void_p(grad_mask_t.data_ptr() if grad_mask_t is not None else 0)))
+
+    @staticmethod
+    def records_nb(nz):
+        """levels per record for nz <= 8 levels: 2, 4 or 8"""
+        return 8 if nz > 4 else (4 if nz > 2 else 2)
+
+    def gradient_records(self, halo_t, nz, rec_t):
+        """halo'd levels [nz, F] -> rec [ncells, 3, records_nb(nz)] = {field, grad_x, grad_y} per level: the layout
+        XgridPlan.apply_records sweeps, with no level-major gradient arrays in between."""
+        check(lib().fg_c2l_gradient_records(self._h, C.c_void_p(halo_t.data_ptr()), nz, C.c_void_p(rec_t.data_ptr())))

@@ -348,6 +348,14 @@ class XgridPlan:
                                               ptr(out_il_t), C.byref(g) if want_gsum else None))
         return g.value if want_gsum else None
 
+    def apply_records(self, nz, rec_t, out_t, want_gsum=False):
+        """Order-2 sweep of nz <= 8 levels on the records C2lPrep.gradient_records wrote ([ncells_in, 3, nb] device tensor);
+        out [nz, ndst] level-major.  Bit-identical to apply() on the level-major gradients."""
+        g = C.c_double(0.0)
+        check(lib().fg_plan_apply_records(self._h, nz, C.c_void_p(rec_t.data_ptr()), C.c_void_p(out_t.data_ptr()),
+                                          C.byref(g) if want_gsum else None))
+        return g.value if want_gsum else None
+
 
 @dataclass
 class InterpConfig:

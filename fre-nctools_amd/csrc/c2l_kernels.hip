@@ -80,31 +80,35 @@ __device__ __forceinline__ double d_a2b(const double *q, int nx, int ny, int i, 
   return 0.25 * (q[j * w + i] + q[j * w + i + 1] + q[(j + 1) * w + i] + q[(j + 1) * w + i + 1]);
 }
 
-__global__ __launch_bounds__(256) void k_grad_c2l(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
-                                                   const double *data, C2lGeom g, double *grad_x, double *grad_y)
-{
-  long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncells) return;
-  const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
-  const int nx = T.nx, ny = T.ny, nxp = nx + 1;
-  long loc = c - T.cell_off;
-  const int i = (int)(loc % nx), j = (int)(loc / nx);
-  const double *ew = g.edge_w + T.ew_off, *ee = g.edge_e + T.ew_off, *es = g.edge_s + T.es_off, *en = g.edge_n + T.es_off;
-  const double *dx = g.dx + T.dx_off, *dy = g.dy + T.dy_off;
-  const double *enn = g.en_n + 3 * T.dx_off, *ene = g.en_e + 3 * T.dy_off;
-  const long ms = (long)j * nx + i, mn = (long)(j + 1) * nx + i;       // south / north edges of the cell
-  const long mw = (long)j * nxp + i, me = mw + 1;                       // west / east edges
-  // the geometry of the cell is level-independent: load it once, then sweep the levels
-  const double dxs = dx[ms], dxn = dx[mn], dyw = dy[mw], dye = dy[me];
+// grad_c2l of one cell: the level-independent geometry is loaded once (ctor), then one call per level.  The expression order
+// is the reference's (gradient_c2l.c:84-117), so both kernels below give its bits.
+struct C2lCell {
+  int nx, ny, i, j;
+  const double *ew, *ee, *es, *en;
+  double dxs, dxn, dyw, dye, area;
   double ens[3], enn3[3], enw[3], ene3[3], vlo[3], vla[3];
+  __device__ C2lCell(const C2lTile &T, long c, const C2lGeom &g)
+  {
+    nx = T.nx; ny = T.ny;
+    const int nxp = nx + 1;
+    const long loc = c - T.cell_off;
+    i = (int)(loc % nx); j = (int)(loc / nx);
+    ew = g.edge_w + T.ew_off; ee = g.edge_e + T.ew_off; es = g.edge_s + T.es_off; en = g.edge_n + T.es_off;
+    const double *dx = g.dx + T.dx_off, *dy = g.dy + T.dy_off;
+    const double *enn = g.en_n + 3 * T.dx_off, *ene = g.en_e + 3 * T.dy_off;
+    const long ms = (long)j * nx + i, mn = (long)(j + 1) * nx + i;       // south / north edges of the cell
+    const long mw = (long)j * nxp + i, me = mw + 1;                       // west / east edges
+    dxs = dx[ms]; dxn = dx[mn]; dyw = dy[mw]; dye = dy[me];
 #pragma unroll
-  for (int n = 0; n < 3; n++) {
-    ens[n] = enn[3 * ms + n]; enn3[n] = enn[3 * mn + n]; enw[n] = ene[3 * mw + n]; ene3[n] = ene[3 * me + n];
-    vlo[n] = g.vlon[3 * c + n]; vla[n] = g.vlat[3 * c + n];
+    for (int n = 0; n < 3; n++) {
+      ens[n] = enn[3 * ms + n]; enn3[n] = enn[3 * mn + n]; enw[n] = ene[3 * mw + n]; ene3[n] = ene[3 * me + n];
+      vlo[n] = g.vlon[3 * c + n]; vla[n] = g.vlat[3 * c + n];
+    }
+    area = g.area[c];
   }
-  const double area = g.area[c];
-  for (int k = 0; k < nz; k++) {
-    const double *q = data + (size_t)k * F + T.f_off;
+  // q = the tile's halo'd level
+  __device__ __forceinline__ void level(const double *q, double *gx_out, double *gy_out) const
+  {
     const double b00 = d_a2b(q, nx, ny, i, j, ew, ee, es, en), b10 = d_a2b(q, nx, ny, i + 1, j, ew, ee, es, en);
     const double b01 = d_a2b(q, nx, ny, i, j + 1, ew, ee, es, en), b11 = d_a2b(q, nx, ny, i + 1, j + 1, ew, ee, es, en);
     double g3[3];
@@ -120,9 +124,54 @@ __global__ __launch_bounds__(256) void k_grad_c2l(const C2lTile *tiles, int ntil
     gx *= 6371000.;
     double gy = (vla[0] * g3[0] + vla[1] * g3[1] + vla[2] * g3[2]) / area;
     gy *= 6371000.;
+    *gx_out = gx; *gy_out = gy;
+  }
+};
+
+__global__ __launch_bounds__(256) void k_grad_c2l(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
+                                                   const double *data, C2lGeom g, double *grad_x, double *grad_y)
+{
+  long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncells) return;
+  const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
+  const C2lCell cell(T, c, g);
+  for (int k = 0; k < nz; k++) {
+    double gx, gy;
+    cell.level(data + (size_t)k * F + T.f_off, &gx, &gy);
     grad_x[(size_t)k * ncells + c] = gx;
     grad_y[(size_t)k * ncells + c] = gy;
   }
+}
+
+// The same gradients written as the sweep's merged records rec[cell][3][NB] = {field, grad_x, grad_y} x levels (zero padded
+// beyond nz): what fg_plan_apply would otherwise build from the level-major arrays with k_merge3.  One lane per cell computes
+// its record into LDS; the block then stores the CB records as one contiguous run.
+template <int NB, int CB>
+__global__ __launch_bounds__(CB) void k_grad_c2l_rec(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
+                                                     const double *data, C2lGeom g, double *rec)
+{
+  constexpr int R = 3 * NB;
+  __shared__ double tile[CB * (R + 1)];
+  const long c0 = (long)blockIdx.x * CB;
+  const long c = c0 + threadIdx.x;
+  if (c < ncells) {
+    const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
+    const C2lCell cell(T, c, g);
+    double *row = tile + threadIdx.x * (R + 1);
+    const long fc = T.f_off + (long)(cell.j + 1) * (T.nx + 2) + cell.i + 1;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      double f = 0.0, gx = 0.0, gy = 0.0;
+      if (k < nz) {
+        f = data[(size_t)k * F + fc];
+        cell.level(data + (size_t)k * F + T.f_off, &gx, &gy);
+      }
+      row[k] = f; row[NB + k] = gx; row[2 * NB + k] = gy;
+    }
+  }
+  __syncthreads();
+  const long cnt = ((ncells - c0) < CB ? (ncells - c0) : CB) * R;
+  for (long e = threadIdx.x; e < cnt; e += CB) rec[(size_t)c0 * R + e] = tile[(e / R) * (R + 1) + (e % R)];
 }
 
 __global__ __launch_bounds__(256) void k_grad_mask(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
@@ -161,6 +210,16 @@ void fgd_grad_c2l(const void *tiles, int ntiles, long ncells, long F, int nz, co
   if (ncells <= 0 || nz <= 0) return;
   C2lGeom g{geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9], geom[10]};
   k_grad_c2l<<<nblk(ncells, 256), 256, 0, st>>>((const C2lTile *)tiles, ntiles, ncells, F, nz, data, g, grad_x, grad_y);
+}
+void fgd_grad_c2l_rec(const void *tiles, int ntiles, long ncells, long F, int nz, int nb_pad, const double *data,
+                      const double *const *geom, double *rec, hipStream_t st)
+{
+  if (ncells <= 0 || nz <= 0) return;
+  C2lGeom g{geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9], geom[10]};
+  const C2lTile *T = (const C2lTile *)tiles;
+  if (nb_pad == 8) k_grad_c2l_rec<8, 64><<<nblk(ncells, 64), 64, 0, st>>>(T, ntiles, ncells, F, nz, data, g, rec);
+  else if (nb_pad == 4) k_grad_c2l_rec<4, 128><<<nblk(ncells, 128), 128, 0, st>>>(T, ntiles, ncells, F, nz, data, g, rec);
+  else k_grad_c2l_rec<2, 128><<<nblk(ncells, 128), 128, 0, st>>>(T, ntiles, ncells, F, nz, data, g, rec);
 }
 void fgd_grad_mask(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, double missing, int *mask, hipStream_t st)
 {

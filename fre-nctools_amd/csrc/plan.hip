@@ -1124,6 +1124,34 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
   return 0;
 }
 
+// The order-2 sweep on records made by fg_c2l_gradient_records: no level-major detour, no merge pass.
+extern "C" int fg_plan_apply_records(fg_plan *pl, int nz, const double *rec, double *out, double *gsum_out)
+{
+  if (!pl || !rec || !out) return fail(FG_ERR_ARG, "null argument");
+  if (!pl->finalized) return fail(FG_ERR_STATE, "fg_plan_apply_records: call fg_plan_finalize first");
+  if (pl->order != 2) return fail(FG_ERR_ARG, "fg_plan_apply_records: records carry gradients, the plan is first order");
+  if (nz < 1 || nz > 8) return fail(FG_ERR_ARG, "fg_plan_apply_records: 1 to 8 levels per call");
+  HIPCHK(hipSetDevice(pl->device));
+  hipStream_t st = pl->stream;
+  const int ndst = pl->ndst, nbp = nz > 4 ? 8 : (nz > 2 ? 4 : 2);
+  if (gsum_out && !pl->il_rs) {
+    pl->il_rs = pl->alloc<double>((size_t)ndst * 16);
+    if (!pl->il_rs) return fail(FG_ERR_HIP, "out of device memory");
+  }
+  pl->apply_pt.start(g_profiling != 0, st);
+  pl->apply_pt.begin(PH_APPLY);
+  fgd_apply_il_merged(nbp, ndst, pl->csr, rec, -1.e20, out, gsum_out ? pl->il_rs : nullptr, (long)ndst, nz, st);
+  if (gsum_out) fgd_reduce_sum(pl->il_rs, (long)ndst * nbp, pl->red_partial, pl->red_result, st);
+  pl->apply_pt.end();
+  if (pl->apply_pt.on) pl->apply_spans++;
+  if (gsum_out) {
+    HIPCHK(hipMemcpyAsync(gsum_out, pl->red_result, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------- the sweep with every option
 static int ex_check(fg_plan *pl, const fg_apply_opts *o, const double *data, const double *gx, const double *gy, int nz, const char *who)
 {
@@ -1953,6 +1981,18 @@ extern "C" int fg_c2l_gradient(fg_c2l *h, const double *halo_data, int nz, int h
     if (has_missing) fgd_grad_mask(h->tiles_dev, h->ntiles, h->ncells, h->F, nz, halo_data, missing, grad_mask, h->stream);
     else HIPCHK(hipMemsetAsync(grad_mask, 0, (size_t)nz * h->ncells * sizeof(int), h->stream));
   }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int records_nb_pad(int nz) { return nz > 4 ? 8 : (nz > 2 ? 4 : 2); }
+
+extern "C" int fg_c2l_gradient_records(fg_c2l *h, const double *halo_data, int nz, double *rec)
+{
+  if (!h || !halo_data || !rec) return fail(FG_ERR_ARG, "bad argument");
+  if (nz < 1 || nz > 8) return fail(FG_ERR_ARG, "fg_c2l_gradient_records: 1 to 8 levels per call");
+  HIPCHK(hipSetDevice(h->device));
+  fgd_grad_c2l_rec(h->tiles_dev, h->ntiles, h->ncells, h->F, nz, records_nb_pad(nz), halo_data, (const double *const *)h->geom_dev, rec, h->stream);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -176,6 +176,8 @@ void fgd_pack_interior(const void *tiles, int ntiles, long ncells, long F, int n
 void fgd_halo_gather(long F, int nz, const int *map, double *data, hipStream_t st);
 void fgd_grad_c2l(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, const double *const *geom,
                   double *grad_x, double *grad_y, hipStream_t st);
+void fgd_grad_c2l_rec(const void *tiles, int ntiles, long ncells, long F, int nz, int nb_pad, const double *data,
+                      const double *const *geom, double *rec, hipStream_t st);
 void fgd_grad_mask(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, double missing, int *mask, hipStream_t st);
 size_t fgd_c2l_tile_size(void);
 void fgd_c2l_tile_fill(void *dst, int idx, int nx, int ny, long cell_off, long f_off, long dx_off, long dy_off, long ew_off, long es_off);

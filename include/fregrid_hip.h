@@ -220,6 +220,11 @@ int fg_plan_apply(fg_plan *plan, const double *data, const double *grad_x, const
 int fg_plan_apply_interleaved(fg_plan *plan, int nb, const double *data_il, const double *grad_x_il,
                               const double *grad_y_il, double *out_il, double *gsum_out);
 
+/* The order-2 sweep of 1 <= nz <= 8 levels on the records fg_c2l_gradient_records writes (rec[ncells_in][3][nb], device):
+ * the layout fg_plan_apply builds internally, so out [nz][ndst] (level-major, device) equals fg_plan_apply's bit for bit
+ * while the level-major gradient arrays and the transposition pass are skipped.  gsum_out as in fg_plan_apply. */
+int fg_plan_apply_records(fg_plan *plan, int nz, const double *rec, double *out, double *gsum_out);
+
 /* The sweep with every remaining option of do_scalar_conserve_interp (conserve_interp.c:507-910).  All pointers are
  * DEVICE pointers over the flattened source cells (tiles back to back, [ny][nx], no halo) or destination cells.
  *   weight          grid_in[].weight (weight_exist, --weight_file/--weight_field), or NULL
@@ -319,6 +324,11 @@ int  fg_c2l_fill_halo(fg_c2l *h, const double *src, double *halo_data, int nz);
 /* halo_data [nz][F] -> grad_x, grad_y [nz][ncells]; grad_mask int [nz][ncells] or NULL.  Device pointers. */
 int  fg_c2l_gradient(fg_c2l *h, const double *halo_data, int nz, int has_missing, double missing,
                      double *grad_x, double *grad_y, int *grad_mask);
+/* The same gradients for 1 <= nz <= 8 levels, written straight into the layout the order-2 sweep reads:
+ * rec[ncells][3][nb] = {field, grad_x, grad_y} x levels, nb = 2, 4 or 8 (the least >= nz, zero padded).  Device pointers;
+ * rec holds ncells * 3 * nb doubles.  Pair with fg_plan_apply_records: halo_data -> records -> remapped levels, with no
+ * level-major gradient arrays in between (no missing values: nz > 1 forbids them, conserve_interp.c:541). */
+int  fg_c2l_gradient_records(fg_c2l *h, const double *halo_data, int nz, double *rec);
 
 /* Host helpers behind fg_c2l_create, exported for tests and for callers without a mosaic file. */
 int fg_c2l_grid_info(int nx, int ny, const double *xt, const double *yt, const double *xc, const double *yc,
