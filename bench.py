@@ -239,7 +239,7 @@ def main():
     dtb = time.perf_counter() - tb
     apply_kernel_ms = p.phase_ms()["apply"]
     # ---- per-chunk pipeline of an order-2 variable: halo update + grad_c2l + sweep of nz levels, (a) through the reference's
-    # level-major gradient arrays, (b) fused: gradients written straight into the sweep's records (fg_c2l_gradient_records +
+    # level-major gradient arrays, (b) fused: one kernel from the unpadded levels to the sweep's records (fg_c2l_records +
     # fg_plan_apply_records) -- bit-identical outputs (tests/test_gpu_c2l.py)
     dtl = dtf = 0.0
     if nz <= 8:
@@ -250,8 +250,7 @@ def main():
             p.apply(data_t, out_t, nz=nz, grad_x_t=gx_t, grad_y_t=gy_t)
 
         def pipe_fused():
-            prep.fill_halo(src_t, data_t, nz)
-            prep.gradient_records(data_t, nz, rec_t)
+            prep.records(src_t, nz, rec_t)
             p.apply_records(nz, rec_t, out_t)
 
         times = []
@@ -346,8 +345,8 @@ def main():
             "pipeline": None if dtf <= 0 else {
                 "levels": nz, "level_major_ms_per_call": dtl * 1e3, "fused_ms_per_call": dtf * 1e3,
                 "fused_remapped_points_per_s": ndst * nz / dtf,
-                "note": "halo update + grad_c2l + order-2 sweep of one chunk of levels; fused = gradients written straight into "
-                        "the sweep's [cell][field,grad_x,grad_y][level] records (no level-major gradient arrays, no merge pass)"},
+                "note": "halo update + grad_c2l + order-2 sweep of one chunk of levels; fused = one kernel from the unpadded levels to "
+                        "the sweep's [cell][field,grad_x,grad_y][level] records (no halo'd copy, no level-major gradients, no merge pass)"},
             "phase_ms": phases, "search_stats": stats,
             "roofline": roof, "roofline_apply": roof_a,
         }

@@ -38,7 +38,7 @@ EXPORTS = [
     "create_xgrid_1dx2d_order1_", "create_xgrid_1dx2d_order2_", "create_xgrid_2dx1d_order1_", "create_xgrid_2dx1d_order2_",
     "clip", "box_ctrlat", "box_ctrlon", "get_grid_area_no_adjust", "get_grid_area_no_adjust_", "fg_plan_stream", "fg_plan_sync",
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
-    "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_gradient_records", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
+    "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_gradient_records", "fg_c2l_records", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
     "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
     "fg_plan_stats", "fg_set_search_mode", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
@@ -219,6 +219,8 @@ def lib():
     L.fg_c2l_gradient.restype = C.c_int
     L.fg_c2l_gradient_records.argtypes = [vp, vp, C.c_int, vp]
     L.fg_c2l_gradient_records.restype = C.c_int
+    L.fg_c2l_records.argtypes = [vp, vp, C.c_int, vp]
+    L.fg_c2l_records.restype = C.c_int
     L.fg_c2l_grid_info.argtypes = [C.c_int, C.c_int] + [dp] * 15
     L.fg_c2l_grid_info.restype = C.c_int
     L.fg_find_contacts.argtypes = [C.c_int, ip, ip, dpp, dpp, C.c_int] + [ip] * 10

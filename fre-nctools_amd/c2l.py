@@ -123,3 +123,8 @@ class C2lPrep:
         """halo'd levels [nz, F] -> rec [ncells, 3, records_nb(nz)] = {field, grad_x, grad_y} per level: the layout
         XgridPlan.apply_records sweeps, with no level-major gradient arrays in between."""
         check(lib().fg_c2l_gradient_records(self._h, C.c_void_p(halo_t.data_ptr()), nz, C.c_void_p(rec_t.data_ptr())))
+
+    def records(self, src_t, nz, rec_t):
+        """unpadded levels [nz, ncells] -> rec [ncells, 3, records_nb(nz)] in one pass (fg_c2l_records): halo values are read
+        from the neighbour tiles through the halo map, no halo'd copy is made."""
+        check(lib().fg_c2l_records(self._h, C.c_void_p(src_t.data_ptr()), nz, C.c_void_p(rec_t.data_ptr())))

@@ -50,34 +50,33 @@ __global__ __launch_bounds__(256) void k_halo_gather(long F, int nz, const int *
   if (src >= 0) data[(size_t)k * F + e] = data[(size_t)k * F + src];   // sources are interior cells: no read/write overlap
 }
 
-// B-grid value at corner (i, j) of a tile, all four tile edges treated as cubed-sphere edges (gradient_c2l.c:124-195)
-__device__ __forceinline__ double d_a2b(const double *q, int nx, int ny, int i, int j,
-                                        const double *edge_w, const double *edge_e, const double *edge_s, const double *edge_n)
+// B-grid value at corner (i, j) of a tile from the four A-grid cells around it, all four tile edges treated as cubed-sphere
+// edges (gradient_c2l.c:124-195).  cXY = halo'd cell (i+X, j+Y); the sums keep the reference's term order.
+__device__ __forceinline__ double d_a2b4(double c00, double c10, double c01, double c11, int nx, int ny, int i, int j,
+                                         const double *edge_w, const double *edge_e, const double *edge_s, const double *edge_n)
 {
-  const int w = nx + 2;
   const double r3 = 1. / 3.;
-  const int nxp = nx + 1, nyp = ny + 1;
-  if (i == 0 && j == 0)   return r3 * (q[1 * w + 1] + q[1 * w] + q[1]);
-  if (i == nx && j == 0)  return r3 * (q[1 * w + nx] + q[nx] + q[1 * w + nxp]);
-  if (i == nx && j == ny) return r3 * (q[ny * w + nx] + q[ny * w + nxp] + q[nyp * w + nx]);
-  if (i == 0 && j == ny)  return r3 * (q[ny * w + 1] + q[ny * w] + q[nyp * w + 1]);
+  if (i == 0 && j == 0)   return r3 * (c11 + c01 + c10);
+  if (i == nx && j == 0)  return r3 * (c01 + c00 + c11);
+  if (i == nx && j == ny) return r3 * (c00 + c10 + c01);
+  if (i == 0 && j == ny)  return r3 * (c10 + c00 + c11);
   if (i == 0) {
-    double a = 0.5 * (q[j * w] + q[j * w + 1]), b = 0.5 * (q[(j + 1) * w] + q[(j + 1) * w + 1]);
+    double a = 0.5 * (c00 + c10), b = 0.5 * (c01 + c11);
     return edge_w[j] * a + (1 - edge_w[j]) * b;
   }
   if (i == nx) {
-    double a = 0.5 * (q[j * w + nx] + q[j * w + nxp]), b = 0.5 * (q[(j + 1) * w + nx] + q[(j + 1) * w + nxp]);
+    double a = 0.5 * (c00 + c10), b = 0.5 * (c01 + c11);
     return edge_e[j] * a + (1 - edge_e[j]) * b;
   }
   if (j == 0) {
-    double a = 0.5 * (q[i] + q[w + i]), b = 0.5 * (q[i + 1] + q[w + i + 1]);
+    double a = 0.5 * (c00 + c01), b = 0.5 * (c10 + c11);
     return edge_s[i] * a + (1 - edge_s[i]) * b;
   }
   if (j == ny) {
-    double a = 0.5 * (q[ny * w + i] + q[nyp * w + i]), b = 0.5 * (q[ny * w + i + 1] + q[nyp * w + i + 1]);
+    double a = 0.5 * (c00 + c01), b = 0.5 * (c10 + c11);
     return edge_n[i] * a + (1 - edge_n[i]) * b;
   }
-  return 0.25 * (q[j * w + i] + q[j * w + i + 1] + q[(j + 1) * w + i] + q[(j + 1) * w + i + 1]);
+  return 0.25 * (c00 + c10 + c01 + c11);
 }
 
 // grad_c2l of one cell: the level-independent geometry is loaded once (ctor), then one call per level.  The expression order
@@ -109,8 +108,21 @@ struct C2lCell {
   // q = the tile's halo'd level
   __device__ __forceinline__ void level(const double *q, double *gx_out, double *gy_out) const
   {
-    const double b00 = d_a2b(q, nx, ny, i, j, ew, ee, es, en), b10 = d_a2b(q, nx, ny, i + 1, j, ew, ee, es, en);
-    const double b01 = d_a2b(q, nx, ny, i, j + 1, ew, ee, es, en), b11 = d_a2b(q, nx, ny, i + 1, j + 1, ew, ee, es, en);
+    const int w = nx + 2;
+    double v[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++) v[dy][dx] = q[(size_t)(j + dy) * w + i + dx];
+    stencil(v, gx_out, gy_out);
+  }
+  // v[dy][dx] = halo'd cell (i + dx, j + dy): the cell itself is v[1][1]
+  __device__ __forceinline__ void stencil(const double (&v)[3][3], double *gx_out, double *gy_out) const
+  {
+    const double b00 = d_a2b4(v[0][0], v[0][1], v[1][0], v[1][1], nx, ny, i, j, ew, ee, es, en);
+    const double b10 = d_a2b4(v[0][1], v[0][2], v[1][1], v[1][2], nx, ny, i + 1, j, ew, ee, es, en);
+    const double b01 = d_a2b4(v[1][0], v[1][1], v[2][0], v[2][1], nx, ny, i, j + 1, ew, ee, es, en);
+    const double b11 = d_a2b4(v[1][1], v[1][2], v[2][1], v[2][2], nx, ny, i + 1, j + 1, ew, ee, es, en);
     double g3[3];
 #pragma unroll
     for (int n = 0; n < 3; n++) {
@@ -174,6 +186,48 @@ __global__ __launch_bounds__(CB) void k_grad_c2l_rec(const C2lTile *tiles, int n
   for (long e = threadIdx.x; e < cnt; e += CB) rec[(size_t)c0 * R + e] = tile[(e / R) * (R + 1) + (e % R)];
 }
 
+// Unpadded levels src[nz][ncells] -> the sweep's records in one pass: no halo'd copy, no halo fill.  cell_of[e] is, for
+// every element e of the halo'd layout, the (unpadded) cell whose value update_halo would leave there: the cell itself in
+// the interior, the neighbour tile's cell in the halo, -1 where init_halo's zero stays (fg_c2l_create builds it from the same
+// gather map k_halo_gather uses).  Same stencil, same arithmetic as k_grad_c2l_rec on filled halo'd data.
+template <int NB, int CB>
+__global__ __launch_bounds__(CB) void k_c2l_records(const C2lTile *tiles, int ntiles, long ncells, int nz, const double *src,
+                                                    const int *cell_of, C2lGeom g, double *rec)
+{
+  constexpr int R = 3 * NB;
+  __shared__ double tile[CB * (R + 1)];
+  const long c0 = (long)blockIdx.x * CB;
+  const long c = c0 + threadIdx.x;
+  if (c < ncells) {
+    const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
+    const C2lCell cell(T, c, g);
+    int at[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++) at[dy][dx] = cell_of[T.f_off + (long)(cell.j + dy) * (T.nx + 2) + cell.i + dx];
+    double *row = tile + threadIdx.x * (R + 1);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      double f = 0.0, gx = 0.0, gy = 0.0;
+      if (k < nz) {
+        const double *lev = src + (size_t)k * ncells;
+        double v[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++) v[dy][dx] = (at[dy][dx] >= 0) ? lev[at[dy][dx]] : 0.0;
+        f = v[1][1];
+        cell.stencil(v, &gx, &gy);
+      }
+      row[k] = f; row[NB + k] = gx; row[2 * NB + k] = gy;
+    }
+  }
+  __syncthreads();
+  const long cnt = ((ncells - c0) < CB ? (ncells - c0) : CB) * R;
+  for (long e = threadIdx.x; e < cnt; e += CB) rec[(size_t)c0 * R + e] = tile[(e / R) * (R + 1) + (e % R)];
+}
+
 __global__ __launch_bounds__(256) void k_grad_mask(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
                                                     const double *data, double missing, int *mask)
 {
@@ -220,6 +274,16 @@ void fgd_grad_c2l_rec(const void *tiles, int ntiles, long ncells, long F, int nz
   if (nb_pad == 8) k_grad_c2l_rec<8, 64><<<nblk(ncells, 64), 64, 0, st>>>(T, ntiles, ncells, F, nz, data, g, rec);
   else if (nb_pad == 4) k_grad_c2l_rec<4, 128><<<nblk(ncells, 128), 128, 0, st>>>(T, ntiles, ncells, F, nz, data, g, rec);
   else k_grad_c2l_rec<2, 128><<<nblk(ncells, 128), 128, 0, st>>>(T, ntiles, ncells, F, nz, data, g, rec);
+}
+void fgd_c2l_records(const void *tiles, int ntiles, long ncells, int nz, int nb_pad, const double *src, const int *cell_of,
+                     const double *const *geom, double *rec, hipStream_t st)
+{
+  if (ncells <= 0 || nz <= 0) return;
+  C2lGeom g{geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9], geom[10]};
+  const C2lTile *T = (const C2lTile *)tiles;
+  if (nb_pad == 8) k_c2l_records<8, 64><<<nblk(ncells, 64), 64, 0, st>>>(T, ntiles, ncells, nz, src, cell_of, g, rec);
+  else if (nb_pad == 4) k_c2l_records<4, 128><<<nblk(ncells, 128), 128, 0, st>>>(T, ntiles, ncells, nz, src, cell_of, g, rec);
+  else k_c2l_records<2, 128><<<nblk(ncells, 128), 128, 0, st>>>(T, ntiles, ncells, nz, src, cell_of, g, rec);
 }
 void fgd_grad_mask(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, double missing, int *mask, hipStream_t st)
 {

@@ -1847,6 +1847,7 @@ struct fg_c2l {
   std::vector<void *> owned;
   void *tiles_dev = nullptr;
   int *map_dev = nullptr;
+  int *cell_of_dev = nullptr;                     // halo'd element -> unpadded cell whose value it holds after update_halo (-1: zero)
   double *geom_dev[11] = {nullptr};
   std::vector<double> lont_halo, latt_halo;       // host copies (tests / inspection)
   template <typename T> T *alloc(size_t n) { void *p = g_pool.get(device, n * sizeof(T)); if (p) owned.push_back(p); return (T *)p; }
@@ -1916,8 +1917,15 @@ extern "C" int fg_c2l_create(int ntiles, const int *nx, const int *ny, const dou
   for (int t = 0; t < ntiles; t++) fgd_c2l_tile_fill(th.data(), t, nx[t], ny[t], cell_off[t], f_off[t], dx_off[t], dy_off[t], ew_off[t], es_off[t]);
   const std::vector<double> *src[11] = {&dx, &dy, &area, &ew, &ee, &es, &en, &enn, &ene, &vlon, &vlat};
   bool ok = true;
-  h->tiles_dev = h->alloc<char>(th.size()); h->map_dev = h->alloc<int>(fo);
-  ok = ok && h->tiles_dev && h->map_dev;
+  h->tiles_dev = h->alloc<char>(th.size()); h->map_dev = h->alloc<int>(fo); h->cell_of_dev = h->alloc<int>(fo);
+  ok = ok && h->tiles_dev && h->map_dev && h->cell_of_dev;
+  // the gather map composed with the packing: which unpadded cell ends up in each halo'd element
+  std::vector<int> cell_of(fo, -1);
+  for (int t = 0; t < ntiles; t++)
+    for (int j = 0; j < ny[t]; j++) for (int i = 0; i < nx[t]; i++)
+      cell_of[f_off[t] + (long)(j + 1) * (nx[t] + 2) + i + 1] = (int)(cell_off[t] + (long)j * nx[t] + i);
+  for (long e = 0; e < fo; e++) if (map[e] >= 0) cell_of[e] = cell_of[map[e]];     // sources are interior elements
+  ok = ok && hipMemcpy(h->cell_of_dev, cell_of.data(), fo * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
   for (int k = 0; k < 11 && ok; k++) { h->geom_dev[k] = h->alloc<double>(src[k]->size()); ok = ok && h->geom_dev[k]; }
   if (!ok) { fg_c2l_destroy(h); return fail(FG_ERR_HIP, "out of device memory"); }
   ok = ok && hipMemcpy(h->tiles_dev, th.data(), th.size(), hipMemcpyHostToDevice) == hipSuccess;
@@ -1986,6 +1994,16 @@ extern "C" int fg_c2l_gradient(fg_c2l *h, const double *halo_data, int nz, int h
 }
 
 static int records_nb_pad(int nz) { return nz > 4 ? 8 : (nz > 2 ? 4 : 2); }
+
+extern "C" int fg_c2l_records(fg_c2l *h, const double *src, int nz, double *rec)
+{
+  if (!h || !src || !rec) return fail(FG_ERR_ARG, "bad argument");
+  if (nz < 1 || nz > 8) return fail(FG_ERR_ARG, "fg_c2l_records: 1 to 8 levels per call");
+  HIPCHK(hipSetDevice(h->device));
+  fgd_c2l_records(h->tiles_dev, h->ntiles, h->ncells, nz, records_nb_pad(nz), src, h->cell_of_dev, (const double *const *)h->geom_dev, rec, h->stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 
 extern "C" int fg_c2l_gradient_records(fg_c2l *h, const double *halo_data, int nz, double *rec)
 {

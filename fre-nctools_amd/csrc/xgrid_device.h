@@ -178,6 +178,8 @@ void fgd_grad_c2l(const void *tiles, int ntiles, long ncells, long F, int nz, co
                   double *grad_x, double *grad_y, hipStream_t st);
 void fgd_grad_c2l_rec(const void *tiles, int ntiles, long ncells, long F, int nz, int nb_pad, const double *data,
                       const double *const *geom, double *rec, hipStream_t st);
+void fgd_c2l_records(const void *tiles, int ntiles, long ncells, int nz, int nb_pad, const double *src, const int *cell_of,
+                     const double *const *geom, double *rec, hipStream_t st);
 void fgd_grad_mask(const void *tiles, int ntiles, long ncells, long F, int nz, const double *data, double missing, int *mask, hipStream_t st);
 size_t fgd_c2l_tile_size(void);
 void fgd_c2l_tile_fill(void *dst, int idx, int nx, int ny, long cell_off, long f_off, long dx_off, long dy_off, long ew_off, long es_off);

@@ -329,6 +329,10 @@ int  fg_c2l_gradient(fg_c2l *h, const double *halo_data, int nz, int has_missing
  * rec holds ncells * 3 * nb doubles.  Pair with fg_plan_apply_records: halo_data -> records -> remapped levels, with no
  * level-major gradient arrays in between (no missing values: nz > 1 forbids them, conserve_interp.c:541). */
 int  fg_c2l_gradient_records(fg_c2l *h, const double *halo_data, int nz, double *rec);
+/* The whole preparation in one pass: src [nz][ncells] (no halo, as fg_c2l_fill_halo takes it) -> the same records, reading the
+ * neighbour tiles' cells through the halo map instead of materialising the halo'd copy.  Bit-identical to
+ * fg_c2l_fill_halo + fg_c2l_gradient_records. */
+int  fg_c2l_records(fg_c2l *h, const double *src, int nz, double *rec);
 
 /* Host helpers behind fg_c2l_create, exported for tests and for callers without a mosaic file. */
 int fg_c2l_grid_info(int nx, int ny, const double *xt, const double *yt, const double *xc, const double *yc,

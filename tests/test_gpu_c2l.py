@@ -175,6 +175,10 @@ def test_gradient_records_and_sweep_bitwise(fg, gpu_ok, nz):
     assert np.array_equal(_bits(r[:, 1, :nz].T), _bits(gx.cpu().numpy()))
     assert np.array_equal(_bits(r[:, 2, :nz].T), _bits(gy.cpu().numpy()))
     assert np.all(r[:, :, nz:] == 0.0)
+    rec1 = torch.full_like(rec, float("nan"))            # the one-pass variant straight from the unpadded levels
+    prep.records(src, nz, rec1)
+    prep.sync()
+    assert np.array_equal(_bits(rec1.cpu().numpy()), _bits(r))
     ga = plan.apply(halo, out_a, nz=nz, grad_x_t=gx, grad_y_t=gy, want_gsum=True)
     gb = plan.apply_records(nz, rec, out_b, want_gsum=True)
     plan.sync()
