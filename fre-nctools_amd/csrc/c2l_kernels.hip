@@ -155,21 +155,44 @@ __global__ __launch_bounds__(256) void k_grad_c2l(const C2lTile *tiles, int ntil
   }
 }
 
+// Block-wide store of CB records held in registers (row[3*NB] per thread, thread t = cell c0 + t) as one contiguous run, through
+// an LDS tile of CB/PASSES rows: with all 64 rows of a wave staged at once (12.8 KB at NB = 8) LDS alone would cap a CU at
+// three waves per SIMD, so the rows go in PASSES batches.
+template <int NB, int CB, int PASSES>
+__device__ __forceinline__ void d_store_records(const double *row, bool valid, long c0, long ncells, double *rec)
+{
+  constexpr int R = 3 * NB, H = CB / PASSES;
+  __shared__ double tile[H * (R + 1)];
+#pragma unroll
+  for (int p = 0; p < PASSES; p++) {
+    if (p) __syncthreads();
+    if (valid && (int)threadIdx.x / H == p) {
+      double *dst = tile + ((int)threadIdx.x % H) * (R + 1);
+#pragma unroll
+      for (int q = 0; q < R; q++) dst[q] = row[q];
+    }
+    __syncthreads();
+    const long first = c0 + (long)p * H;
+    const long left = ncells - first;
+    const long cnt = (left < H ? (left < 0 ? 0 : left) : H) * R;
+    for (long e = threadIdx.x; e < cnt; e += CB) rec[(size_t)first * R + e] = tile[(e / R) * (R + 1) + (e % R)];
+  }
+}
+
 // The same gradients written as the sweep's merged records rec[cell][3][NB] = {field, grad_x, grad_y} x levels (zero padded
 // beyond nz): what fg_plan_apply would otherwise build from the level-major arrays with k_merge3.  One lane per cell computes
 // its record into LDS; the block then stores the CB records as one contiguous run.
 template <int NB, int CB>
-__global__ __launch_bounds__(CB) void k_grad_c2l_rec(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
+__global__ __launch_bounds__(CB) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_grad_c2l_rec(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
                                                      const double *data, C2lGeom g, double *rec)
 {
   constexpr int R = 3 * NB;
-  __shared__ double tile[CB * (R + 1)];
   const long c0 = (long)blockIdx.x * CB;
   const long c = c0 + threadIdx.x;
+  double row[R];
   if (c < ncells) {
     const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
     const C2lCell cell(T, c, g);
-    double *row = tile + threadIdx.x * (R + 1);
     const long fc = T.f_off + (long)(cell.j + 1) * (T.nx + 2) + cell.i + 1;
 #pragma unroll
     for (int k = 0; k < NB; k++) {
@@ -181,9 +204,7 @@ __global__ __launch_bounds__(CB) void k_grad_c2l_rec(const C2lTile *tiles, int n
       row[k] = f; row[NB + k] = gx; row[2 * NB + k] = gy;
     }
   }
-  __syncthreads();
-  const long cnt = ((ncells - c0) < CB ? (ncells - c0) : CB) * R;
-  for (long e = threadIdx.x; e < cnt; e += CB) rec[(size_t)c0 * R + e] = tile[(e / R) * (R + 1) + (e % R)];
+  d_store_records<NB, CB, (NB >= 8 ? 2 : 1)>(row, c < ncells, c0, ncells, rec);
 }
 
 // Unpadded levels src[nz][ncells] -> the sweep's records in one pass: no halo'd copy, no halo fill.  cell_of[e] is, for
@@ -191,13 +212,13 @@ __global__ __launch_bounds__(CB) void k_grad_c2l_rec(const C2lTile *tiles, int n
 // the interior, the neighbour tile's cell in the halo, -1 where init_halo's zero stays (fg_c2l_create builds it from the same
 // gather map k_halo_gather uses).  Same stencil, same arithmetic as k_grad_c2l_rec on filled halo'd data.
 template <int NB, int CB>
-__global__ __launch_bounds__(CB) void k_c2l_records(const C2lTile *tiles, int ntiles, long ncells, int nz, const double *src,
+__global__ __launch_bounds__(CB) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_c2l_records(const C2lTile *tiles, int ntiles, long ncells, int nz, const double *src,
                                                     const int *cell_of, C2lGeom g, double *rec)
 {
   constexpr int R = 3 * NB;
-  __shared__ double tile[CB * (R + 1)];
   const long c0 = (long)blockIdx.x * CB;
   const long c = c0 + threadIdx.x;
+  double row[R];
   if (c < ncells) {
     const C2lTile T = tiles[d_find_tile(tiles, ntiles, c)];
     const C2lCell cell(T, c, g);
@@ -206,7 +227,6 @@ __global__ __launch_bounds__(CB) void k_c2l_records(const C2lTile *tiles, int nt
     for (int dy = 0; dy < 3; dy++)
 #pragma unroll
       for (int dx = 0; dx < 3; dx++) at[dy][dx] = cell_of[T.f_off + (long)(cell.j + dy) * (T.nx + 2) + cell.i + dx];
-    double *row = tile + threadIdx.x * (R + 1);
 #pragma unroll
     for (int k = 0; k < NB; k++) {
       double f = 0.0, gx = 0.0, gy = 0.0;
@@ -223,9 +243,7 @@ __global__ __launch_bounds__(CB) void k_c2l_records(const C2lTile *tiles, int nt
       row[k] = f; row[NB + k] = gx; row[2 * NB + k] = gy;
     }
   }
-  __syncthreads();
-  const long cnt = ((ncells - c0) < CB ? (ncells - c0) : CB) * R;
-  for (long e = threadIdx.x; e < cnt; e += CB) rec[(size_t)c0 * R + e] = tile[(e / R) * (R + 1) + (e % R)];
+  d_store_records<NB, CB, (NB >= 8 ? 2 : 1)>(row, c < ncells, c0, ncells, rec);
 }
 
 __global__ __launch_bounds__(256) void k_grad_mask(const C2lTile *tiles, int ntiles, long ncells, long F, int nz,
