@@ -325,7 +325,7 @@ def main():
                   "kernel_ms_separate_arrays": apply_kernel_ms}
         roof_a["frac"] = roof_a["achieved"] / HBM_PEAK_GBS if roof_a["achieved"] else None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1:      # the PMC passes were taken on the single-GPU launch sizes
             try:
                 tr = json.load(open(pmc))
                 roof["traffic"] = tr.get("k_clip_quad")
