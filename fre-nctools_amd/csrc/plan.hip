@@ -400,9 +400,10 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(scan_n));
   int *cand_cnt = pl->alloc<int>(ncand + 1);
   int *cand_off = pl->alloc<int>(ncand + 1);
+  int *cand_stage = pl->alloc<int>(4 * (size_t)(ncand + 1));        // int4 per candidate lane (k_candidates)
   int *heavy_list = pl->alloc<int>(nsrc + 1);
   pl->xoff = pl->alloc<int>(nsrc + 1);
-  if (!zero_blk || !bin_start || !scan_ws || !cand_cnt || !cand_off || !heavy_list || !pl->xoff) return fail(FG_ERR_HIP, "out of device memory");
+  if (!zero_blk || !bin_start || !scan_ws || !cand_cnt || !cand_off || !cand_stage || !heavy_list || !pl->xoff) return fail(FG_ERR_HIP, "out of device memory");
   DevCounters *dc = (DevCounters *)zero_blk;
   int *bin_cnt = (int *)(zero_blk + zc), *bin_fill = bin_cnt + (nslots + 1), *nacc = bin_fill + (nslots + 1);
   HIPCHK(hipMemsetAsync(zero_blk, 0, zbytes, st));
@@ -452,7 +453,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
 
   // --- candidate pairs
   pt.begin(PH_CANDIDATES);
-  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, &dc->heavy_cnt, 0, st);
+  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, &dc->heavy_cnt, 0, cand_stage, st);
   fgd_exclusive_scan(cand_cnt, ncand, cand_off, scan_ws, &dc->total[1], st);
   pt.end();
   unsigned long long npairs64 = cap_pairs;
@@ -472,7 +473,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   if (!pair_src || !pair_dst || !tmp_area || !defer_list || (order == 2 && (!tmp_clon || !tmp_clat)))
     return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_CANDIDATES);
-  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, &dc->heavy_cnt, npairs, st);
+  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, &dc->heavy_cnt, npairs, cand_stage, st);
   pt.end();
 
   // --- clip, area, centroid integrals (+ accepted count per source cell)
@@ -558,7 +559,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pl->stats[FG_STAT_EXACT] = fast ? 0 : 1;
 
   // scratch no longer needed
-  void *scratch[] = {zero_blk, bin_start, scan_ws, bin_entries, heavy_list, cand_cnt, cand_off, pair_src, pair_dst,
+  void *scratch[] = {zero_blk, bin_start, scan_ws, bin_entries, heavy_list, cand_cnt, cand_off, cand_stage, pair_src, pair_dst,
                      tmp_area, tmp_clon, tmp_clat, defer_list};
   for (void *p : scratch) pl->release(p);
   pl->searched = true;
