@@ -21,25 +21,73 @@ __global__ __launch_bounds__(256) void k_csr_count(long nx, const int *x_dst, in
   if (n < nx) atomicAdd(&row_cnt[x_dst[n]], 1);
 }
 
+// Slot of every exchange cell in its destination row.  Exchange cells are ordered by source cell, so in a fine -> coarse remap
+// long runs of consecutive cells fall into the same row (C768 -> 1 deg: ~8): one atomic per run of equal rows within a wave
+// instead of one per cell (the per-cell version spent 0.4 ms there on same-address atomics); the cells of a run take
+// consecutive slots in ascending order.
 __global__ __launch_bounds__(256) void k_csr_fill(long nx, const int *x_dst, const int *row_ptr, int *row_fill, int *perm)
 {
-  long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= nx) return;
-  int d = x_dst[n];
-  int pos = atomicAdd(&row_fill[d], 1);
-  perm[row_ptr[d] + pos] = (int)n;
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int d = (n < nx) ? x_dst[n] : -1;
+  const int prev = __shfl_up(d, 1);
+  const bool head = (lane == 0) || (d != prev);
+  const unsigned long long heads = __ballot(head);
+  const int start = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));     // head of this lane's run
+  const unsigned long long above = (start == 63) ? 0ull : (heads & ~((2ull << start) - 1ull));
+  const int end = above ? (__ffsll((long long)above) - 1) : 64;
+  int base = 0;
+  if (lane == start && d >= 0) base = atomicAdd(&row_fill[d], end - start);
+  base = __shfl(base, start);
+  if (d >= 0) perm[row_ptr[d] + base + (lane - start)] = (int)n;
 }
 
-// restore ascending exchange-cell order inside each row (rows are short: ~4 entries)
-__global__ __launch_bounds__(256) void k_csr_sort_rows(int ndst, const int *row_ptr, int *perm)
+// Restore ascending exchange-cell order inside each row.  Rows are short when the grids are of similar resolution (~4
+// entries): one thread sorts its row by insertion.  Fine -> coarse remaps have rows of 50-1000 entries (C768 -> 1 deg: 73 on
+// average), where that serial O(n^2) loop in global memory took 2.2 ms; such rows are sorted by the whole wave instead: the
+// row is staged in LDS and every lane places its elements at their rank (the exchange-cell numbers are distinct).
+// RPW = rows per wave: 64 when rows are short (every lane sorts its own), 16 when the mean row is long, so that four times
+// as many waves are in flight to hide the global-memory round trips of the row-by-row part.
+template <int RPW>
+__global__ __launch_bounds__(64) void k_csr_sort_rows(int ndst, const int *row_ptr, int *perm)
 {
-  int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= ndst) return;
-  int b = row_ptr[d], e = row_ptr[d + 1];
-  for (int i = b + 1; i < e; i++) {
-    int v = perm[i], j = i - 1;
-    while (j >= b && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
-    perm[j + 1] = v;
+  constexpr int SHORT = 12, CAP = 2048, BT = 64;
+  __shared__ int sh[CAP];
+  __shared__ int long_b[RPW], long_n[RPW];
+  __shared__ int nlong;
+  if (threadIdx.x == 0) nlong = 0;
+  __syncthreads();
+  const int d = blockIdx.x * RPW + threadIdx.x;
+  int b = 0, e = 0;
+  if ((int)threadIdx.x < RPW && d < ndst) { b = row_ptr[d]; e = row_ptr[d + 1]; }
+  if (e - b > SHORT) { const int q = atomicAdd(&nlong, 1); long_b[q] = b; long_n[q] = e - b; }
+  else
+    for (int i = b + 1; i < e; i++) {
+      int v = perm[i], j = i - 1;
+      while (j >= b && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
+      perm[j + 1] = v;
+    }
+  __syncthreads();
+  const int nl = nlong;
+  for (int q = 0; q < nl; q++) {
+    const int rb = long_b[q], n = long_n[q];
+    if (n <= CAP) {
+      for (int i = threadIdx.x; i < n; i += BT) sh[i] = perm[rb + i];
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += BT) {
+        const int v = sh[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (sh[j] < v) ? 1 : 0;
+        perm[rb + rank] = v;
+      }
+      __syncthreads();
+    } else if (threadIdx.x == 0) {                       // beyond the staging capacity: serial, as before
+      for (int i = rb + 1; i < rb + n; i++) {
+        int v = perm[i], j = i - 1;
+        while (j >= rb && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
+        perm[j + 1] = v;
+      }
+    }
   }
 }
 
@@ -486,9 +534,11 @@ void fgd_csr_fill(long nx, const int *x_dst, const int *row_ptr, int *row_fill, 
 {
   if (nx > 0) k_csr_fill<<<nblk(nx, 256), 256, 0, st>>>(nx, x_dst, row_ptr, row_fill, perm);
 }
-void fgd_csr_sort_rows(int ndst, const int *row_ptr, int *perm, hipStream_t st)
+void fgd_csr_sort_rows(int ndst, long nx, const int *row_ptr, int *perm, hipStream_t st)
 {
-  if (ndst > 0) k_csr_sort_rows<<<nblk(ndst, 256), 256, 0, st>>>(ndst, row_ptr, perm);
+  if (ndst <= 0) return;
+  if (nx > 8 * (long)ndst) k_csr_sort_rows<16><<<nblk(ndst, 16), 64, 0, st>>>(ndst, row_ptr, perm);
+  else                     k_csr_sort_rows<64><<<nblk(ndst, 64), 64, 0, st>>>(ndst, row_ptr, perm);
 }
 void fgd_csr_gather(int order, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
                     const double *x_c2, const int *src_idx_f, FgCsr csr, hipStream_t st)

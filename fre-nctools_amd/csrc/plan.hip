@@ -878,7 +878,7 @@ static int build_csr(fg_plan *pl)
   }
   fgd_exclusive_scan(row_cnt, ndst, pl->csr.row_ptr, scan_ws, total_dev, st);
   fgd_csr_fill(nx, pl->x_dst, pl->csr.row_ptr, row_cnt + ndst + 1, perm, st);
-  fgd_csr_sort_rows(ndst, pl->csr.row_ptr, perm, st);
+  fgd_csr_sort_rows(ndst, nx, pl->csr.row_ptr, perm, st);
   fgd_csr_gather(pl->order, nx, perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, pl->csr, st);
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());

@@ -97,7 +97,7 @@ struct FgCsr {
 };
 void fgd_csr_count(long nx, const int *x_dst, int *row_cnt, hipStream_t st);
 void fgd_csr_fill(long nx, const int *x_dst, const int *row_ptr, int *row_fill, int *perm, hipStream_t st);
-void fgd_csr_sort_rows(int ndst, const int *row_ptr, int *perm, hipStream_t st);
+void fgd_csr_sort_rows(int ndst, long nx, const int *row_ptr, int *perm, hipStream_t st);
 void fgd_csr_gather(int order, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
                     const double *x_c2, const int *src_idx_f, FgCsr csr, hipStream_t st);
 void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsrc, int *src_idx_f, hipStream_t st);

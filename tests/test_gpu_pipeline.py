@@ -84,8 +84,19 @@ def test_setup_conserve_interp_vs_oracle(fg, gpu_ok, order, ni, nlon, nlat):
 def test_sweep_bitwise_with_oracle_weights(fg, gpu_ok, order, nz, has_missing):
     """Feed the ORACLE's exchange cells to the device sweep: the CSR row order reproduces the reference's
     summation order, so the remapped field is bit-identical (bar: 1e-6 relative)."""
+    _sweep_bitwise(fg, order, nz, has_missing, 24, 72, 36)
+
+
+@pytest.mark.parametrize("order,nz,ni,nlon,nlat", [(2, 3, 32, 6, 3), (1, 2, 64, 4, 2), (2, 8, 64, 4, 2)])
+def test_sweep_bitwise_long_rows(fg, gpu_ok, order, nz, ni, nlon, nlat):
+    """Fine -> coarse: destination rows of ~400 exchange cells (sorted by a whole wave, k_csr_sort_rows) and of ~3400
+    (beyond its LDS staging: the serial path), filled with one atomic per run of equal rows (k_csr_fill).  The row order must
+    still be the reference's summation order: bit-identical remapped levels."""
+    _sweep_bitwise(fg, order, nz, False, ni, nlon, nlat)
+
+
+def _sweep_bitwise(fg, order, nz, has_missing, ni, nlon, nlat):
     import torch
-    ni, nlon, nlat = 24, 72, 36
     lon, lat = fg.gnomonic_ed_corners(ni)
     lo, la = fg.latlon_corners(nlon, nlat)
     o = orc.orc_setup(order, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
