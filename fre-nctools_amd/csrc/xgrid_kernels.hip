@@ -162,44 +162,59 @@ long fgd_scan_ws_elems(long n) { return (n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK + 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cell_struct(const FgTile *tiles, int ntiles, int ncells, FgCells c, unsigned *err)
 {
+  // the 16 vertex doubles of a cell record are staged so that the block stores its 256 records as one contiguous run
+  // (a lane writing its own 128-byte record makes sixteen 8-byte stores at a 128-byte stride)
+  __shared__ double vtile[256 * 17];
   d_load_trig_table();
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ncells) return;
-  int t = 0;
-  while (t + 1 < ntiles && s >= tiles[t + 1].cell_off) t++;
-  const FgTile T = tiles[t];
-  int loc = s - T.cell_off;
-  int i = loc % T.nx, j = loc / T.nx;
-  int nxp = T.nx + 1;
-  int n0 = j * nxp + i, n1 = n0 + 1, n3 = n0 + nxp, n2 = n3 + 1;
-  double x[G_FIXCAP], y[G_FIXCAP];
-  x[0] = T.lon[n0]; y[0] = T.lat[n0];
-  x[1] = T.lon[n1]; y[1] = T.lat[n1];
-  x[2] = T.lon[n2]; y[2] = T.lat[n2];
-  x[3] = T.lon[n3]; y[3] = T.lat[n3];
-  double lmin = y[0], lmax = y[0];
+  const int s0 = blockIdx.x * blockDim.x;
+  const int s = s0 + threadIdx.x;
+  double *row = vtile + threadIdx.x * 17;
 #pragma unroll
-  for (int k = 1; k < 4; k++) { if (y[k] < lmin) lmin = y[k]; if (y[k] > lmax) lmax = y[k]; }
-  c.lat_min[s] = lmin; c.lat_max[s] = lmax;
-  if (!(lmin >= -G_HPI - 1.e-6) || !(lmax <= G_HPI + 1.e-6)) atomicOr(err, G_ERRBIT_BADLAT);   // also catches NaN
-  int n = d_fix_lon(x, y, 4, G_PI);
-  if (n < 0 || n > G_MAXV) {
-    atomicOr(err, G_ERRBIT_MAXV);
-    c.nv[s] = 0; c.lon_min[s] = 0; c.lon_max[s] = 0; c.lon_avg[s] = 0; c.area[s] = 0;
-    return;
+  for (int k = 0; k < 16; k++) row[k] = 0.0;
+  if (s < ncells) {
+    int t = 0;
+    while (t + 1 < ntiles && s >= tiles[t + 1].cell_off) t++;
+    const FgTile T = tiles[t];
+    int loc = s - T.cell_off;
+    int i = loc % T.nx, j = loc / T.nx;
+    int nxp = T.nx + 1;
+    int n0 = j * nxp + i, n1 = n0 + 1, n3 = n0 + nxp, n2 = n3 + 1;
+    double x[G_FIXCAP], y[G_FIXCAP];
+    x[0] = T.lon[n0]; y[0] = T.lat[n0];
+    x[1] = T.lon[n1]; y[1] = T.lat[n1];
+    x[2] = T.lon[n2]; y[2] = T.lat[n2];
+    x[3] = T.lon[n3]; y[3] = T.lat[n3];
+    double lmin = y[0], lmax = y[0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) { if (y[k] < lmin) lmin = y[k]; if (y[k] > lmax) lmax = y[k]; }
+    c.lat_min[s] = lmin; c.lat_max[s] = lmax;
+    if (!(lmin >= -G_HPI - 1.e-6) || !(lmax <= G_HPI + 1.e-6)) atomicOr(err, G_ERRBIT_BADLAT);   // also catches NaN
+    int n = d_fix_lon(x, y, 4, G_PI);
+    if (n < 0 || n > G_MAXV) {
+      atomicOr(err, G_ERRBIT_MAXV);
+      c.nv[s] = 0; c.lon_min[s] = 0; c.lon_max[s] = 0; c.lon_avg[s] = 0; c.area[s] = 0;
+    } else {
+      double xmin = x[0], xmax = x[0], xs = 0;
+      for (int k = 1; k < n; k++) { if (x[k] < xmin) xmin = x[k]; if (x[k] > xmax) xmax = x[k]; }
+      for (int k = 0; k < n; k++) xs += x[k];
+      xs /= n;
+      c.lon_min[s] = xmin; c.lon_max[s] = xmax; c.lon_avg[s] = xs;
+      c.nv[s] = n;
+      for (int k = 0; k < G_MAXV; k++) {
+        row[k] = (k < n) ? x[k] : 0.0;
+        row[8 + k] = (k < n) ? y[k] : 0.0;
+      }
+      c.area[s] = d_poly_area<1>(x, y, n);
+    }
   }
-  double xmin = x[0], xmax = x[0], xs = 0;
-  for (int k = 1; k < n; k++) { if (x[k] < xmin) xmin = x[k]; if (x[k] > xmax) xmax = x[k]; }
-  for (int k = 0; k < n; k++) xs += x[k];
-  xs /= n;
-  c.lon_min[s] = xmin; c.lon_max[s] = xmax; c.lon_avg[s] = xs;
-  c.nv[s] = n;
-  double *vp = c.verts + (size_t)s * 16;
-  for (int k = 0; k < G_MAXV; k++) {
-    vp[k] = (k < n) ? x[k] : 0.0;
-    vp[8 + k] = (k < n) ? y[k] : 0.0;
+  __syncthreads();
+  const long cnt = (long)min(256, ncells - s0) * 16;
+  double *out = c.verts + (size_t)s0 * 16;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const long e = (long)q * 256 + threadIdx.x;
+    if (e < cnt) out[e] = vtile[(e >> 4) * 17 + (e & 15)];
   }
-  c.area[s] = d_poly_area<1>(x, y, n);
 }
 
 // ---------------------------------------------------------------------------------------
