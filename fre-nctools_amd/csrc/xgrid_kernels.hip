@@ -242,31 +242,52 @@ __device__ __forceinline__ void d_cell_box(double lat_min, double lat_max, doubl
 }
 __device__ __forceinline__ int d_colmod(long long l, int nb) { return (int)(((l % nb) + nb) % nb); }
 
+// one atomic per run of consecutive lanes that target the same slot (key >= 0; lanes with key < 0 sit out): returns this
+// lane's position in the slot.  Consecutive cells of a regular grid share a bin (2.25 cells per bin), and same-address
+// atomics that return a value are the expensive part of the fill pass.
+__device__ __forceinline__ int d_slot_position(int *slot_cnt, int key)
+{
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(key, 1);
+  const bool head = (lane == 0) || (key != prev);
+  const unsigned long long heads = __ballot(head);
+  const int start = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));
+  const unsigned long long above = (start == 63) ? 0ull : (heads & ~((2ull << start) - 1ull));
+  const int end = above ? (__ffsll((long long)above) - 1) : 64;
+  int base = 0;
+  if (lane == start && key >= 0) base = atomicAdd(&slot_cnt[key], end - start);
+  base = __shfl(base, start);
+  return base + (lane - start);
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin_build(int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start,
                                                     FgBinEntry *entries, int cap)
 {
-  int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= ncells) return;
-  if (c.nv[d] == 0) return;
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = d < ncells && c.nv[d] != 0;      // (no early return: the slot positions are a wave-wide operation)
   FgBinEntry E;
-  E.lat_min = c.lat_min[d]; E.lat_max = c.lat_max[d];
-  E.lon_min = c.lon_min[d]; E.lon_max = c.lon_max[d]; E.lon_avg = c.lon_avg[d];
-  E.d = d;
-  int r0, r1; long long l0, l1;
-  d_cell_box(E.lat_min, E.lat_max, E.lon_min, E.lon_max, b, &r0, &r1, &l0, &l1);
-  E.row0 = r0;
+  int r0 = 0, r1 = 0; long long l0 = 0, l1 = 0;
+  if (live) {
+    E.lat_min = c.lat_min[d]; E.lat_max = c.lat_max[d];
+    E.lon_min = c.lon_min[d]; E.lon_max = c.lon_max[d]; E.lon_avg = c.lon_avg[d];
+    E.d = d;
+    d_cell_box(E.lat_min, E.lat_max, E.lon_min, E.lon_max, b, &r0, &r1, &l0, &l1);
+    E.row0 = r0;
+  }
   const int nbins = b.nblat * b.nblon;
-  if (r1 - r0 <= 1 && l1 - l0 <= 1) {
-    int slot = r0 * b.nblon + d_colmod(l0, b.nblon);
-    int pos = atomicAdd(&slot_cnt[slot], 1);
-    if (FILL) { const int at = slot_start[slot] + pos; if (at < cap) entries[at] = E; }
-  } else {
+  const bool regular = live && r1 - r0 <= 1 && l1 - l0 <= 1;
+  const int slot = regular ? r0 * b.nblon + d_colmod(l0, b.nblon) : -1;
+  if (FILL) {
+    const int pos = d_slot_position(slot_cnt, slot);
+    if (regular) { const int at = slot_start[slot] + pos; if (at < cap) entries[at] = E; }
+  } else if (regular)
+    atomicAdd(&slot_cnt[slot], 1);
+  if (live && !regular)
     for (int r = r0; r <= r1; r++) {
       int pos = atomicAdd(&slot_cnt[nbins + r], 1);
       if (FILL) { const int at = slot_start[nbins + r] + pos; if (at < cap) entries[at] = E; }
     }
-  }
 }
 
 // ---------------------------------------------------------------------------------------
