@@ -42,6 +42,13 @@ __global__ __launch_bounds__(256) void k_csr_fill(long nx, const int *x_dst, con
   if (d >= 0) perm[row_ptr[d] + base + (lane - start)] = (int)n;
 }
 
+// the same with slots already taken while the search scattered its exchange cells (k_scatter_xcells): no atomics
+__global__ __launch_bounds__(256) void k_csr_fill_pos(long nx, const int *x_dst, const int *row_ptr, const int *x_rowpos, int *perm)
+{
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < nx) perm[row_ptr[x_dst[n]] + x_rowpos[n]] = (int)n;
+}
+
 // Restore ascending exchange-cell order inside each row.  Rows are short when the grids are of similar resolution (~4
 // entries): one thread sorts its row by insertion.  Fine -> coarse remaps have rows of 50-1000 entries (C768 -> 1 deg: 73 on
 // average), where that serial O(n^2) loop in global memory took 2.2 ms; such rows are sorted by the whole wave instead: the
@@ -533,6 +540,10 @@ void fgd_csr_count(long nx, const int *x_dst, int *row_cnt, hipStream_t st)
 void fgd_csr_fill(long nx, const int *x_dst, const int *row_ptr, int *row_fill, int *perm, hipStream_t st)
 {
   if (nx > 0) k_csr_fill<<<nblk(nx, 256), 256, 0, st>>>(nx, x_dst, row_ptr, row_fill, perm);
+}
+void fgd_csr_fill_pos(long nx, const int *x_dst, const int *row_ptr, const int *x_rowpos, int *perm, hipStream_t st)
+{
+  if (nx > 0) k_csr_fill_pos<<<nblk(nx, 256), 256, 0, st>>>(nx, x_dst, row_ptr, x_rowpos, perm);
 }
 void fgd_csr_sort_rows(int ndst, long nx, const int *row_ptr, int *perm, hipStream_t st)
 {

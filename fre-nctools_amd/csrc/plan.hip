@@ -203,6 +203,7 @@ struct fg_plan {
   int *x_src = nullptr, *x_dst = nullptr;
   double *x_area = nullptr, *x_c1 = nullptr, *x_c2 = nullptr;
   int *xoff = nullptr;
+  int *x_rowpos = nullptr;       // slot of every exchange cell in its destination row, taken while scattering
   int *row_cnt = nullptr;        // exchange cells per destination cell, counted while scattering (2*(ndst+1): counts | cursors)
   double *sums = nullptr, *cen = nullptr;
   // sweep
@@ -524,11 +525,12 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   if (order == 2) { pl->x_c1 = pl->alloc<double>(nx_alloc + 1); pl->x_c2 = pl->alloc<double>(nx_alloc + 1); }
   if (!pl->x_src || !pl->x_dst || !pl->x_area || (order == 2 && (!pl->x_c1 || !pl->x_c2))) return fail(FG_ERR_HIP, "out of device memory");
   pl->row_cnt = pl->alloc<int>(2 * ((size_t)ndst + 1));
-  if (!pl->row_cnt) return fail(FG_ERR_HIP, "out of device memory");
+  pl->x_rowpos = pl->alloc<int>(nx_alloc + 1);
+  if (!pl->row_cnt || !pl->x_rowpos) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_COMPACT);
   HIPCHK(hipMemsetAsync(pl->row_cnt, 0, 2 * ((size_t)ndst + 1) * sizeof(int), st));
   fgd_scatter_xcells(order, npairs, pair_src, pair_dst, cand_off, pl->xoff, tmp_area, tmp_clon, tmp_clat,
-                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, pl->row_cnt, np_dev, st);
+                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, pl->row_cnt, pl->x_rowpos, np_dev, st);
   pt.end();
   if (order == 2) {
     pl->sums = pl->alloc<double>(3 * (size_t)nsrc);
@@ -583,7 +585,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
     (void)hipStreamSynchronize(pl->stream);
     while (pl->owned.size() > keep) { void *p = pl->owned.back(); pl->owned.pop_back(); g_pool.put(p); }
     pl->tiles_dev = nullptr; pl->mask_dev = nullptr; pl->S = FgCells{}; pl->D = FgCells{};
-    pl->x_src = pl->x_dst = nullptr; pl->x_area = pl->x_c1 = pl->x_c2 = nullptr; pl->xoff = nullptr; pl->row_cnt = nullptr; pl->sums = nullptr;
+    pl->x_src = pl->x_dst = nullptr; pl->x_area = pl->x_c1 = pl->x_c2 = nullptr; pl->xoff = nullptr; pl->row_cnt = nullptr; pl->x_rowpos = nullptr; pl->sums = nullptr;
     pl->have_geom = false;
   }
   return plan_search_core(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon, gc_in, gc_out, boxm, false);
@@ -877,12 +879,13 @@ static int build_csr(fg_plan *pl)
     fgd_csr_count(nx, pl->x_dst, row_cnt, st);
   }
   fgd_exclusive_scan(row_cnt, ndst, pl->csr.row_ptr, scan_ws, total_dev, st);
-  fgd_csr_fill(nx, pl->x_dst, pl->csr.row_ptr, row_cnt + ndst + 1, perm, st);
+  if (counted && pl->x_rowpos) fgd_csr_fill_pos(nx, pl->x_dst, pl->csr.row_ptr, pl->x_rowpos, perm, st);
+  else fgd_csr_fill(nx, pl->x_dst, pl->csr.row_ptr, row_cnt + ndst + 1, perm, st);
   fgd_csr_sort_rows(ndst, nx, pl->csr.row_ptr, perm, st);
   fgd_csr_gather(pl->order, nx, perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, pl->csr, st);
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
-  pl->release(row_cnt); pl->row_cnt = nullptr; pl->release(perm); pl->release(scan_ws); pl->release(total_dev);
+  pl->release(row_cnt); pl->row_cnt = nullptr; pl->release(pl->x_rowpos); pl->x_rowpos = nullptr; pl->release(perm); pl->release(scan_ws); pl->release(total_dev);
   if (!pl->red_partial) { pl->red_partial = pl->alloc<double>(1024); pl->red_result = pl->alloc<double>(260); }
   if (!pl->red_partial || !pl->red_result) return fail(FG_ERR_HIP, "out of device memory");
   return 0;

@@ -77,7 +77,7 @@ int  fgd_cand_group(void);   // lanes per source cell in the candidate scan: can
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
                         const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                        int *row_cnt, const unsigned long long *np_dev, hipStream_t st);
+                        int *row_cnt, int *x_rowpos, const unsigned long long *np_dev, hipStream_t st);
 void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
                    const double *x_c2, double *sums, hipStream_t st);
 void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st);
@@ -97,6 +97,7 @@ struct FgCsr {
 };
 void fgd_csr_count(long nx, const int *x_dst, int *row_cnt, hipStream_t st);
 void fgd_csr_fill(long nx, const int *x_dst, const int *row_ptr, int *row_fill, int *perm, hipStream_t st);
+void fgd_csr_fill_pos(long nx, const int *x_dst, const int *row_ptr, const int *x_rowpos, int *perm, hipStream_t st);
 void fgd_csr_sort_rows(int ndst, long nx, const int *row_ptr, int *perm, hipStream_t st);
 void fgd_csr_gather(int order, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
                     const double *x_c2, const int *src_idx_f, FgCsr csr, hipStream_t st);

@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
                                                          const int *cand_off, const int *xoff,
                                                          const double *tmp_area, const double *tmp_clon, const double *tmp_clat,
                                                          int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                                                         int *row_cnt, const unsigned long long *np_dev)
+                                                         int *row_cnt, int *x_rowpos, const unsigned long long *np_dev)
 {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (np_dev) { const unsigned long long nd = *np_dev; if (nd < (unsigned long long)npairs) npairs = (int)nd; }
@@ -760,7 +760,9 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
     rank += ((unsigned)pair_dst[o + k] < (unsigned)d) ? 1 : 0;    // rejected entries are 0xffffffff
   int pos = xoff[s] + rank;
   x_src[pos] = s; x_dst[pos] = d; x_area[pos] = tmp_area[p];
-  atomicAdd(&row_cnt[d], 1);                         // destination-row sizes for the CSR build (fg_plan_finalize)
+  // destination-row sizes for the CSR build (fg_plan_finalize), and this cell's slot in its row: the value-returning atomic
+  // costs little here, where it overlaps the gathers, and saves the CSR fill pass its own (k_csr_fill_pos)
+  x_rowpos[pos] = atomicAdd(&row_cnt[d], 1);
   if (ORDER == 2) { x_c1[pos] = tmp_clon[p]; x_c2[pos] = tmp_clat[p]; }
 }
 
@@ -898,11 +900,11 @@ int fgd_cand_group(void) { return CAND_G; }
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
                         const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                        int *row_cnt, const unsigned long long *np_dev, hipStream_t st)
+                        int *row_cnt, int *x_rowpos, const unsigned long long *np_dev, hipStream_t st)
 {
   if (npairs <= 0) return;
-  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, np_dev);
-  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, np_dev);
+  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, x_rowpos, np_dev);
+  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, x_rowpos, np_dev);
 }
 
 void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
