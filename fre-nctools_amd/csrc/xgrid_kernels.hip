@@ -795,9 +795,27 @@ __global__ __launch_bounds__(256) void k_cell_sums(int nsrc, const int *xoff, co
   int o = xoff[s], c = xoff[s + 1] - o;
   if (staged) {
     int q = o - e0;
-    for (int k = 0; k < c; k++) { a += sh[0][q + k]; l += sh[1][q + k]; t += sh[2][q + k]; }
+    int k = 0;
+    for (; k + 8 <= c; k += 8) {                     // reads ahead of the ordered additions, as in the direct loop below
+      double va[8], vl[8], vt[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { va[u] = sh[0][q + k + u]; vl[u] = sh[1][q + k + u]; vt[u] = sh[2][q + k + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { a += va[u]; l += vl[u]; t += vt[u]; }
+    }
+    for (; k < c; k++) { a += sh[0][q + k]; l += sh[1][q + k]; t += sh[2][q + k]; }
   } else {
-    for (int k = 0; k < c; k++) { a += x_area[o + k]; l += x_c1[o + k]; t += x_c2[o + k]; }
+    // ranges that do not fit hold the cells around a pole of the target grid, with hundreds of exchange cells each: their
+    // serial chains set the duration of the whole launch, so the loads go out 16 entries ahead of the (ordered) additions
+    int k = 0;
+    for (; k + 16 <= c; k += 16) {
+      double va[16], vl[16], vt[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) { va[u] = x_area[o + k + u]; vl[u] = x_c1[o + k + u]; vt[u] = x_c2[o + k + u]; }
+#pragma unroll
+      for (int u = 0; u < 16; u++) { a += va[u]; l += vl[u]; t += vt[u]; }
+    }
+    for (; k < c; k++) { a += x_area[o + k]; l += x_c1[o + k]; t += x_c2[o + k]; }
   }
   sums[s] = a; sums[nsrc + s] = l; sums[2 * (size_t)nsrc + s] = t;
 }
