@@ -530,7 +530,8 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pt.begin(PH_COMPACT);
   HIPCHK(hipMemsetAsync(pl->row_cnt, 0, 2 * ((size_t)ndst + 1) * sizeof(int), st));
   fgd_scatter_xcells(order, npairs, pair_src, pair_dst, cand_off, pl->xoff, tmp_area, tmp_clon, tmp_clat,
-                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, pl->row_cnt, pl->x_rowpos, np_dev, st);
+                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, pl->row_cnt, pl->x_rowpos, np_dev, heavy_list, &dc->heavy_cnt,
+                     cand_stage, /* pair_rank: the deferral list is spent by now */ defer_list, st);
   pt.end();
   if (order == 2) {
     pl->sums = pl->alloc<double>(3 * (size_t)nsrc);

@@ -77,7 +77,8 @@ int  fgd_cand_group(void);   // lanes per source cell in the candidate scan: can
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
                         const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                        int *row_cnt, int *x_rowpos, const unsigned long long *np_dev, hipStream_t st);
+                        int *row_cnt, int *x_rowpos, const unsigned long long *np_dev, const int *heavy_list, const int *heavy_cnt,
+                        const int *stage, int *pair_rank, hipStream_t st);
 void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
                    const double *x_c2, double *sums, hipStream_t st);
 void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st);

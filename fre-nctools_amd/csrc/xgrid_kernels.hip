@@ -749,12 +749,72 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
 // ---------------------------------------------------------------------------------------
 // compaction into canonical order
 // ---------------------------------------------------------------------------------------
+// Rank of every accepted pair of a heavy source cell among that cell's accepted pairs, by destination index (the canonical
+// order inside a source cell).  k_scatter_xcells ranks a pair by comparing it with all the others of its cell, which is
+// quadratic: fine for 5 pairs, but a source cell at a pole of the target grid holds thousands (great-circle search: ~3000 in
+// each of ~600 cells, which was 0.4 ms).  Here a block marks the cell's destination indices in an LDS bitmap over their span
+// and reads each rank off as a prefix population count: linear.  rank = -1 where the span does not fit (scatter falls back).
+#define RANK_WORDS 2048      // 131072 destination indices: 91 rows of a 1440-column grid
+__global__ __launch_bounds__(256) void k_rank_heavy(const int *heavy_list, const int *heavy_cnt, const int *cand_off,
+                                                    const int *pair_dst, int *pair_rank, int cap)
+{
+  __shared__ unsigned long long bits[RANK_WORDS];
+  __shared__ int pref[RANK_WORDS];
+  __shared__ int smin, smax;
+  const int nheavy = *heavy_cnt;
+  for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    const int s = heavy_list[h];
+    const int o = cand_off[s * CAND_G];
+    int c = cand_off[(s + 1) * CAND_G] - o;
+    if (o + c > cap) c = max(0, cap - o);                 // (an overflowing fast search is repeated anyway)
+    if (threadIdx.x == 0) { smin = 0x7fffffff; smax = -1; }
+    __syncthreads();
+    int lmin = 0x7fffffff, lmax = -1;
+    for (int k = threadIdx.x; k < c; k += 256) { const int d = pair_dst[o + k]; if (d >= 0) { lmin = min(lmin, d); lmax = max(lmax, d); } }
+    if (lmax >= 0) { atomicMin(&smin, lmin); atomicMax(&smax, lmax); }
+    __syncthreads();
+    const int dmin = smin, dmax = smax;
+    const long span = (long)dmax - dmin + 1;
+    if (dmax < 0 || span > (long)RANK_WORDS * 64) {
+      for (int k = threadIdx.x; k < c; k += 256) pair_rank[o + k] = -1;
+      __syncthreads();
+      continue;
+    }
+    const int nw = (int)((span + 63) >> 6);
+    for (int w = threadIdx.x; w < nw; w += 256) bits[w] = 0ull;
+    __syncthreads();
+    for (int k = threadIdx.x; k < c; k += 256) {
+      const int d = pair_dst[o + k];
+      if (d >= 0) atomicOr(&bits[(d - dmin) >> 6], 1ull << ((d - dmin) & 63));
+    }
+    __syncthreads();
+    // exclusive prefix of the word populations: each thread owns a contiguous chunk of words
+    const int per = (nw + 255) / 256, w0 = threadIdx.x * per, w1 = min(nw, w0 + per);
+    int mine = 0;
+    for (int w = w0; w < w1; w++) mine += __popcll(bits[w]);
+    unsigned tot;
+    const int before = (int)block_incl_scan((unsigned)mine, &tot) - mine;
+    int run = before;
+    for (int w = w0; w < w1; w++) { pref[w] = run; run += __popcll(bits[w]); }
+    __syncthreads();
+    for (int k = threadIdx.x; k < c; k += 256) {
+      const int d = pair_dst[o + k];
+      if (d >= 0) {
+        const int w = (d - dmin) >> 6, b = (d - dmin) & 63;
+        pair_rank[o + k] = pref[w] + __popcll(bits[w] & ((1ull << b) - 1ull));
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *pair_src, const int *pair_dst,
                                                          const int *cand_off, const int *xoff,
                                                          const double *tmp_area, const double *tmp_clon, const double *tmp_clat,
                                                          int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                                                         int *row_cnt, int *x_rowpos, const unsigned long long *np_dev)
+                                                         int *row_cnt, int *x_rowpos, const unsigned long long *np_dev,
+                                                         const int4 *stage, const int *pair_rank)
 {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (np_dev) { const unsigned long long nd = *np_dev; if (nd < (unsigned long long)npairs) npairs = (int)nd; }
@@ -762,9 +822,13 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
   const int d = pair_dst[p];                        // -1: rejected by the clip kernels
   if (d < 0) return;
   const int s = pair_src[p];
-  int o = cand_off[s * CAND_G], c = cand_off[(s + 1) * CAND_G] - o, rank = 0;
-  for (int k = 0; k < c; k++)                       // destination index ascending == the reference's ij loop
-    rank += ((unsigned)pair_dst[o + k] < (unsigned)d) ? 1 : 0;    // rejected entries are 0xffffffff
+  int rank = (stage[(size_t)s * CAND_G].x == -2) ? pair_rank[p] : -1;    // heavy cells: ranked by k_rank_heavy
+  if (rank < 0) {
+    int o = cand_off[s * CAND_G], c = cand_off[(s + 1) * CAND_G] - o;
+    rank = 0;
+    for (int k = 0; k < c; k++)                       // destination index ascending == the reference's ij loop
+      rank += ((unsigned)pair_dst[o + k] < (unsigned)d) ? 1 : 0;    // rejected entries are 0xffffffff
+  }
   int pos = xoff[s] + rank;
   x_src[pos] = s; x_dst[pos] = d; x_area[pos] = tmp_area[p];
   // destination-row sizes for the CSR build (fg_plan_finalize), and this cell's slot in its row: the value-returning atomic
@@ -925,11 +989,13 @@ int fgd_cand_group(void) { return CAND_G; }
 void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
                         const int *xoff, const double *tmp_area, const double *tmp_clon,
                         const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                        int *row_cnt, int *x_rowpos, const unsigned long long *np_dev, hipStream_t st)
+                        int *row_cnt, int *x_rowpos, const unsigned long long *np_dev, const int *heavy_list, const int *heavy_cnt,
+                        const int *stage, int *pair_rank, hipStream_t st)
 {
   if (npairs <= 0) return;
-  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, x_rowpos, np_dev);
-  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, x_rowpos, np_dev);
+  k_rank_heavy<<<1024, 256, 0, st>>>(heavy_list, heavy_cnt, cand_off, pair_dst, pair_rank, npairs);
+  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, x_rowpos, np_dev, (const int4 *)stage, pair_rank);
+  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, x_rowpos, np_dev, (const int4 *)stage, pair_rank);
 }
 
 void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
