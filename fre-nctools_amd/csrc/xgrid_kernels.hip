@@ -343,7 +343,9 @@ __device__ __forceinline__ bool d_box_pass(const FgBinEntry &E, double lat_in_mi
   return true;
 }
 
-#define HEAVY_ENTRIES 64      // scanned bins + wide entries above which a source cell gets a whole wave
+#define HEAVY_ENTRIES 32      // scanned bins + wide entries above which a source cell gets a whole wave (measured: 16 / 24 / 32 / 64 / 128
+                              // give 0.31 / 0.27 / 0.28 / 0.305 / 0.38 ms for the candidate phase at C384 -> 0.25 deg; the lanes with the
+                              // longest scans set the duration of the four-lanes-per-cell kernel)
 #define CAND_G 4          // lanes per source cell in the candidate scan (one bin row each)
 
 // CAND_G lanes per source cell, each scanning every CAND_G-th bin row of the cell's query.  Counts and
