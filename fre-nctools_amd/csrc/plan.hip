@@ -449,12 +449,13 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   FgBinEntry *bin_entries = pl->alloc<FgBinEntry>(nentries ? nentries : 1);
   if (!bin_entries) return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_BINS);
-  fgd_bin_build(true, ndst, pl->D, bins, bin_fill, bin_start, bin_entries, (int)std::min<unsigned long long>(nentries, 2147483647ull), st);
+  const int ecap = (int)std::min<unsigned long long>(nentries, 2147483647ull);     // records the buffer holds: writes and reads stop there
+  fgd_bin_build(true, ndst, pl->D, bins, bin_fill, bin_start, bin_entries, ecap, st);
   pt.end();
 
   // --- candidate pairs
   pt.begin(PH_CANDIDATES);
-  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, &dc->heavy_cnt, 0, cand_stage, st);
+  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, &dc->heavy_cnt, 0, cand_stage, ecap, st);
   fgd_exclusive_scan(cand_cnt, ncand, cand_off, scan_ws, &dc->total[1], st);
   pt.end();
   unsigned long long npairs64 = cap_pairs;
@@ -474,7 +475,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   if (!pair_src || !pair_dst || !tmp_area || !defer_list || (order == 2 && (!tmp_clon || !tmp_clat)))
     return fail(FG_ERR_HIP, "out of device memory");
   pt.begin(PH_CANDIDATES);
-  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, &dc->heavy_cnt, npairs, cand_stage, st);
+  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, &dc->heavy_cnt, npairs, cand_stage, ecap, st);
   pt.end();
 
   // --- clip, area, centroid integrals (+ accepted count per source cell)

@@ -66,7 +66,7 @@ void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, co
                    hipStream_t st);
 void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start,
                     const FgBinEntry *entries, int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                    int *heavy_list, int *heavy_cnt, int cap, int *stage, hipStream_t st);
+                    int *heavy_list, int *heavy_cnt, int cap, int *stage, int ecap, hipStream_t st);
 void fgd_clip_general(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);

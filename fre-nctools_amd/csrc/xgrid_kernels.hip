@@ -348,7 +348,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const double *mask, FgBins b,
                                                      const int *slot_start, const FgBinEntry *entries,
                                                      int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                                                     int *heavy_list, int *heavy_cnt, int cap, int4 *stage)
+                                                     int *heavy_list, int *heavy_cnt, int cap, int4 *stage, int ecap)
 {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int s = (int)(t / CAND_G), sub = (int)(t % CAND_G);
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
         if (seg && !q.n1) break;
         int e0 = seg ? slot_start[base] : slot_start[base + q.c_start];
         int e1 = seg ? slot_start[base + q.n1] : slot_start[base + q.c_start + q.n0];
+        e1 = min(e1, ecap);                              // a single-sync search may have outgrown its record buffer (it is then repeated)
         for (int e = e0; e < e1; e++) {
           const FgBinEntry E = entries[e];
           if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
       }
     }
     for (int r = q.r0 + sub; r <= q.r1; r += CAND_G) {
-      int e0 = slot_start[nbins + r], e1 = slot_start[nbins + r + 1];
+      int e0 = slot_start[nbins + r], e1 = min(slot_start[nbins + r + 1], ecap);
       for (int e = e0; e < e1; e++) {
         const FgBinEntry E = entries[e];
         if (r != max(q.r0, E.row0)) continue;          // a wide cell sits in every row it spans
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) void k_candidates(int nsrc, FgCells S, const d
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_candidates_heavy(FgCells S, FgBins b, const int *slot_start, const FgBinEntry *entries,
                                                           int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                                                          const int *heavy_list, const int *heavy_cnt, int cap)
+                                                          const int *heavy_list, const int *heavy_cnt, int cap, int ecap)
 {
   const int lane = threadIdx.x;
   const int nheavy = *heavy_cnt;
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(64) void k_candidates_heavy(FgCells S, FgBins b, co
         wide_row = q.r0 + (it - 2 * nrows_reg);
         e0 = slot_start[nbins + wide_row]; e1 = slot_start[nbins + wide_row + 1];
       }
+      e1 = min(e1, ecap);
       for (int eb = e0; eb < e1; eb += 64) {
         int e = eb + lane;
         bool pass = false;
@@ -803,6 +805,7 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
                                                          const int4 *stage, const int *pair_rank)
 {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cap = npairs;                           // entries the pair arrays hold
   if (np_dev) { const unsigned long long nd = *np_dev; if (nd < (unsigned long long)npairs) npairs = (int)nd; }
   if (p >= npairs) return;
   const int d = pair_dst[p];                        // -1: rejected by the clip kernels
@@ -811,6 +814,7 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
   int rank = (stage[(size_t)s * CAND_G].x == -2) ? pair_rank[p] : -1;    // heavy cells: ranked by k_rank_heavy
   if (rank < 0) {
     int o = cand_off[s * CAND_G], c = cand_off[(s + 1) * CAND_G] - o;
+    if (o + c > cap) c = cap - o;                     // a single-sync search that outgrew its buffers is repeated; stay inside them
     rank = 0;
     for (int k = 0; k < c; k++)                       // destination index ascending == the reference's ij loop
       rank += ((unsigned)pair_dst[o + k] < (unsigned)d) ? 1 : 0;    // rejected entries are 0xffffffff
@@ -934,16 +938,16 @@ void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, co
 
 void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start,
                     const FgBinEntry *entries, int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                    int *heavy_list, int *heavy_cnt, int cap, int *stage, hipStream_t st)
+                    int *heavy_list, int *heavy_cnt, int cap, int *stage, int ecap, hipStream_t st)
 {
   if (nsrc <= 0) return;
   int hgrid = nblk(nsrc, 64); if (hgrid > 2048) hgrid = 2048;
   if (fill) {
-    k_candidates<true><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, (int4 *)stage);
-    k_candidates_heavy<true><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap);
+    k_candidates<true><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, (int4 *)stage, ecap);
+    k_candidates_heavy<true><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, ecap);
   } else {
-    k_candidates<false><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, (int4 *)stage);
-    k_candidates_heavy<false><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap);
+    k_candidates<false><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, (int4 *)stage, ecap);
+    k_candidates_heavy<false><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, ecap);
   }
 }
 
