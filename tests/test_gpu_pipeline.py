@@ -373,8 +373,8 @@ def test_fast_search_overflow_falls_back_to_exact_mode(fg, gpu_ok):
 
 
 def test_bin_record_overflow_falls_back_to_exact_mode(fg, gpu_ok):
-    """Bins no larger than the target cells (the caller's mean cell size is an input): every target cell then spans three bin
-    rows, lands in the per-row wide lists three times and the single-sync search's record buffer (2 per target cell) is too
+    """Bins no larger than the target cells (the caller's mean cell size is an input): every target cell then spans four bin
+    rows, lands in the per-row wide lists four times and the single-sync search's record buffer (3 per target cell) is too
     small -- the kernels must stay inside it and the search must be repeated with exact sizes, giving the oracle's list."""
     import torch
     ni, nlon, nlat = 16, 96, 48
@@ -385,11 +385,11 @@ def test_bin_record_overflow_falls_back_to_exact_mode(fg, gpu_ok):
     lat_t = [torch.from_numpy(lat[t]).to(dev) for t in range(6)]
     lo_t, la_t = torch.from_numpy(lo).to(dev), torch.from_numpy(la).to(dev)
     torch.cuda.synchronize()
-    # choose_bins makes bins 1.5 x the mean cell: pass means that make them exactly one target cell
+    # choose_bins makes bins 1.25 x the mean cell: pass means that make them exactly one target cell
     plan = fg.XgridPlan.create_dev(1, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, nlat, lo_t, la_t,
-                                   (np.pi / nlat) / 1.5, (2 * np.pi / nlon) / 1.5)
+                                   (np.pi / nlat) / 2.5, (2 * np.pi / nlon) / 1.25)
     st = plan.stats()
-    assert st["exact_mode"] == 1 and st["bin_entries"] > 2 * nlon * nlat + 4096
+    assert st["exact_mode"] == 1 and st["bin_entries"] > 3 * nlon * nlat + 4096
     x = plan.get_xgrid()
     plan.destroy()
     o = orc.orc_setup(1, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
