@@ -28,8 +28,8 @@
  *       tools/fregrid_gpu/Makefile.am:28-41).
  *
  *  (F)  the callers either side of the path: fg_c2l_* (halo update + grad_c2l on the device,
- *       fregrid_util.c:2168-2216, gradient_c2l.c:58-118), fg_remap_* (fregrid's remap file without libnetcdf,
- *       conserve_interp.c:368-445 / :62-126).
+ *       fregrid_util.c:2168-2216, gradient_c2l.c:58-118; fg_c2l_records + fg_plan_apply_records fuse them with the
+ *       order-2 sweep), fg_remap_* (fregrid's remap file without libnetcdf, conserve_interp.c:368-445 / :62-126).
  *
  *  (G)  host grid generators used to synthesise inputs without make_hgrid files.
  *
