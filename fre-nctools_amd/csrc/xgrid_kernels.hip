@@ -743,6 +743,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
 // each of ~600 cells, which was 0.4 ms).  Here a block marks the cell's destination indices in an LDS bitmap over their span
 // and reads each rank off as a prefix population count: linear.  rank = -1 where the span does not fit (scatter falls back).
 #define RANK_WORDS 2048      // 131072 destination indices: 91 rows of a 1440-column grid
+#define RANK_MIN 64          // pairs of a heavy-list cell from which the bitmap pays (the list also holds cells with few pairs)
 __global__ __launch_bounds__(256) void k_rank_heavy(const int *heavy_list, const int *heavy_cnt, const int *cand_off,
                                                     const int *pair_dst, int *pair_rank, int cap)
 {
@@ -755,6 +756,7 @@ __global__ __launch_bounds__(256) void k_rank_heavy(const int *heavy_list, const
     const int o = cand_off[s * CAND_G];
     int c = cand_off[(s + 1) * CAND_G] - o;
     if (o + c > cap) c = max(0, cap - o);                 // (an overflowing fast search is repeated anyway)
+    if (c <= RANK_MIN) continue;                          // short lists are ranked in place by k_scatter_xcells (block-uniform)
     if (threadIdx.x == 0) { smin = 0x7fffffff; smax = -1; }
     __syncthreads();
     int lmin = 0x7fffffff, lmax = -1;
@@ -811,10 +813,10 @@ __global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *p
   const int d = pair_dst[p];                        // -1: rejected by the clip kernels
   if (d < 0) return;
   const int s = pair_src[p];
-  int rank = (stage[(size_t)s * CAND_G].x == -2) ? pair_rank[p] : -1;    // heavy cells: ranked by k_rank_heavy
+  int o = cand_off[s * CAND_G], c = cand_off[(s + 1) * CAND_G] - o;
+  if (o + c > cap) c = cap - o;                       // a single-sync search that outgrew its buffers is repeated; stay inside them
+  int rank = (c > RANK_MIN && stage[(size_t)s * CAND_G].x == -2) ? pair_rank[p] : -1;    // long lists: ranked by k_rank_heavy
   if (rank < 0) {
-    int o = cand_off[s * CAND_G], c = cand_off[(s + 1) * CAND_G] - o;
-    if (o + c > cap) c = cap - o;                     // a single-sync search that outgrew its buffers is repeated; stay inside them
     rank = 0;
     for (int k = 0; k < c; k++)                       // destination index ascending == the reference's ij loop
       rank += ((unsigned)pair_dst[o + k] < (unsigned)d) ? 1 : 0;    // rejected entries are 0xffffffff
@@ -941,7 +943,7 @@ void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b
                     int *heavy_list, int *heavy_cnt, int cap, int *stage, int ecap, hipStream_t st)
 {
   if (nsrc <= 0) return;
-  int hgrid = nblk(nsrc, 64); if (hgrid > 2048) hgrid = 2048;
+  int hgrid = nblk(nsrc, 64); if (hgrid > 8192) hgrid = 8192;
   if (fill) {
     k_candidates<true><<<nblk((long)nsrc * CAND_G, 256), 256, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, (int4 *)stage, ecap);
     k_candidates_heavy<true><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, ecap);
