@@ -245,7 +245,7 @@ class XgridPlan:
         names = ["pairs", "nonempty", "nxgrid", "borderline", "bins", "bin_entries", "deferred", "heavy", "below", "exact_mode"]
         return dict(zip(names, [int(v) for v in s]))
 
-    PHASES = ["cell_struct", "bins", "candidates", "clip_quad", "clip_general", "compact", "cell_sums",
+    PHASES = ["cell_struct", "bins", "candidates", "clip_quad", "clip_general", "compact", "rows",
               "search_total", "finalize", "apply"]
 
     def phase_ms(self):

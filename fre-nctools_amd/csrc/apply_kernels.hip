@@ -42,78 +42,114 @@ __global__ __launch_bounds__(256) void k_csr_fill(long nx, const int *x_dst, con
   if (d >= 0) perm[row_ptr[d] + base + (lane - start)] = (int)n;
 }
 
-// the same with slots already taken while the search scattered its exchange cells (k_scatter_xcells): no atomics
-__global__ __launch_bounds__(256) void k_csr_fill_pos(long nx, const int *x_dst, const int *row_ptr, const int *x_rowpos, int *perm)
+// the same with slots already taken while the search compacted its exchange cells (k_compact): no atomics.  Launched for
+// the capacity of the exchange-cell arrays when the host does not know the count yet (nx_dev)
+__global__ __launch_bounds__(256) void k_csr_fill_pos(long nx, const unsigned long long *nx_dev, const int *x_dst, const int *row_ptr,
+                                                       const int *x_rowpos, int *perm)
 {
+  if (nx_dev) { const unsigned long long nd = *nx_dev; if (nd < (unsigned long long)nx) nx = (long)nd; }
   const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (n < nx) perm[row_ptr[x_dst[n]] + x_rowpos[n]] = (int)n;
 }
 
-// Restore ascending exchange-cell order inside each row.  Rows are short when the grids are of similar resolution (~4
-// entries): one thread sorts its row by insertion.  Fine -> coarse remaps have rows of 50-1000 entries (C768 -> 1 deg: 73 on
-// average), where that serial O(n^2) loop in global memory took 2.2 ms; such rows are sorted by the whole wave instead: the
-// row is staged in LDS and every lane places its elements at their rank (the exchange-cell numbers are distinct).
-// RPW = rows per wave: 64 when rows are short (every lane sorts its own), 16 when the mean row is long, so that four times
-// as many waves are in flight to hide the global-memory round trips of the row-by-row part.
-template <int RPW>
-__global__ __launch_bounds__(64) void k_csr_sort_rows(int ndst, const int *row_ptr, int *perm)
+// Rows of `perm` into ascending exchange-cell order, then the packed CSR records -- one kernel.  A block owns RPW consecutive
+// rows, i.e. one contiguous run of perm: it is staged in LDS, every lane sorts its own row there by insertion (rows are short
+// when the grids are of similar resolution, ~4 entries); rows longer than SHORT (fine -> coarse remaps: 50-1000 entries) are
+// sorted by the whole wave, every lane placing its elements at their rank (the exchange-cell numbers are distinct).  The
+// records then leave in one coalesced sweep over the run.  RPW = 64 when rows are short, 16 when the mean row is long, so that
+// four times as many waves are in flight.  Runs beyond the staging capacity are sorted in place in global memory.
+// DIST (order 2): x_c1/x_c2 still hold the centroid integrals; di = clon/area - cen_lon, dj = clat/area - cen_lat
+// (conserve_interp.c:256-257,355-356) are formed here, the operations k_distances applies to the arrays themselves.
+template <int ORDER, int RPW, bool DIST>
+__global__ __launch_bounds__(64) void k_csr_sortgather(int ndst, int *perm, const int *x_src, const double *x_area, const double *x_c1,
+                                                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr)
 {
-  constexpr int SHORT = 12, CAP = 2048, BT = 64;
-  __shared__ int sh[CAP];
+  constexpr int SHORT = 12, CAP = (RPW >= 64) ? 1024 : 2048, BT = 64;     // 8 KB of LDS per wave in the short-row case: 20 waves per CU
+  __shared__ int sh[CAP], sh2[CAP];
   __shared__ int long_b[RPW], long_n[RPW];
   __shared__ int nlong;
   if (threadIdx.x == 0) nlong = 0;
   __syncthreads();
-  const int d = blockIdx.x * RPW + threadIdx.x;
+  const int d0 = blockIdx.x * RPW, d1 = min(d0 + RPW, ndst);
+  const int q0 = csr.row_ptr[d0], q1 = csr.row_ptr[d1], nq = q1 - q0;
+  const bool staged = nq <= CAP;
+  const int d = d0 + threadIdx.x;
   int b = 0, e = 0;
-  if ((int)threadIdx.x < RPW && d < ndst) { b = row_ptr[d]; e = row_ptr[d + 1]; }
-  if (e - b > SHORT) { const int q = atomicAdd(&nlong, 1); long_b[q] = b; long_n[q] = e - b; }
-  else
-    for (int i = b + 1; i < e; i++) {
-      int v = perm[i], j = i - 1;
-      while (j >= b && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
-      perm[j + 1] = v;
-    }
-  __syncthreads();
-  const int nl = nlong;
-  for (int q = 0; q < nl; q++) {
-    const int rb = long_b[q], n = long_n[q];
-    if (n <= CAP) {
-      for (int i = threadIdx.x; i < n; i += BT) sh[i] = perm[rb + i];
-      __syncthreads();
+  if ((int)threadIdx.x < RPW && d < ndst) { b = csr.row_ptr[d]; e = csr.row_ptr[d + 1]; }
+  if (staged) {
+    for (int i = threadIdx.x; i < nq; i += BT) sh[i] = perm[q0 + i];
+    __syncthreads();
+    if (e - b > SHORT) { const int q = atomicAdd(&nlong, 1); long_b[q] = b - q0; long_n[q] = e - b; }
+    else
+      for (int i = b - q0 + 1; i < e - q0; i++) {
+        int v = sh[i], j = i - 1;
+        while (j >= b - q0 && sh[j] > v) { sh[j + 1] = sh[j]; j--; }
+        sh[j + 1] = v;
+      }
+    __syncthreads();
+    const int nl = nlong;
+    for (int q = 0; q < nl; q++) {
+      const int rb = long_b[q], n = long_n[q];
       for (int i = threadIdx.x; i < n; i += BT) {
-        const int v = sh[i];
+        const int v = sh[rb + i];
         int rank = 0;
-        for (int j = 0; j < n; j++) rank += (sh[j] < v) ? 1 : 0;
-        perm[rb + rank] = v;
+        for (int j = 0; j < n; j++) rank += (sh[rb + j] < v) ? 1 : 0;
+        sh2[rb + rank] = v;
       }
       __syncthreads();
-    } else if (threadIdx.x == 0) {                       // beyond the staging capacity: serial, as before
-      for (int i = rb + 1; i < rb + n; i++) {
+      for (int i = threadIdx.x; i < n; i += BT) sh[rb + i] = sh2[rb + i];
+      __syncthreads();
+    }
+  } else {
+    // beyond the staging capacity: per row in global memory (lane-serial insertion, or the wave through LDS for long rows)
+    if (e - b > SHORT) { const int q = atomicAdd(&nlong, 1); long_b[q] = b; long_n[q] = e - b; }
+    else
+      for (int i = b + 1; i < e; i++) {
         int v = perm[i], j = i - 1;
-        while (j >= rb && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
+        while (j >= b && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
         perm[j + 1] = v;
       }
+    __syncthreads();
+    const int nl = nlong;
+    for (int q = 0; q < nl; q++) {
+      const int rb = long_b[q], n = long_n[q];
+      if (n <= CAP) {
+        for (int i = threadIdx.x; i < n; i += BT) sh[i] = perm[rb + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += BT) {
+          const int v = sh[i];
+          int rank = 0;
+          for (int j = 0; j < n; j++) rank += (sh[j] < v) ? 1 : 0;
+          perm[rb + rank] = v;
+        }
+        __syncthreads();
+      } else if (threadIdx.x == 0) {                       // serial, as a last resort
+        for (int i = rb + 1; i < rb + n; i++) {
+          int v = perm[i], j = i - 1;
+          while (j >= rb && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
+          perm[j + 1] = v;
+        }
+      }
     }
+    __syncthreads();
   }
-}
-
-template <int ORDER>
-__global__ __launch_bounds__(256) void k_csr_gather(long nx, const int *perm, const int *x_src, const double *x_area,
-                                                     const double *x_c1, const double *x_c2, const int *src_idx_f, FgCsr csr)
-{
-  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nx) return;
-  int n = perm[e];
-  int s = x_src[n];
-  if (ORDER == 2) {
-    FgCsrEntry2 E;
-    E.idx_f = src_idx_f[s]; E.idx_g = s; E.area = x_area[n]; E.di = x_c1[n]; E.dj = x_c2[n];
-    csr.e2[e] = E;
-  } else {
-    FgCsrEntry1 E;
-    E.idx_f = src_idx_f[s]; E.pad = 0; E.area = x_area[n];
-    csr.e1[e] = E;
+  for (int i = threadIdx.x; i < nq; i += BT) {
+    const int n = staged ? sh[i] : perm[q0 + i];
+    const int s = x_src[n];
+    if (ORDER == 2) {
+      FgCsrEntry2 E;
+      E.idx_f = src_idx_f[s]; E.idx_g = s; E.area = x_area[n];
+      if (DIST) {
+        double di = x_c1[n] / E.area, dj = x_c2[n] / E.area;
+        di -= cen[s]; dj -= cen[nsrc + s];
+        E.di = di; E.dj = dj;
+      } else { E.di = x_c1[n]; E.dj = x_c2[n]; }
+      csr.e2[q0 + i] = E;
+    } else {
+      FgCsrEntry1 E;
+      E.idx_f = src_idx_f[s]; E.pad = 0; E.area = x_area[n];
+      csr.e1[q0 + i] = E;
+    }
   }
 }
 
@@ -541,22 +577,23 @@ void fgd_csr_fill(long nx, const int *x_dst, const int *row_ptr, int *row_fill, 
 {
   if (nx > 0) k_csr_fill<<<nblk(nx, 256), 256, 0, st>>>(nx, x_dst, row_ptr, row_fill, perm);
 }
-void fgd_csr_fill_pos(long nx, const int *x_dst, const int *row_ptr, const int *x_rowpos, int *perm, hipStream_t st)
+void fgd_csr_fill_pos(long nx_cap, const unsigned long long *nx_dev, const int *x_dst, const int *row_ptr, const int *x_rowpos, int *perm,
+                      hipStream_t st)
 {
-  if (nx > 0) k_csr_fill_pos<<<nblk(nx, 256), 256, 0, st>>>(nx, x_dst, row_ptr, x_rowpos, perm);
+  if (nx_cap > 0) k_csr_fill_pos<<<nblk(nx_cap, 256), 256, 0, st>>>(nx_cap, nx_dev, x_dst, row_ptr, x_rowpos, perm);
 }
-void fgd_csr_sort_rows(int ndst, long nx, const int *row_ptr, int *perm, hipStream_t st)
+void fgd_csr_sortgather(int order, int ndst, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
+                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr, hipStream_t st)
 {
   if (ndst <= 0) return;
-  if (nx > 8 * (long)ndst) k_csr_sort_rows<16><<<nblk(ndst, 16), 64, 0, st>>>(ndst, row_ptr, perm);
-  else                     k_csr_sort_rows<64><<<nblk(ndst, 64), 64, 0, st>>>(ndst, row_ptr, perm);
-}
-void fgd_csr_gather(int order, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
-                    const double *x_c2, const int *src_idx_f, FgCsr csr, hipStream_t st)
-{
-  if (nx <= 0) return;
-  if (order == 2) k_csr_gather<2><<<nblk(nx, 256), 256, 0, st>>>(nx, perm, x_src, x_area, x_c1, x_c2, src_idx_f, csr);
-  else            k_csr_gather<1><<<nblk(nx, 256), 256, 0, st>>>(nx, perm, x_src, x_area, x_c1, x_c2, src_idx_f, csr);
+  int *pm = const_cast<int *>(perm);                       // sorted in place only for runs beyond the LDS staging capacity
+  const bool longrows = nx > 8 * (long)ndst;
+#define SG(O_, R_, D_) k_csr_sortgather<O_, R_, D_><<<nblk(ndst, R_), 64, 0, st>>>(ndst, pm, x_src, x_area, x_c1, x_c2, src_idx_f, cen, nsrc, csr)
+  if (order == 2) {
+    if (cen) { if (longrows) SG(2, 16, true); else SG(2, 64, true); }
+    else     { if (longrows) SG(2, 16, false); else SG(2, 64, false); }
+  } else     { if (longrows) SG(1, 16, false); else SG(1, 64, false); }
+#undef SG
 }
 void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsrc, int *src_idx_f, hipStream_t st)
 {

@@ -102,7 +102,7 @@ extern "C" void fg_pool_release(void) { g_pool.release_all(); }
 // PyTorch's current stream).
 static int g_profiling = 0;
 extern "C" void fg_set_profiling(int on) { g_profiling = on ? 1 : 0; }
-enum { PH_CELL_STRUCT = 0, PH_BINS, PH_CANDIDATES, PH_CLIP_QUAD, PH_CLIP_GENERAL, PH_COMPACT, PH_CELL_SUMS,
+enum { PH_CELL_STRUCT = 0, PH_BINS, PH_CANDIDATES, PH_CLIP_QUAD, PH_CLIP_GENERAL, PH_COMPACT, PH_ROWS,
        PH_SEARCH_TOTAL, PH_FINALIZE, PH_APPLY, PH_COUNT };
 // Streams and events are cached per process: creating and destroying a stream costs ~0.1 ms each on this runtime, which
 // was a quarter of a millisecond per plan (scripts/host_time.py).
@@ -203,8 +203,10 @@ struct fg_plan {
   int *x_src = nullptr, *x_dst = nullptr;
   double *x_area = nullptr, *x_c1 = nullptr, *x_c2 = nullptr;
   int *xoff = nullptr;
-  int *x_rowpos = nullptr;       // slot of every exchange cell in its destination row, taken while scattering
-  int *row_cnt = nullptr;        // exchange cells per destination cell, counted while scattering (2*(ndst+1): counts | cursors)
+  int *x_rowpos = nullptr;       // slot of every exchange cell in its destination row, taken while compacting (search scratch)
+  int *perm = nullptr;           // exchange cells grouped by destination row (unsorted inside a row) until fg_plan_finalize
+  bool rows_built = false;       // csr.row_ptr and perm come from the search
+  bool dist_pending = false;     // order 2: x_c1/x_c2 still hold the centroid integrals after finalize (fg_plan_get_xgrid applies di/dj)
   double *sums = nullptr, *cen = nullptr;
   // sweep
   FgCsr csr{};
@@ -298,19 +300,12 @@ static void choose_bins(const fg_plan *pl, double mean_dlat, double mean_dlon, F
   b->inv_wlon = nblon / (2.0 * PI);
 }
 
-// Device-side counters of one search: one block, zeroed by one memset, read back with one copy into
-// pinned host memory at each of the three points where the host needs a count to size buffers.
-struct DevCounters {
-  unsigned long long total[4];     // [0] bin-table entries  [1] candidate pairs  [2] nxgrid
-  unsigned err[4];
-  int defer_cnt, heavy_cnt, pad0, pad1;
-  unsigned long long stats[FG_NSTATS];
-};
-
-static DevCounters *pinned_counters()
+// Device-side counters of one search (FgCounters, xgrid_device.h): one block, zeroed by the search's one memset, read back with
+// one copy into pinned host memory when the search has been queued.
+static FgCounters *pinned_counters()
 {
-  static thread_local DevCounters *h = nullptr;
-  if (!h) { if (hipHostMalloc((void **)&h, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) h = nullptr; }
+  static thread_local FgCounters *h = nullptr;
+  if (!h) { if (hipHostMalloc((void **)&h, sizeof(FgCounters), hipHostMallocDefault) != hipSuccess) h = nullptr; }
   return h;
 }
 
@@ -334,32 +329,39 @@ static const char *gc_clip_error(int code)
   }
 }
 
-#define FG_RETRY_EXACT (-1000L)
+// Capacities of one attempt: bin-table records and entries per region of the pair list.  The default capacities (bin records
+// 3*ndst, pairs 8*max(nsrc, ndst)) fit every remap between grids of comparable resolution; every kernel clamps its writes
+// AND reads to them, the counters keep counting, and an attempt that outgrew one is repeated with the counted sizes.
+struct SearchCaps { unsigned long long entries; int regcap; };
+#define FG_RETRY (-1000L)
 static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
                         double mean_dlat, double mean_dlon, const GcXyz *gc_in, const GcXyz *gc_out,
-                        const BoxMode *boxm, bool fast)
+                        const BoxMode *boxm, SearchCaps *caps)
 {
-  // fast: buffers are sized by capacity (bin entries 3*ndst, candidate pairs / exchange cells 8*max(nsrc, ndst)), the
-  // kernels read the true counts from device memory, and the host synchronises ONCE, at the end.  If a capacity turns
-  // out too small the caller repeats the search in exact mode (three readbacks that size every buffer exactly).
+  // Queue order (legacy search, 11 launches + 1 readback; the host synchronises ONCE, at the end):
+  //   memset | cell records + bin counts | bin scan | bin fill + heavy list | candidates | quad clip | general clip |
+  //   compaction (+ big cells) | row scan | row slots -> perm | counters -> host
   const bool gc = gc_in != nullptr;
   pl->great_circle = gc;
   hipStream_t st = pl->stream;
   const int nsrc = pl->nsrc, ndst = pl->ndst, order = pl->order;
-  DevCounters *hc = pinned_counters();
+  FgCounters *hc = pinned_counters();
   if (!hc) return fail(FG_ERR_HIP, "hipHostMalloc failed");
 
   // tile descriptors: source tiles + the destination tile as entry [ntiles]
-  std::vector<FgTile> &th = pl->tiles_host;  // owned by the plan: the upload below needs no sync
+  std::vector<FgTile> &th = pl->tiles_host;  // owned by the plan: an async upload needs no sync
   th.resize(pl->ntiles + 1);
   for (int m = 0; m < pl->ntiles; m++) th[m] = FgTile{gc ? nullptr : d_lon_in[m], gc ? nullptr : d_lat_in[m], pl->nx_in[m], pl->ny_in[m], pl->cell_off[m]};
   th[pl->ntiles] = FgTile{d_lon_out, d_lat_out, pl->nx_out, pl->ny_out, 0};
   pl->tiles_dev = pl->alloc<FgTile>(pl->ntiles + 1);
   if (!pl->tiles_dev) return fail(FG_ERR_HIP, "out of device memory");
-  HIPCHK(hipMemcpyAsync(pl->tiles_dev, th.data(), sizeof(FgTile) * th.size(), hipMemcpyHostToDevice, st));
+  FgTileSet ts; ts.n = 0;
+  const bool by_value = !gc && pl->ntiles + 1 <= FG_TILESET_MAX;        // descriptors travel as a kernel argument
+  if (by_value) { ts.n = pl->ntiles + 1; for (int m = 0; m <= pl->ntiles; m++) ts.t[m] = th[m]; }
+  else HIPCHK(hipMemcpyAsync(pl->tiles_dev, th.data(), sizeof(FgTile) * th.size(), hipMemcpyHostToDevice, st));
   FgTileXyz *gct_dev = nullptr;
-  std::vector<FgTileXyz> gct;                       // must outlive the async upload: synchronised at the first readback
+  std::vector<FgTileXyz> gct;                       // must outlive the async upload: synchronised at the readback
   if (gc) {
     gct.resize(pl->ntiles + 1);
     for (int m = 0; m < pl->ntiles; m++) gct[m] = FgTileXyz{gc_in[m].x, gc_in[m].y, gc_in[m].z, pl->nx_in[m], pl->ny_in[m], pl->cell_off[m]};
@@ -386,35 +388,56 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     }
   }
 
-  // --- bins over the destination cells (sizes known up front)
+  // --- sizes known up front
   FgBins bins;
   choose_bins(pl, mean_dlat, mean_dlon, &bins);
   const long nbins = (long)bins.nblat * bins.nblon;
   const long nslots = nbins + bins.nblat;             // regular bins + one wide list per bin row
-  const long ncand = (long)nsrc * fgd_cand_group();   // one counter per (source cell, scan lane)
+  const unsigned long long nentries = caps->entries;
+  const int ecap = (int)std::min<unsigned long long>(nentries, 2147483647ull);     // records the buffer holds: writes and reads stop there
+  FgPairSpace ps{};
+  ps.nreg = FG_NREG; ps.regcap = caps->regcap;
+  const long npairs = fgd_pairs_total(ps);            // capacity of the pair list
+  const long nx_alloc = npairs;                       // nxgrid <= candidate pairs <= capacity
 
   if (!alloc_cells(pl, &pl->S, nsrc) || !alloc_cells(pl, &pl->D, ndst)) return fail(FG_ERR_HIP, "out of device memory");
-  // one zeroed block: [counters | bin counts | bin fill cursors | accepted-per-source-cell]
-  const size_t zc = (sizeof(DevCounters) + 15) / 16 * 16;
-  const size_t zbytes = zc + ((size_t)(2 * (nslots + 1) + nsrc + 1) * sizeof(int));
+  // one zeroed block: [counters | region fill counters | tickets | look-back words of the three scans | bin counts |
+  //                    bin fill cursors | destination-row counts]
+  const long t_bins = fgd_scan_tiles(nslots), t_rows = fgd_scan_tiles(ndst), t_comp = ((long)nsrc + 255) / 256 + 1;
+  const size_t zc = (sizeof(FgCounters) + 127) / 128 * 128;
+  const size_t zfill = (size_t)FG_NREG * FG_FILL_STRIDE * sizeof(unsigned);
+  const size_t ztick = 128;
+  const size_t zlb = (size_t)(t_bins + t_rows + t_comp) * sizeof(unsigned long long);
+  const size_t zbytes = zc + zfill + ztick + zlb + (size_t)(2 * (nslots + 1) + ndst + 1) * sizeof(int);
   char *zero_blk = pl->alloc<char>(zbytes);
   int *bin_start = pl->alloc<int>(nslots + 1);
-  long scan_n = std::max(std::max(nslots, ncand), (long)std::max(nsrc, ndst)) + 1;
-  unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(scan_n));
-  int *cand_cnt = pl->alloc<int>(ncand + 1);
-  int *cand_off = pl->alloc<int>(ncand + 1);
-  int *cand_stage = pl->alloc<int>(4 * (size_t)(ncand + 1));        // int4 per candidate lane (k_candidates)
   int *heavy_list = pl->alloc<int>(nsrc + 1);
+  int *big_list = pl->alloc<int>(nsrc + 1);
+  int *pair_beg = pl->alloc<int>(nsrc + 1), *pair_cnt = pl->alloc<int>(nsrc + 1);
+  FgBinEntry *bin_entries = pl->alloc<FgBinEntry>(nentries ? nentries : 1);
+  ps.src = pl->alloc<int>(npairs + 1); ps.dst = pl->alloc<int>(npairs + 1);
+  double *tmp_area = pl->alloc<double>(npairs + 1);
+  double *tmp_clon = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
+  double *tmp_clat = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
+  int *defer_list = pl->alloc<int>(npairs + 1);
   pl->xoff = pl->alloc<int>(nsrc + 1);
-  if (!zero_blk || !bin_start || !scan_ws || !cand_cnt || !cand_off || !cand_stage || !heavy_list || !pl->xoff) return fail(FG_ERR_HIP, "out of device memory");
-  DevCounters *dc = (DevCounters *)zero_blk;
-  int *bin_cnt = (int *)(zero_blk + zc), *bin_fill = bin_cnt + (nslots + 1), *nacc = bin_fill + (nslots + 1);
+  pl->x_src = pl->alloc<int>(nx_alloc + 1); pl->x_dst = pl->alloc<int>(nx_alloc + 1);
+  pl->x_area = pl->alloc<double>(nx_alloc + 1);
+  if (order == 2) { pl->x_c1 = pl->alloc<double>(nx_alloc + 1); pl->x_c2 = pl->alloc<double>(nx_alloc + 1); pl->sums = pl->alloc<double>(3 * (size_t)nsrc); }
+  pl->x_rowpos = pl->alloc<int>(nx_alloc + 1);
+  pl->perm = pl->alloc<int>(nx_alloc + 1);
+  pl->csr.row_ptr = pl->alloc<int>(ndst + 1);
+  if (!pl->src_idx_f) pl->src_idx_f = pl->alloc<int>(nsrc + 1);
+  if (!zero_blk || !bin_start || !heavy_list || !big_list || !pair_beg || !pair_cnt || !bin_entries || !ps.src || !ps.dst || !tmp_area ||
+      !defer_list || (order == 2 && (!tmp_clon || !tmp_clat || !pl->x_c1 || !pl->x_c2 || !pl->sums)) || !pl->xoff || !pl->x_src || !pl->x_dst ||
+      !pl->x_area || !pl->x_rowpos || !pl->perm || !pl->csr.row_ptr || !pl->src_idx_f)
+    return fail(FG_ERR_HIP, "out of device memory");
+  FgCounters *dc = (FgCounters *)zero_blk;
+  ps.fill = (unsigned *)(zero_blk + zc);
+  unsigned *tickets = (unsigned *)(zero_blk + zc + zfill);                 // [0] bins [1] rows [2] compaction
+  unsigned long long *lb_bins = (unsigned long long *)(zero_blk + zc + zfill + ztick), *lb_rows = lb_bins + t_bins, *lb_comp = lb_rows + t_rows;
+  int *bin_cnt = (int *)(zero_blk + zc + zfill + ztick + zlb), *bin_fill = bin_cnt + (nslots + 1), *row_cnt = bin_fill + (nslots + 1);
   HIPCHK(hipMemsetAsync(zero_blk, 0, zbytes, st));
-  auto readback = [&]() -> int {
-    HIPCHK(hipMemcpyAsync(hc, dc, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    return 0;
-  };
 
   PhaseTimer pt, ptot;
   pt.start(g_profiling != 0, st); ptot.start(g_profiling != 0, st);
@@ -424,135 +447,78 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   if (gc) {
     fgd_gc_cell_struct(gct_dev, pl->ntiles, nsrc, pl->S, st);
     fgd_gc_cell_struct(gct_dev + pl->ntiles, 1, ndst, pl->D, st);
-  } else {
-    fgd_cell_struct(pl->tiles_dev, pl->ntiles, nsrc, pl->S, dc->err, st);
-    fgd_cell_struct(pl->tiles_dev + pl->ntiles, 1, ndst, pl->D, dc->err, st);
-  }
+    fgd_src_field_index(order, pl->tiles_dev, pl->ntiles, nsrc, pl->src_idx_f, st);
+  } else
+    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, dc->err, st);
   if (boxm) fgd_box_cell_boxes(boxm->box, pl->S, st);
   if (boxm && boxm->no_adjust) fgd_box_area_no_adjust(boxm->box, pl->S.area, st);      // create_xgrid.c:239-242
   pt.end();
   pl->have_geom = true;
 
-  const long big = std::max((long)nsrc, (long)ndst);
-  const unsigned long long cap_entries = 3ull * (unsigned long long)ndst + 4096ull;
-  const unsigned long long cap_pairs = std::min<unsigned long long>(8ull * (unsigned long long)big + 65536ull, 2000000000ull);
   pt.begin(PH_BINS);
-  fgd_bin_build(false, ndst, pl->D, bins, bin_cnt, nullptr, nullptr, 0, st);
-  fgd_exclusive_scan(bin_cnt, nslots, bin_start, scan_ws, &dc->total[0], st);
-  pt.end();
-  unsigned long long nentries = cap_entries;
-  if (!fast) {
-    if (readback()) return FG_ERR_HIP;
-    if (hc->err[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
-    if (hc->err[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
-    nentries = hc->total[0];
-    if (nentries > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
-  }
-  FgBinEntry *bin_entries = pl->alloc<FgBinEntry>(nentries ? nentries : 1);
-  if (!bin_entries) return fail(FG_ERR_HIP, "out of device memory");
-  pt.begin(PH_BINS);
-  const int ecap = (int)std::min<unsigned long long>(nentries, 2147483647ull);     // records the buffer holds: writes and reads stop there
-  fgd_bin_build(true, ndst, pl->D, bins, bin_fill, bin_start, bin_entries, ecap, st);
+  if (gc) fgd_bin_count(ndst, pl->D, bins, bin_cnt, st);
+  fgd_exclusive_scan1(bin_cnt, nslots, bin_start, lb_bins, &tickets[0], &dc->total[0], dc->err, st);
+  fgd_bin_fill(ndst, pl->D, bins, bin_fill, bin_start, bin_entries, ecap, nsrc, pl->S, pl->mask_dev, heavy_list, &dc->heavy_cnt, st);
   pt.end();
 
-  // --- candidate pairs
+  // --- candidate pairs (one pass)
   pt.begin(PH_CANDIDATES);
-  fgd_candidates(false, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, nullptr, nullptr, nullptr, heavy_list, &dc->heavy_cnt, 0, cand_stage, ecap, st);
-  fgd_exclusive_scan(cand_cnt, ncand, cand_off, scan_ws, &dc->total[1], st);
-  pt.end();
-  unsigned long long npairs64 = cap_pairs;
-  if (!fast) {
-    if (readback()) return FG_ERR_HIP;
-    npairs64 = hc->total[1];
-    if (npairs64 > 2000000000ull) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
-  }
-  const int npairs = (int)npairs64;                                 // exact count, or the capacity the kernels are launched for
-  const unsigned long long *np_dev = fast ? &dc->total[1] : nullptr;
-
-  int *pair_src = pl->alloc<int>(npairs + 1), *pair_dst = pl->alloc<int>(npairs + 1);
-  double *tmp_area = pl->alloc<double>(npairs + 1);
-  double *tmp_clon = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
-  double *tmp_clat = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
-  int *defer_list = pl->alloc<int>(npairs + 1);
-  if (!pair_src || !pair_dst || !tmp_area || !defer_list || (order == 2 && (!tmp_clon || !tmp_clat)))
-    return fail(FG_ERR_HIP, "out of device memory");
-  pt.begin(PH_CANDIDATES);
-  fgd_candidates(true, nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, &dc->heavy_cnt, npairs, cand_stage, ecap, st);
+  fgd_candidates1(nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, ecap, ps, pair_beg, pair_cnt, heavy_list, &dc->heavy_cnt, st);
   pt.end();
 
-  // --- clip, area, centroid integrals (+ accepted count per source cell)
+  // --- clip, area, centroid integrals
   if (boxm) {
     pt.begin(PH_CLIP_GENERAL);
-    fgd_clip_box(order, npairs, pair_src, pair_dst, boxm->box, th[pl->ntiles], pl->S, pl->D, pl->mask_dev, boxm->mask_quad,
-                 tmp_area, tmp_clon, tmp_clat, nacc, dc->stats, dc->err, np_dev, st);
+    fgd_clip_box(order, ps, boxm->box, th[pl->ntiles], pl->S, pl->D, pl->mask_dev, boxm->mask_quad, tmp_area, tmp_clon, tmp_clat, dc->stats, dc->err, st);
     pt.end();
   } else if (gc) {
     pt.begin(PH_CLIP_GENERAL);
-    fgd_gc_clip(npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, np_dev, st);
+    fgd_gc_clip(ps, pl->S, pl->mask_dev, pl->D, tmp_area, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
     pt.end();
   } else {
     pt.begin(PH_CLIP_QUAD);
-    fgd_clip_quad(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-                  nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, np_dev, st);
+    fgd_clip_quad(order, ps, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
     pt.end();
     pt.begin(PH_CLIP_GENERAL);
-    fgd_clip_general(order, npairs, pair_src, pair_dst, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat,
-                     nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
+    fgd_clip_general(order, ps, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
     pt.end();
   }
 
-  // --- compaction into canonical order
+  // --- compaction into canonical order, per-source-cell sums, destination rows
   pt.begin(PH_COMPACT);
-  fgd_exclusive_scan(nacc, nsrc, pl->xoff, scan_ws, &dc->total[2], st);
+  FgCompactIo io{};
+  io.pair_beg = pair_beg; io.pair_cnt = pair_cnt; io.tmp_area = tmp_area; io.tmp_clon = tmp_clon; io.tmp_clat = tmp_clat;
+  io.xoff = pl->xoff; io.x_src = pl->x_src; io.x_dst = pl->x_dst; io.x_area = pl->x_area; io.x_c1 = pl->x_c1; io.x_c2 = pl->x_c2;
+  io.row_cnt = row_cnt; io.x_rowpos = pl->x_rowpos; io.sums = pl->sums; io.big_list = big_list;
+  io.lb_status = lb_comp; io.ticket = &tickets[2]; io.dc = dc; io.xcap = nx_alloc;
+  fgd_compact(order, nsrc, ps, io, st);
   pt.end();
-  auto check_errors = [&]() -> int {
-    if (hc->err[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
-    if (hc->err[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
-    if (hc->err[0] & 2u) return fail(FG_ERR_PARALLEL, "the line between <x1_0,y1_0> and  <x1_1,y1_1> should not parallel to "
-                                                      "the line between <x2_0,y2_0> and  <x2_1,y2_1>");
-    if (hc->err[0] & 4u) return fail(FG_ERR_MAXV, "clipped polygon exceeds 16 vertices");
-    if (hc->err[0] & G_ERRBIT_GC_CONVEX1) return fail(FG_ERR_GEOM, "create_xgrid.c(clip_2dx2d_great_circle): grid box 1 is not convex");
-    if (hc->err[0] & G_ERRBIT_GC_CONVEX2) return fail(FG_ERR_GEOM, "create_xgrid.c(clip_2dx2d_great_circle): grid box 2 is not convex");
-    if (hc->err[0] & G_ERRBIT_GC_CLIP) return fail(FG_ERR_GEOM, "%s", gc_clip_error((int)hc->err[1]));
-    return 0;
-  };
-  long nx_alloc = (long)npairs;                                     // fast: nxgrid <= candidate pairs <= capacity
-  if (!fast) {
-    if (readback()) return FG_ERR_HIP;
-    { int rc = check_errors(); if (rc) return rc; }
-    pl->nx = (long)hc->total[2];
-    nx_alloc = pl->nx;
-  }
-  pl->x_src = pl->alloc<int>(nx_alloc + 1); pl->x_dst = pl->alloc<int>(nx_alloc + 1);
-  pl->x_area = pl->alloc<double>(nx_alloc + 1);
-  if (order == 2) { pl->x_c1 = pl->alloc<double>(nx_alloc + 1); pl->x_c2 = pl->alloc<double>(nx_alloc + 1); }
-  if (!pl->x_src || !pl->x_dst || !pl->x_area || (order == 2 && (!pl->x_c1 || !pl->x_c2))) return fail(FG_ERR_HIP, "out of device memory");
-  pl->row_cnt = pl->alloc<int>(2 * ((size_t)ndst + 1));
-  pl->x_rowpos = pl->alloc<int>(nx_alloc + 1);
-  if (!pl->row_cnt || !pl->x_rowpos) return fail(FG_ERR_HIP, "out of device memory");
-  pt.begin(PH_COMPACT);
-  HIPCHK(hipMemsetAsync(pl->row_cnt, 0, 2 * ((size_t)ndst + 1) * sizeof(int), st));
-  fgd_scatter_xcells(order, npairs, pair_src, pair_dst, cand_off, pl->xoff, tmp_area, tmp_clon, tmp_clat,
-                     pl->x_src, pl->x_dst, pl->x_area, pl->x_c1, pl->x_c2, pl->row_cnt, pl->x_rowpos, np_dev, heavy_list, &dc->heavy_cnt,
-                     cand_stage, /* pair_rank: the deferral list is spent by now */ defer_list, st);
+  pt.begin(PH_ROWS);
+  fgd_exclusive_scan1(row_cnt, ndst, pl->csr.row_ptr, lb_rows, &tickets[1], &dc->rows_total, dc->err, st);
+  fgd_csr_fill_pos(nx_alloc, &dc->total[2], pl->x_dst, pl->csr.row_ptr, pl->x_rowpos, pl->perm, st);
   pt.end();
-  if (order == 2) {
-    pl->sums = pl->alloc<double>(3 * (size_t)nsrc);
-    if (!pl->sums) return fail(FG_ERR_HIP, "out of device memory");
-    pt.begin(PH_CELL_SUMS);
-    fgd_cell_sums(nsrc, pl->xoff, pl->x_area, pl->x_c1, pl->x_c2, pl->sums, st);
-    pt.end();
-  }
   ptot.end();
-  if (fast) {
-    if (readback()) return FG_ERR_HIP;                             // the one synchronisation of the fast path
-    if (hc->total[0] > cap_entries || hc->total[1] > cap_pairs) return FG_RETRY_EXACT;
-    { int rc = check_errors(); if (rc) return rc; }
-    pl->nx = (long)hc->total[2];
-  } else
-    HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMemcpyAsync(hc, dc, sizeof(FgCounters), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));                              // the one synchronisation of a search
+  pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms);          // (also hands the timing events back on every exit below)
   HIPCHK(hipGetLastError());
-  pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms);
+  if (hc->total[0] > nentries) { caps->entries = hc->total[0]; return FG_RETRY; }
+  if (hc->total[0] > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
+  if (hc->total[3] > (unsigned long long)ps.regcap) {
+    if (hc->total[3] > 2000000000ull / FG_NREG) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
+    caps->regcap = (int)((hc->total[3] + 255) / 256 * 256);
+    return FG_RETRY;
+  }
+  if (hc->err[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
+  if (hc->err[0] & 1u) return fail(FG_ERR_MAXV, "create_xgrid.c: n2_in is greater than MAX_V");
+  if (hc->err[0] & 2u) return fail(FG_ERR_PARALLEL, "the line between <x1_0,y1_0> and  <x1_1,y1_1> should not parallel to "
+                                                    "the line between <x2_0,y2_0> and  <x2_1,y2_1>");
+  if (hc->err[0] & 4u) return fail(FG_ERR_MAXV, "clipped polygon exceeds 16 vertices");
+  if (hc->err[0] & G_ERRBIT_GC_CONVEX1) return fail(FG_ERR_GEOM, "create_xgrid.c(clip_2dx2d_great_circle): grid box 1 is not convex");
+  if (hc->err[0] & G_ERRBIT_GC_CONVEX2) return fail(FG_ERR_GEOM, "create_xgrid.c(clip_2dx2d_great_circle): grid box 2 is not convex");
+  if (hc->err[0] & G_ERRBIT_GC_CLIP) return fail(FG_ERR_GEOM, "%s", gc_clip_error((int)hc->err[1]));
+  if (hc->err[0] & G_ERRBIT_LOOKBACK) return fail(FG_ERR_HIP, "single-pass scan: a tile waited too long for its predecessor");
+  pl->nx = (long)hc->total[2];
   pl->stats[FG_STAT_PAIRS] = (long)hc->total[1];
   pl->stats[FG_STAT_NONEMPTY] = (long)(hc->total[2] + hc->stats[FG_STAT_BELOW]);
   pl->stats[FG_STAT_NXGRID] = pl->nx;
@@ -562,19 +528,22 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pl->stats[FG_STAT_DEFERRED] = hc->defer_cnt;
   pl->stats[FG_STAT_HEAVY] = hc->heavy_cnt;
   pl->stats[FG_STAT_BELOW] = (long)hc->stats[FG_STAT_BELOW];
-  pl->stats[FG_STAT_EXACT] = fast ? 0 : 1;
 
   // scratch no longer needed
-  void *scratch[] = {zero_blk, bin_start, scan_ws, bin_entries, heavy_list, cand_cnt, cand_off, cand_stage, pair_src, pair_dst,
+  void *scratch[] = {zero_blk, bin_start, bin_entries, heavy_list, big_list, pair_beg, pair_cnt, ps.src, ps.dst,
                      tmp_area, tmp_clon, tmp_clat, defer_list};
   for (void *p : scratch) pl->release(p);
+  pl->release(pl->x_rowpos); pl->x_rowpos = nullptr;
+  pl->rows_built = true;
   pl->searched = true;
   return pl->nx;
 }
 
-// Fast path first; if one of its capacities was too small (coarse -> very fine grids: a source cell with thousands of
-// candidates), drop everything the attempt allocated and search again with exactly sized buffers.
-static int g_search_exact = 0;                       // FREGRID_HIP_EXACT_SEARCH=1 / fg_set_search_mode(1): always use exact mode
+// Default capacities first; an attempt that outgrew one (coarse -> very fine grids: a source cell with thousands of
+// candidates) drops everything it allocated and is repeated with the sizes its counters report -- at most twice, since the
+// candidate counts of an attempt whose bin table was cut short mean nothing.  fg_set_search_mode(1) /
+// FREGRID_HIP_EXACT_SEARCH=1 starts from empty buffers, i.e. sizes everything by counting (tests; memory-tight callers).
+static int g_search_exact = 0;
 extern "C" void fg_set_search_mode(int exact) { g_search_exact = exact; }
 static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
@@ -582,17 +551,29 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
                         const BoxMode *boxm = nullptr)
 {
   static const bool env_exact = getenv("FREGRID_HIP_EXACT_SEARCH") && atoi(getenv("FREGRID_HIP_EXACT_SEARCH")) != 0;
-  if (!g_search_exact && !env_exact) {
-    const size_t keep = pl->owned.size();            // blocks the caller staged before the search stay
-    long rc = plan_search_core(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon, gc_in, gc_out, boxm, true);
-    if (rc != FG_RETRY_EXACT) return rc;
-    (void)hipStreamSynchronize(pl->stream);
-    while (pl->owned.size() > keep) { void *p = pl->owned.back(); pl->owned.pop_back(); g_pool.put(p); }
-    pl->tiles_dev = nullptr; pl->mask_dev = nullptr; pl->S = FgCells{}; pl->D = FgCells{};
-    pl->x_src = pl->x_dst = nullptr; pl->x_area = pl->x_c1 = pl->x_c2 = nullptr; pl->xoff = nullptr; pl->row_cnt = nullptr; pl->x_rowpos = nullptr; pl->sums = nullptr;
-    pl->have_geom = false;
+  const bool exact = g_search_exact || env_exact;
+  const long big = std::max((long)pl->nsrc, (long)pl->ndst);
+  SearchCaps caps;
+  caps.entries = exact ? 0ull : 3ull * (unsigned long long)pl->ndst + 4096ull;
+  const unsigned long long cap_pairs = std::min<unsigned long long>(8ull * (unsigned long long)big + 65536ull, 2000000000ull);
+  caps.regcap = exact ? 0 : (int)((cap_pairs / FG_NREG + 255) / 256 * 256);
+  const size_t keep = pl->owned.size();              // blocks the caller staged before the search stay
+  long rc = FG_RETRY;
+  int attempts = 0;
+  for (; attempts < 4 && rc == FG_RETRY; attempts++) {
+    if (attempts) {
+      (void)hipStreamSynchronize(pl->stream);
+      while (pl->owned.size() > keep) { void *p = pl->owned.back(); pl->owned.pop_back(); g_pool.put(p); }
+      pl->tiles_dev = nullptr; pl->mask_dev = nullptr; pl->S = FgCells{}; pl->D = FgCells{};
+      pl->x_src = pl->x_dst = nullptr; pl->x_area = pl->x_c1 = pl->x_c2 = nullptr; pl->xoff = nullptr; pl->x_rowpos = nullptr;
+      pl->perm = nullptr; pl->csr.row_ptr = nullptr; pl->src_idx_f = nullptr; pl->sums = nullptr;
+      pl->have_geom = false;
+    }
+    rc = plan_search_core(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon, gc_in, gc_out, boxm, &caps);
   }
-  return plan_search_core(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon, gc_in, gc_out, boxm, false);
+  if (rc == FG_RETRY) return fail(FG_ERR_CAPACITY, "exchange-grid search: capacities did not settle");
+  if (rc >= 0) pl->stats[FG_STAT_EXACT] = (attempts > 1) ? 1 : 0;
+  return rc;
 }
 
 // mean cell extents from a strided sample of corner arrays (host or device-copied-to-host)
@@ -856,7 +837,10 @@ extern "C" int fg_plan_stats(const fg_plan *pl, long *stats, int n)
   return 0;
 }
 
-static int build_csr(fg_plan *pl)
+// Destination-row CSR.  A searched plan arrives with row_ptr and perm (rows grouped, unsorted inside a row) already built on
+// the device by the search; a plan loaded from a remap file (fg_plan_set_xgrid) counts and fills its rows here.
+// cen != null: order 2, x_c1/x_c2 hold the centroid integrals and di/dj are formed while the records are packed.
+static int build_csr(fg_plan *pl, const double *cen)
 {
   hipStream_t st = pl->stream;
   const int ndst = pl->ndst;
@@ -867,29 +851,29 @@ static int build_csr(fg_plan *pl)
     if (!pl->src_idx_f) return fail(FG_ERR_HIP, "out of device memory");
     fgd_src_field_index(pl->order, pl->tiles_dev, pl->ntiles, pl->nsrc, pl->src_idx_f, st);
   }
-  int *row_cnt = pl->row_cnt;
-  const bool counted = row_cnt != nullptr;                  // the search's scatter kernel already counted the rows
-  if (!counted) row_cnt = pl->alloc<int>(2 * ((size_t)ndst + 1));   // counts | fill cursors, one memset
-  int *perm = pl->alloc<int>(nx + 1);
-  unsigned long long *scan_ws = pl->alloc<unsigned long long>(fgd_scan_ws_elems(ndst + 1));
-  unsigned long long *total_dev = pl->alloc<unsigned long long>(4);
-  pl->csr.row_ptr = pl->alloc<int>(ndst + 1);
+  void *scratch = nullptr;
+  if (!pl->rows_built) {
+    const long t_rows = fgd_scan_tiles(ndst);
+    const size_t zb = 256 + (size_t)t_rows * sizeof(unsigned long long) + 2 * ((size_t)ndst + 1) * sizeof(int);
+    char *z = pl->alloc<char>(zb);                                    // [ticket, total, err | look-back words | counts | fill cursors]
+    pl->perm = pl->alloc<int>(nx + 1);
+    pl->csr.row_ptr = pl->alloc<int>(ndst + 1);
+    if (!z || !pl->perm || !pl->csr.row_ptr) return fail(FG_ERR_HIP, "out of device memory");
+    HIPCHK(hipMemsetAsync(z, 0, zb, st));
+    unsigned long long *lb = (unsigned long long *)(z + 256);
+    int *row_cnt = (int *)(z + 256 + (size_t)t_rows * sizeof(unsigned long long));
+    fgd_csr_count(nx, pl->x_dst, row_cnt, st);
+    fgd_exclusive_scan1(row_cnt, ndst, pl->csr.row_ptr, lb, (unsigned *)z, (unsigned long long *)(z + 8), (unsigned *)(z + 16), st);
+    fgd_csr_fill(nx, pl->x_dst, pl->csr.row_ptr, row_cnt + ndst + 1, pl->perm, st);
+    scratch = z;
+  }
   if (pl->order == 2) pl->csr.e2 = pl->alloc<FgCsrEntry2>(nx + 1);
   else pl->csr.e1 = pl->alloc<FgCsrEntry1>(nx + 1);
-  if (!row_cnt || !perm || !scan_ws || !total_dev || !pl->csr.row_ptr || (!pl->csr.e1 && !pl->csr.e2))
-    return fail(FG_ERR_HIP, "out of device memory");
-  if (!counted) {
-    HIPCHK(hipMemsetAsync(row_cnt, 0, 2 * ((size_t)ndst + 1) * sizeof(int), st));
-    fgd_csr_count(nx, pl->x_dst, row_cnt, st);
-  }
-  fgd_exclusive_scan(row_cnt, ndst, pl->csr.row_ptr, scan_ws, total_dev, st);
-  if (counted && pl->x_rowpos) fgd_csr_fill_pos(nx, pl->x_dst, pl->csr.row_ptr, pl->x_rowpos, perm, st);
-  else fgd_csr_fill(nx, pl->x_dst, pl->csr.row_ptr, row_cnt + ndst + 1, perm, st);
-  fgd_csr_sort_rows(ndst, nx, pl->csr.row_ptr, perm, st);
-  fgd_csr_gather(pl->order, nx, perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, pl->csr, st);
+  if (!pl->csr.e1 && !pl->csr.e2) return fail(FG_ERR_HIP, "out of device memory");
+  fgd_csr_sortgather(pl->order, ndst, nx, pl->perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, cen, pl->nsrc, pl->csr, st);
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
-  pl->release(row_cnt); pl->row_cnt = nullptr; pl->release(pl->x_rowpos); pl->x_rowpos = nullptr; pl->release(perm); pl->release(scan_ws); pl->release(total_dev);
+  pl->release(scratch); pl->release(pl->perm); pl->perm = nullptr;
   if (!pl->red_partial) { pl->red_partial = pl->alloc<double>(1024); pl->red_result = pl->alloc<double>(260); }
   if (!pl->red_partial || !pl->red_result) return fail(FG_ERR_HIP, "out of device memory");
   return 0;
@@ -908,9 +892,9 @@ extern "C" int fg_plan_finalize(fg_plan *pl, const double *total_cell_sums_dev)
     if (!pl->cen) return fail(FG_ERR_HIP, "out of device memory");
     const double *tot = total_cell_sums_dev ? total_cell_sums_dev : pl->sums;
     fgd_centroids(pl->nsrc, pl->S, tot, pl->cen, pl->stream);
-    fgd_distances(pl->nx, pl->nsrc, pl->x_src, pl->x_area, pl->cen, pl->x_c1, pl->x_c2, pl->stream);
+    pl->dist_pending = true;                 // the CSR records get di/dj now; the exchange-cell arrays when somebody asks for them
   }
-  int rc = build_csr(pl);
+  int rc = build_csr(pl, pl->order == 2 ? pl->cen : nullptr);
   if (rc) return rc;
   pt.end();
   HIPCHK(hipStreamSynchronize(pl->stream));
@@ -921,7 +905,7 @@ extern "C" int fg_plan_finalize(fg_plan *pl, const double *total_cell_sums_dev)
 
 // phase times (ms) of the last search/finalize/apply when fg_set_profiling(1) was active:
 // [0] cell records [1] binning [2] candidates [3] clip quad [4] clip general [5] compaction
-// [6] cell sums [7] whole search (device span) [8] finalize [9] last apply
+// [6] destination rows [7] whole search (device span) [8] finalize [9] last apply
 extern "C" int fg_plan_phase_ms(fg_plan *pl, float *ms, int n)
 {
   if (!pl || !ms) return fail(FG_ERR_ARG, "null argument");
@@ -946,6 +930,12 @@ extern "C" int fg_plan_get_xgrid(const fg_plan *pl, int *t_in, int *i_in, int *j
   HIPCHK(hipStreamSynchronize(pl->stream));
   const long nx = pl->nx;
   if (nx == 0) return 0;
+  if (pl->dist_pending) {                     // di = clon/area - centroid (conserve_interp.c:256-257,355-356), on first use
+    fg_plan *m = const_cast<fg_plan *>(pl);
+    fgd_distances(nx, pl->nsrc, pl->x_src, pl->x_area, pl->cen, m->x_c1, m->x_c2, pl->stream);
+    HIPCHK(hipStreamSynchronize(pl->stream));
+    m->dist_pending = false;
+  }
   if (t_in || i_in || j_in || i_out || j_out) {
     // index decomposition on the device, then plain copies (the host loop with two divisions per exchange cell took longer
     // than the transfer)
@@ -1041,7 +1031,7 @@ extern "C" int fg_plan_set_xgrid(fg_plan *pl, long nxgrid, const int *t_in, cons
     }
   }
   pl->searched = true;
-  int rc = build_csr(pl);
+  int rc = build_csr(pl, nullptr);
   if (rc) return rc;
   pl->finalized = true;
   return 0;

@@ -56,31 +56,81 @@ enum {
   FG_NSTATS = 10
 };
 
-// n inputs -> n+1 exclusive prefixes (out[n] = total, also stored 64-bit in *total_dev)
-int  fgd_exclusive_scan(const int *in, long n, int *out, unsigned long long *bsum_ws,
-                        unsigned long long *total_dev, hipStream_t st);
-long fgd_scan_ws_elems(long n);
+// ---- candidate pairs: one pair list in FG_NREG regions of `regcap` entries.  A wave of the candidate kernel appends the
+// pairs of its source cells to one region with a single atomic on that region's fill counter (a counter per 128-byte
+// line: appends to different regions do not serialise), so the list is written in ONE pass -- no count pass, no scan.
+// A region may overflow (fill > regcap): writes beyond it are dropped, the host sees it at its one readback and repeats
+// the search with regions sized by the counters.  regcap is a multiple of 256, so a block of a pair kernel lies in one region.
+#define FG_NREG 64
+#define FG_FILL_STRIDE 32            // unsigned words per region counter (128 B)
+struct FgPairSpace {
+  int *src, *dst;                    // [nreg * regcap]: source / destination cell of pair p; dst = -1 once a clip rejected it
+  unsigned *fill;                    // fill[r * FG_FILL_STRIDE] = pairs appended to region r (true count, may exceed regcap)
+  int regcap, nreg;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ bool d_pair_live(const FgPairSpace &ps, int p)
+{
+  const unsigned first = blockIdx.x * blockDim.x;                 // block-uniform (scalar) region lookup
+  const unsigned r = first / (unsigned)ps.regcap;
+  const unsigned f = ps.fill[r * FG_FILL_STRIDE];
+  return (unsigned)p - r * (unsigned)ps.regcap < (f < (unsigned)ps.regcap ? f : (unsigned)ps.regcap);
+}
+#endif
+static inline long fgd_pairs_total(const FgPairSpace &ps) { return (long)ps.regcap * ps.nreg; }
 
+// source tiles + the destination tile as a kernel argument (no descriptor upload before the first kernel)
+#define FG_TILESET_MAX 8
+struct FgTileSet { FgTile t[FG_TILESET_MAX]; int n; };
+
+// device-side counters of one search (plan.hip reads them back once)
+struct FgCounters {
+  unsigned long long total[4];     // [0] bin-table entries  [1] candidate pairs  [2] nxgrid  [3] largest region fill
+  unsigned long long rows_total;   // total of the destination-row scan (= nxgrid)
+  unsigned err[4];
+  int defer_cnt, heavy_cnt, big_cnt, pad1;
+  unsigned long long stats[FG_NSTATS];
+};
+#define G_ERRBIT_LOOKBACK 128u     // a single-pass scan waited too long for its predecessor tile (never observed)
+
+// single-pass exclusive scan (decoupled look-back): n inputs -> n+1 prefixes (out[n] = total, also 64-bit in *total_dev).
+// status: zeroed words, one per tile of 2048 inputs (fgd_scan_tiles); ticket: zeroed word
+long fgd_scan_tiles(long n);
+void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *status, unsigned *ticket,
+                         unsigned long long *total_dev, unsigned *err, hipStream_t st);
+
+// per-cell records of the source tiles and of the destination tile in ONE launch; also counts the destination cells into
+// their bins (slot_cnt), fills src_idx_f and stores the tile descriptors at tiles_out
+void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, FgCells D,
+                      FgBins b, int *slot_cnt, int order, int *src_idx_f, unsigned *err, hipStream_t st);
 void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c, unsigned *err, hipStream_t st);
-void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start, FgBinEntry *entries, int cap,
-                   hipStream_t st);
-void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start,
-                    const FgBinEntry *entries, int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                    int *heavy_list, int *heavy_cnt, int cap, int *stage, int ecap, hipStream_t st);
-void fgd_clip_general(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
-              double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
+void fgd_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt, hipStream_t st);
+// bin fill + list of the source cells whose candidate scan gets a whole wave
+void fgd_bin_fill(int ndst, FgCells D, FgBins b, int *slot_fill, const int *slot_start, FgBinEntry *entries, int cap,
+                  int nsrc, FgCells S, const double *mask, int *heavy_list, int *heavy_cnt, hipStream_t st);
+void fgd_candidates1(int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
+                     FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, hipStream_t st);
+void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
+              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);
-void fgd_clip_quad(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
-              double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-              unsigned long long *stats, unsigned *err, const unsigned long long *np_dev, hipStream_t st);
-int  fgd_cand_group(void);   // lanes per source cell in the candidate scan: cand_cnt/cand_off hold nsrc*group (+1) entries
-void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
-                        const int *xoff, const double *tmp_area, const double *tmp_clon,
-                        const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                        int *row_cnt, int *x_rowpos, const unsigned long long *np_dev, const int *heavy_list, const int *heavy_cnt,
-                        const int *stage, int *pair_rank, hipStream_t st);
-void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
-                   const double *x_c2, double *sums, hipStream_t st);
+void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
+              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+              unsigned long long *stats, unsigned *err, hipStream_t st);
+// accepted pairs -> exchange cells in canonical order, per-source-cell offsets (xoff) and sums, destination-row sizes and slots
+struct FgCompactIo {
+  const int *pair_beg, *pair_cnt;
+  const double *tmp_area, *tmp_clon, *tmp_clat;
+  int *xoff, *x_src, *x_dst;
+  double *x_area, *x_c1, *x_c2;
+  int *row_cnt, *x_rowpos;
+  double *sums;                      // [3][nsrc] (order 2) or null
+  int *big_list;                     // [nsrc] scratch
+  unsigned long long *lb_status;     // zeroed, one word per 256 source cells
+  unsigned *ticket;                  // zeroed
+  FgCounters *dc;
+  long xcap;                         // entries the x_* arrays hold
+};
+void fgd_compact(int order, int nsrc, FgPairSpace ps, const FgCompactIo &io, hipStream_t st);
 void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st);
 void fgd_distances(long nx, int nsrc, const int *x_src, const double *x_area, const double *cen, double *x_c1,
                    double *x_c2, hipStream_t st);
@@ -98,10 +148,13 @@ struct FgCsr {
 };
 void fgd_csr_count(long nx, const int *x_dst, int *row_cnt, hipStream_t st);
 void fgd_csr_fill(long nx, const int *x_dst, const int *row_ptr, int *row_fill, int *perm, hipStream_t st);
-void fgd_csr_fill_pos(long nx, const int *x_dst, const int *row_ptr, const int *x_rowpos, int *perm, hipStream_t st);
-void fgd_csr_sort_rows(int ndst, long nx, const int *row_ptr, int *perm, hipStream_t st);
-void fgd_csr_gather(int order, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
-                    const double *x_c2, const int *src_idx_f, FgCsr csr, hipStream_t st);
+// nx_cap threads; the true count is read from *nx_dev (null: nx_cap is the count)
+void fgd_csr_fill_pos(long nx_cap, const unsigned long long *nx_dev, const int *x_dst, const int *row_ptr, const int *x_rowpos, int *perm,
+                      hipStream_t st);
+// rows of perm into ascending exchange-cell order, then the packed CSR records; cen != null (order 2): x_c1/x_c2 still hold the
+// centroid integrals and di/dj are formed here (conserve_interp.c:256-257,355-356), else they are taken as they are
+void fgd_csr_sortgather(int order, int ndst, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
+                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr, hipStream_t st);
 void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsrc, int *src_idx_f, hipStream_t st);
 void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, const int *gmask,
                 int has_missing, double missing, double *out, double *row_sum, hipStream_t st);
@@ -147,9 +200,9 @@ void fgd_mono_limit(long nx, FgCsr csr, const double *f, double missing, const d
 
 // ---- 1-D x 2-D variants (box_kernels.hip): the regular grid given by its 1-D bounds (device pointers)
 struct FgBox { const double *lon, *lat; int nx, ny; };
-void fgd_clip_box(int order, int npairs, const int *pair_src, int *pair_dst, FgBox box, FgTile quad, FgCells S, FgCells D,
-                  const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
-                  unsigned long long *stats, unsigned *err, const unsigned long long *np_dev, hipStream_t st);
+void fgd_clip_box(int order, FgPairSpace ps, FgBox box, FgTile quad, FgCells S, FgCells D,
+                  const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon, double *tmp_clat,
+                  unsigned long long *stats, unsigned *err, hipStream_t st);
 void fgd_box_area_no_adjust(FgBox box, double *area, hipStream_t st);
 void fgd_box_cell_boxes(FgBox box, FgCells c, hipStream_t st);
 void fgd_clip_single(const double *lon_in, const double *lat_in, int n_in, double ll_lon, double ll_lat, double ur_lon, double ur_lat,
@@ -159,9 +212,8 @@ void fgd_grid_area_no_adjust(int nx, int ny, const double *lon, const double *la
 
 // ---- great-circle path (gc_kernels.hip)
 void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st);
-void fgd_gc_clip(int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
-                 double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err,
-                 const unsigned long long *np_dev, hipStream_t st);
+void fgd_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
+                 double *tmp_area, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st);
 #define FG_GC_POLY_CAP 16
 void fgd_gc_clip_batch(int n, const double *a, const double *b, double *out, int *n_out, double *area, hipStream_t st);
 void fgd_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *n, double *area, hipStream_t st);

@@ -2,22 +2,26 @@
 //
 // Pipeline for one destination tile against all source tiles:
 //
-//   k_cell_struct      per cell: lat min/max, fix_lon, lon min/max/avg, <=8 vertices, area
-//                      [get_grid_cell_struct semantics, create_xgrid.c:991-1016; get_grid_area :66-88]
-//   k_bin_build        destination cells -> uniform (lat x lon mod 2pi) bins, one 48-byte record per
-//                      cell stored in bin order (single insertion; wide cells in per-row lists)
-//   k_candidates(+_heavy)  per source cell: scan the <= 2 contiguous record ranges per bin row,
-//                      apply the reference's exact bounding-box rejects (create_xgrid.c:1055-1079)
-//                      -> candidate pairs [get_upbound_nxcells_2dx2d semantics]; count pass + fill
-//                      pass; source cells at the poles (huge longitude range) get a whole wave
+//   k_cell_struct2     per cell (source tiles and destination tile in one launch): lat min/max, fix_lon, lon
+//                      min/max/avg, <=8 vertices, area [get_grid_cell_struct semantics, create_xgrid.c:991-1016;
+//                      get_grid_area :66-88]; destination cells are counted into their bins on the way
+//   k_scan1            single-pass exclusive scan (decoupled look-back) of the bin counts / row counts
+//   k_bin_fill         destination cells -> uniform (lat x lon mod 2pi) bins, one 48-byte record per
+//                      cell stored in bin order (single insertion; wide cells in per-row lists); the same launch lists
+//                      the source cells whose query is large (poles: huge longitude range)
+//   k_candidates1      per source cell: scan the <= 2 contiguous record ranges per bin row, apply the reference's
+//                      exact bounding-box rejects (create_xgrid.c:1055-1079) -> candidate pairs
+//                      [get_upbound_nxcells_2dx2d semantics], appended to the pair list in ONE pass (a wave reserves
+//                      its range with one atomic on a region counter); listed cells get a whole wave, same launch
 //   k_clip_quad        one lane per candidate pair, quad x quad fast path: Sutherland-Hodgman
 //                      clip (create_xgrid.c:1266-1341) with the polygon staged in LDS
 //                      [vertex][lane], then area / centroid integrals and the 1e-6 area test
 //   k_clip_general     same for pairs with pole-fixed cells (5..8 vertices) or fast-path overflow
-//   (accepted pairs are counted per source cell inside the clip kernels: wave-segmented ballot, one atomic per run)
-//   k_scatter_xcells   compaction into the reference's canonical order (source cell ascending,
-//                      destination cell index ascending) via per-source-cell rank; counts the CSR row sizes
-//   k_cell_sums, k_centroids, k_distances     order-2 centroid pass (conserve_interp.c:216-221,319-358)
+//   k_compact(+_big)   compaction into the reference's canonical order (source cell ascending, destination cell index
+//                      ascending): a block owns 256 consecutive source cells, counts their accepted pairs, takes its
+//                      offset by look-back, ranks, writes the exchange cells coalesced, takes the destination-row slots
+//                      and adds up the per-source-cell sums in exchange-cell order (conserve_interp.c:216-221)
+//   k_centroids, k_distances     order-2 centroid pass (conserve_interp.c:319-358)
 //
 // No MFMA: this is FP64 VALU + irregular gather work.  Every floating-point operation uses the reference's expression
 // trees, sin/cos included (geom.hip.h, sincos_glibc.h): lists, areas and centroid integrals are the reference's bits.
@@ -36,11 +40,19 @@ __device__ __forceinline__ void d_load_trig_table()
 }
 
 // ---------------------------------------------------------------------------------------
-// exclusive scan of int32 counts (3 kernels: block sums, top-level, apply)
+// single-pass exclusive scan (decoupled look-back) and the look-back itself
 // ---------------------------------------------------------------------------------------
+// A tile publishes its aggregate in one 64-bit word {flag:2, value:62} and walks back over its predecessors until it meets
+// one whose inclusive prefix is known.  Tiles are numbered by a ticket taken when the block starts, so every predecessor a
+// block waits for is already running: the wait ends whatever order the hardware dispatches blocks in.  The spin is bounded
+// all the same (G_ERRBIT_LOOKBACK).  Value and flag share the word, so relaxed agent-scope accesses are all the protocol needs.
 #define SCAN_THREADS 256
 #define SCAN_ITEMS   8
 #define SCAN_CHUNK   (SCAN_THREADS * SCAN_ITEMS)
+#define LB_AGG   (1ull << 62)
+#define LB_INC   (2ull << 62)
+#define LB_MASK  ((1ull << 62) - 1ull)
+#define LB_SPIN_LIMIT (1u << 22)
 
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane)
 {
@@ -68,96 +80,119 @@ __device__ __forceinline__ unsigned block_incl_scan(unsigned v, unsigned *total)
   return inc + base;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const int *in, long n, unsigned long long *bsum)
+__device__ __forceinline__ unsigned long long lb_load(const unsigned long long *p)
 {
-  long base = (long)blockIdx.x * SCAN_CHUNK;
-  unsigned s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) {
-    long idx = base + (long)k * SCAN_THREADS + threadIdx.x;
-    if (idx < n) s += (unsigned)in[idx];
-  }
-  unsigned tot;
-  block_incl_scan(s, &tot);
-  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lb_store(unsigned long long *p, unsigned long long v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// out[i] = exclusive prefix for i in [0, n] (n inputs, n+1 outputs; 32-bit, the host checks the 64-bit total fits).
-// Each block adds up the sums of the blocks before it by itself (at most a few thousand 8-byte values from L2) instead of
-// waiting for a separate single-block pass over them: one launch less per scan, and the search runs four scans.
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int *in, long n, const unsigned long long *bsum, int *out,
-                                                              unsigned long long *total_out)
+// Called by all 64 lanes of ONE wave of the block owning `tile`; returns the sum of the aggregates of tiles 0..tile-1 and
+// publishes this tile's inclusive prefix.  Each round inspects 64 predecessors at once.
+__device__ inline unsigned long long d_lookback_wave(unsigned long long *status, int tile, unsigned long long agg, unsigned *err)
+{
+  const int lane = threadIdx.x & 63;
+  if (tile == 0) { if (lane == 0) lb_store(&status[0], LB_INC | (agg & LB_MASK)); return 0ull; }
+  if (lane == 0) lb_store(&status[tile], LB_AGG | (agg & LB_MASK));
+  unsigned long long excl = 0ull;
+  int base = tile - 1;
+  unsigned spins = 0;
+  for (;;) {
+    const int t = base - lane;
+    const unsigned long long v = (t >= 0) ? lb_load(&status[t]) : LB_INC;      // "tiles" before the first: prefix 0, known
+    const unsigned flag = (unsigned)(v >> 62);
+    const unsigned long long inc = __ballot(flag == 2u), zero = __ballot(flag == 0u);
+    const int first_inc = inc ? (__ffsll((long long)inc) - 1) : 63;
+    const unsigned long long need = (first_inc >= 63) ? ~0ull : ((2ull << first_inc) - 1ull);   // lanes 0..first_inc
+    if (zero & need) {                                  // a predecessor this round depends on has not published yet
+      if (++spins > LB_SPIN_LIMIT) { if (lane == 0) atomicOr(err, G_ERRBIT_LOOKBACK); break; }
+      __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    unsigned long long val = ((need >> lane) & 1ull) ? (v & LB_MASK) : 0ull;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) val += __shfl_xor(val, o);
+    excl += val;
+    if (inc) break;
+    base -= 64;
+  }
+  if (lane == 0) lb_store(&status[tile], LB_INC | ((excl + agg) & LB_MASK));
+  return excl;
+}
+
+// out[i] = exclusive prefix for i in [0, n] (n inputs, n+1 outputs; 32-bit offsets, 64-bit total for the host's checks)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan1(const int *in, long n, int *out, unsigned long long *status, unsigned *ticket,
+                                                        unsigned long long *total_out, unsigned *err)
 {
   __shared__ unsigned tile[SCAN_CHUNK];
-  __shared__ unsigned long long part[SCAN_THREADS / 64];
-  long base = (long)blockIdx.x * SCAN_CHUNK;
-  // 64-bit sum of the preceding blocks' totals
-  unsigned long long before = 0;
-  for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS) before += bsum[i];
-#pragma unroll
-  for (int o = 32; o; o >>= 1) before += __shfl_xor(before, o);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = before;
-  // thread t owns items t*SCAN_ITEMS .. +SCAN_ITEMS-1 of the chunk (blocked arrangement via LDS)
+  __shared__ int sh_t;
+  __shared__ unsigned long long sh_excl;
+  if (threadIdx.x == 0) sh_t = (int)atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int t = sh_t;
+  const long base = (long)t * SCAN_CHUNK;
+  // thread k owns items k*SCAN_ITEMS .. +SCAN_ITEMS-1 of the chunk (blocked arrangement via LDS, coalesced global accesses)
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) {
-    int li = k * SCAN_THREADS + threadIdx.x;
-    long idx = base + li;
+    const int li = k * SCAN_THREADS + threadIdx.x;
+    const long idx = base + li;
     tile[li] = (idx < n) ? (unsigned)in[idx] : 0u;
   }
   __syncthreads();
-  unsigned long long block_base = 0;
-#pragma unroll
-  for (int w = 0; w < SCAN_THREADS / 64; w++) block_base += part[w];
   unsigned loc[SCAN_ITEMS];
   unsigned s = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) { loc[k] = tile[threadIdx.x * SCAN_ITEMS + k]; s += loc[k]; }
   unsigned tot;
-  unsigned inc = block_incl_scan(s, &tot);
-  unsigned run = (unsigned)block_base + inc - s;
+  const unsigned inc = block_incl_scan(s, &tot);
+  if (threadIdx.x < 64) {
+    const unsigned long long e = d_lookback_wave(status, t, (unsigned long long)tot, err);
+    if (threadIdx.x == 0) sh_excl = e;
+  }
   __syncthreads();
+  const unsigned long long excl = sh_excl;
+  unsigned run = (unsigned)excl + inc - s;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) { tile[threadIdx.x * SCAN_ITEMS + k] = run; run += loc[k]; }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) {
-    int li = k * SCAN_THREADS + threadIdx.x;
-    long idx = base + li;
+    const int li = k * SCAN_THREADS + threadIdx.x;
+    const long idx = base + li;
     if (idx <= n) out[idx] = (int)tile[li];
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = block_base + tot;
+  if (threadIdx.x == 0 && n >= base && n < base + SCAN_CHUNK) *total_out = excl + tot;      // the tile holding out[n]
 }
 
-int fgd_exclusive_scan(const int *in, long n, int *out, unsigned long long *bsum_ws,
-                       unsigned long long *total_dev, hipStream_t st)
+long fgd_scan_tiles(long n) { if (n < 0) n = 0; return (n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK; }
+
+void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *status, unsigned *ticket,
+                         unsigned long long *total_dev, unsigned *err, hipStream_t st)
 {
-  // n inputs -> n+1 outputs (out[n] = total); blocks cover n+1 positions, inputs beyond n read as 0
   if (n < 0) n = 0;
-  int nb = (int)((n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK);
-  k_scan_block_sums<<<nb, SCAN_THREADS, 0, st>>>(in, n, bsum_ws);
-  k_scan_apply<<<nb, SCAN_THREADS, 0, st>>>(in, n, bsum_ws, out, total_dev);
-  return 0;
+  k_scan1<<<(int)fgd_scan_tiles(n), SCAN_THREADS, 0, st>>>(in, n, out, status, ticket, total_dev, err);
 }
-
-long fgd_scan_ws_elems(long n) { return (n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK + 1; }
 
 // ---------------------------------------------------------------------------------------
 // per-cell records
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cell_struct(const FgTile *tiles, int ntiles, int ncells, FgCells c, unsigned *err)
+// body shared by the two kernels below: record of cell s0 + threadIdx.x of `ncells` cells described by `tiles`; the 16 vertex
+// doubles are staged so that the block stores its 256 records as one contiguous run (a lane writing its own 128-byte
+// record makes sixteen 8-byte stores at a 128-byte stride).  Returns the vertex count (0: no record) and the box.
+__device__ __forceinline__ int d_cell_record(const FgTile *tiles, int ntiles, int ncells, const FgCells &c, unsigned *err, int s0,
+                                             double *vtile, double *box /* lat_min, lat_max, lon_min, lon_max */, int *tile_of)
 {
-  // the 16 vertex doubles of a cell record are staged so that the block stores its 256 records as one contiguous run
-  // (a lane writing its own 128-byte record makes sixteen 8-byte stores at a 128-byte stride)
-  __shared__ double vtile[256 * 17];
-  d_load_trig_table();
-  const int s0 = blockIdx.x * blockDim.x;
   const int s = s0 + threadIdx.x;
   double *row = vtile + threadIdx.x * 17;
 #pragma unroll
   for (int k = 0; k < 16; k++) row[k] = 0.0;
+  int nvert = 0;
   if (s < ncells) {
     int t = 0;
     while (t + 1 < ntiles && s >= tiles[t + 1].cell_off) t++;
+    *tile_of = t;
     const FgTile T = tiles[t];
     int loc = s - T.cell_off;
     int i = loc % T.nx, j = loc / T.nx;
@@ -172,6 +207,7 @@ __global__ __launch_bounds__(256) void k_cell_struct(const FgTile *tiles, int nt
 #pragma unroll
     for (int k = 1; k < 4; k++) { if (y[k] < lmin) lmin = y[k]; if (y[k] > lmax) lmax = y[k]; }
     c.lat_min[s] = lmin; c.lat_max[s] = lmax;
+    box[0] = lmin; box[1] = lmax;
     if (!(lmin >= -G_HPI - 1.e-6) || !(lmax <= G_HPI + 1.e-6)) atomicOr(err, G_ERRBIT_BADLAT);   // also catches NaN
     int n = d_fix_lon(x, y, 4, G_PI);
     if (n < 0 || n > G_MAXV) {
@@ -183,7 +219,9 @@ __global__ __launch_bounds__(256) void k_cell_struct(const FgTile *tiles, int nt
       for (int k = 0; k < n; k++) xs += x[k];
       xs /= n;
       c.lon_min[s] = xmin; c.lon_max[s] = xmax; c.lon_avg[s] = xs;
+      box[2] = xmin; box[3] = xmax; box[4] = xs;
       c.nv[s] = n;
+      nvert = n;
       for (int k = 0; k < G_MAXV; k++) {
         row[k] = (k < n) ? x[k] : 0.0;
         row[8 + k] = (k < n) ? y[k] : 0.0;
@@ -199,6 +237,15 @@ __global__ __launch_bounds__(256) void k_cell_struct(const FgTile *tiles, int nt
     const long e = (long)q * 256 + threadIdx.x;
     if (e < cnt) out[e] = vtile[(e >> 4) * 17 + (e & 15)];
   }
+  return nvert;
+}
+
+__global__ __launch_bounds__(256) void k_cell_struct(const FgTile *tiles, int ntiles, int ncells, FgCells c, unsigned *err)
+{
+  __shared__ double vtile[256 * 17];
+  d_load_trig_table();
+  double box[5]; int tl = 0;
+  (void)d_cell_record(tiles, ntiles, ncells, c, err, blockIdx.x * 256, vtile, box, &tl);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -244,19 +291,18 @@ __device__ __forceinline__ int d_slot_position(int *slot_cnt, int key)
   return base + (lane - start);
 }
 
+// Count (FILL = false) or store (FILL = true) destination cell d in its bin / wide lists.  Wave-wide: every lane of the
+// wave must call it (live = false for lanes without a cell).
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_bin_build(int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start,
-                                                    FgBinEntry *entries, int cap)
+__device__ __forceinline__ void d_bin_insert(bool live, int d, double lat_min, double lat_max, double lon_min, double lon_max, double lon_avg,
+                                             FgBins b, int *slot_cnt, const int *slot_start, FgBinEntry *entries, int cap)
 {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = d < ncells && c.nv[d] != 0;      // (no early return: the slot positions are a wave-wide operation)
   FgBinEntry E;
   int r0 = 0, r1 = 0; long long l0 = 0, l1 = 0;
   if (live) {
-    E.lat_min = c.lat_min[d]; E.lat_max = c.lat_max[d];
-    E.lon_min = c.lon_min[d]; E.lon_max = c.lon_max[d]; E.lon_avg = c.lon_avg[d];
+    E.lat_min = lat_min; E.lat_max = lat_max; E.lon_min = lon_min; E.lon_max = lon_max; E.lon_avg = lon_avg;
     E.d = d;
-    d_cell_box(E.lat_min, E.lat_max, E.lon_min, E.lon_max, b, &r0, &r1, &l0, &l1);
+    d_cell_box(lat_min, lat_max, lon_min, lon_max, b, &r0, &r1, &l0, &l1);
     E.row0 = r0;
   }
   const int nbins = b.nblat * b.nblon;
@@ -264,7 +310,7 @@ __global__ __launch_bounds__(256) void k_bin_build(int ncells, FgCells c, FgBins
   const int slot = regular ? r0 * b.nblon + d_colmod(l0, b.nblon) : -1;
   if (FILL) {
     const int pos = d_slot_position(slot_cnt, slot);
-    if (regular) { const int at = slot_start[slot] + pos; if (at < cap) entries[at] = E; }
+    if (regular) { const int at = slot_start[slot] + pos; if ((unsigned)at < (unsigned)cap) entries[at] = E; }
   } else if (regular)
     atomicAdd(&slot_cnt[slot], 1);
   // wide cells go into the per-row lists of every row they span.  Neighbouring cells of a grid row span the same rows, so a
@@ -277,8 +323,53 @@ __global__ __launch_bounds__(256) void k_bin_build(int ncells, FgCells c, FgBins
   for (int it = 0; it < maxrows; it++) {
     const int key = (it < nrows) ? nbins + r0 + it : -1;
     const int pos = d_slot_position(slot_cnt, key);
-    if (FILL && key >= 0) { const int at = slot_start[key] + pos; if (at < cap) entries[at] = E; }
+    if (FILL && key >= 0) { const int at = slot_start[key] + pos; if ((unsigned)at < (unsigned)cap) entries[at] = E; }
   }
+}
+
+// Source tiles (blocks [0, nbS)) and the destination tile (the rest) in one launch.  Source blocks also store the index of
+// each cell inside one level of the field array (order 1: no halo, index == s; order 2: 1-cell halo per tile,
+// fregrid_util.c:2137-2145); destination blocks count their cells into the bins; block 0 stores the tile descriptors.
+__global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst,
+                                                       int nbS, FgCells S, FgCells D, FgBins b, int *slot_cnt, int order, int *src_idx_f,
+                                                       unsigned *err)
+{
+  __shared__ double vtile[256 * 17];
+  __shared__ FgTile sh_tiles[FG_TILESET_MAX];
+  if (ts.n && (int)threadIdx.x < ts.n) sh_tiles[threadIdx.x] = ts.t[threadIdx.x];
+  d_load_trig_table();                                   // (barrier inside)
+  const FgTile *tiles = ts.n ? sh_tiles : tiles_in;
+  if (ts.n && blockIdx.x == 0 && (int)threadIdx.x < ts.n) tiles_out[threadIdx.x] = sh_tiles[threadIdx.x];
+  const bool isD = (int)blockIdx.x >= nbS;
+  double box[5] = {0, 0, 0, 0, 0};
+  int tl = 0;
+  if (!isD) {
+    const int s0 = blockIdx.x * 256, s = s0 + threadIdx.x;
+    (void)d_cell_record(tiles, ntiles, nsrc, S, err, s0, vtile, box, &tl);
+    if (s < nsrc && src_idx_f) {
+      if (order != 2) src_idx_f[s] = s;
+      else {
+        int foff = 0;
+        for (int t = 0; t < tl; t++) foff += (tiles[t].nx + 2) * (tiles[t].ny + 2);
+        const int loc = s - tiles[tl].cell_off, i = loc % tiles[tl].nx, j = loc / tiles[tl].nx;
+        src_idx_f[s] = foff + (j + 1) * (tiles[tl].nx + 2) + i + 1;
+      }
+    }
+  } else {
+    const int d0 = ((int)blockIdx.x - nbS) * 256, d = d0 + threadIdx.x;
+    const int nv = d_cell_record(tiles + ntiles, 1, ndst, D, err, d0, vtile, box, &tl);
+    d_bin_insert<false>(d < ndst && nv != 0, d, box[0], box[1], box[2], box[3], box[4], b, slot_cnt, nullptr, nullptr, 0);
+  }
+}
+
+// stand-alone bin count for searches whose cell records come from another kernel (great circle)
+__global__ __launch_bounds__(256) void k_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt)
+{
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = d < ncells && c.nv[d] != 0;      // (no early return: the slot positions are a wave-wide operation)
+  double v[5] = {0, 0, 0, 0, 0};
+  if (live) { v[0] = c.lat_min[d]; v[1] = c.lat_max[d]; v[2] = c.lon_min[d]; v[3] = c.lon_max[d]; v[4] = c.lon_avg[d]; }
+  d_bin_insert<false>(live, d, v[0], v[1], v[2], v[3], v[4], b, slot_cnt, nullptr, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -306,8 +397,8 @@ __device__ __forceinline__ SrcQuery d_src_query(double lat_min, double lat_max, 
   return q;
 }
 
-// size of the query: bins scanned (a bin holds ~2 cells: bins are 1.5x the mean cell) plus the entries of
-// the wide lists of its rows (two table loads).  Only used to route huge queries to the wave-per-cell kernel.
+// size of the query: bins scanned (a bin holds ~2 cells: bins are 1.25x the mean cell) plus the entries of
+// the wide lists of its rows (two table loads).  Only used to route huge queries to the wave-per-cell path.
 __device__ __forceinline__ int d_query_size(const SrcQuery &q, FgBins b, const int *slot_start)
 {
   const int nbins = b.nblat * b.nblon;
@@ -329,142 +420,219 @@ __device__ __forceinline__ bool d_box_pass(const FgBinEntry &E, double lat_in_mi
 
 #define HEAVY_ENTRIES 32      // scanned bins + wide entries above which a source cell gets a whole wave (measured: 16 / 24 / 32 / 64 / 128
                               // give 0.31 / 0.27 / 0.28 / 0.305 / 0.38 ms for the candidate phase at C384 -> 0.25 deg; the lanes with the
-                              // longest scans set the duration of the four-lanes-per-cell kernel)
+                              // longest scans set the duration of the four-lanes-per-cell path)
 #define CAND_G 4          // lanes per source cell in the candidate scan (one bin row each)
+#define HEAVY_BLOCKS 2048 // waves serving the listed cells, appended to the grid of the four-lanes-per-cell blocks
 
-// CAND_G lanes per source cell, each scanning every CAND_G-th bin row of the cell's query.  Counts and
-// offsets are kept per lane (index s*CAND_G + sub) so the fill pass needs no second counting sweep:
-//   FILL == false: cand_cnt[s*G+sub] = number of destination cells passing the rejects in this lane's rows;
-//                  cells whose query touches more than HEAVY_ENTRIES table entries are appended to
-//                  heavy_list instead (k_candidates_heavy gives them a whole wave and writes cand_cnt[s*G]).
-//   FILL == true:  write the pairs at cand_off[s*G+sub]...
-//   stage[s*G+sub]: the first four destination cells the counting pass found, so that a lane with at most four (the common
-//                  case: 5.2 pairs per source cell over four lanes) copies them in the fill pass instead of scanning the
-//                  bins again; x = -2 marks a heavy cell.  Lanes with more than four rescan, in the same order, so the pair
-//                  list is the one the plain two-pass scheme writes.  (Staging a whole cell's list and sending every
-//                  overflow to the wave-per-cell kernel was measured too: no faster at C384 -> 0.25 deg, 45 % slower for
-//                  coarse -> fine grids, where most cells overflow.)
-// (one wave per block: a block gives its slots back when its slowest wave is done, and the scan lengths vary a lot --
-// measured 256 / 128 / 64 threads: 0.240 / 0.230 / 0.224 ms for the phase)
-template <bool FILL>
-__global__ __launch_bounds__(64) void k_candidates(int nsrc, FgCells S, const double *mask, FgBins b,
-                                                     const int *slot_start, const FgBinEntry *entries,
-                                                     int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                                                     int *heavy_list, int *heavy_cnt, int cap, int4 *stage, int ecap)
+__device__ __forceinline__ bool d_src_active(const FgCells &S, const double *mask, int s)
 {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int s = (int)(t / CAND_G), sub = (int)(t % CAND_G);
-  if (s >= nsrc) return;
-  int cnt = 0;
-  int id0 = -1, id1 = -1, id2 = -1, id3 = -1;
-  if (FILL) {
-    const int4 sg = stage[t];
-    if (sg.x == -2) return;                              // heavy cell: k_candidates_heavy writes its pairs
-    const int n = cand_cnt[t];
-    if (n == 0) return;
-    if (n <= 4) {
-      const int wbase = cand_off[t];
-      const int ids[4] = {sg.x, sg.y, sg.z, sg.w};
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (k < n && wbase + k < cap) { pair_src[wbase + k] = s; pair_dst[wbase + k] = ids[k]; }
-      return;
-    }
-  }
   bool active = S.nv[s] > 0;
   if (active && mask) active = mask[s] > 0.5;          // MASK_THRESH, create_xgrid.c:1030
-  if (active) {
-    const double lat_in_min = S.lat_min[s], lat_in_max = S.lat_max[s];
-    const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
-    SrcQuery q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
-    if (!FILL && d_query_size(q, b, slot_start) > HEAVY_ENTRIES) {
-      if (sub == 0) { int h = atomicAdd(heavy_cnt, 1); heavy_list[h] = s; }
-      else cand_cnt[t] = 0;                            // cand_cnt[s*G] comes from the heavy kernel
-      stage[t] = make_int4(-2, 0, 0, 0);
-      return;
+  return active;
+}
+
+// Bin fill (blocks [0, nbD): destination cells -> their bin records) and, in the same launch, the list of the source cells
+// whose query touches more than HEAVY_ENTRIES table entries (blocks [nbD, ...): one atomic per wave that has any).
+__global__ __launch_bounds__(256) void k_bin_fill(int ndst, int nbD, FgCells D, FgBins b, int *slot_fill, const int *slot_start,
+                                                   FgBinEntry *entries, int cap, int nsrc, FgCells S, const double *mask,
+                                                   int *heavy_list, int *heavy_cnt)
+{
+  if ((int)blockIdx.x < nbD) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const bool live = d < ndst && D.nv[d] != 0;
+    double v[5] = {0, 0, 0, 0, 0};
+    if (live) { v[0] = D.lat_min[d]; v[1] = D.lat_max[d]; v[2] = D.lon_min[d]; v[3] = D.lon_max[d]; v[4] = D.lon_avg[d]; }
+    d_bin_insert<true>(live, d, v[0], v[1], v[2], v[3], v[4], b, slot_fill, slot_start, entries, cap);
+    return;
+  }
+  const int s = ((int)blockIdx.x - nbD) * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  bool heavy = false;
+  if (s < nsrc && d_src_active(S, mask, s)) {
+    const SrcQuery q = d_src_query(S.lat_min[s], S.lat_max[s], S.lon_min[s], S.lon_max[s], b);
+    heavy = d_query_size(q, b, slot_start) > HEAVY_ENTRIES;
+  }
+  const unsigned long long m = __ballot(heavy);
+  if (m) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(heavy_cnt, __popcll(m));
+    base = __shfl(base, 0);
+    if (heavy) heavy_list[base + __popcll(m & ((1ull << lane) - 1ull))] = s;
+  }
+}
+
+// One wave per listed source cell (pole caps of the source grid: their longitude range covers hundreds of bins); lanes
+// stride the contiguous entry ranges, ballot + popcount compacts.  FILL = false counts, FILL = true writes at most `limit`
+// pairs from position wbase on.
+template <bool FILL>
+__device__ __forceinline__ int d_heavy_scan(const SrcQuery &q, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
+                                            double lat_in_min, double lat_in_max, double lon_in_min, double lon_in_max, double lon_in_avg,
+                                            int s, int *pair_src, int *pair_dst, int wbase, int limit)
+{
+  const int lane = threadIdx.x & 63;
+  const int nbins = b.nblat * b.nblon;
+  int cnt = 0;
+  const int nrows_reg = q.rb - q.ra + 1, nrows_wide = q.r1 - q.r0 + 1;
+  for (int it = 0; it < 2 * nrows_reg + nrows_wide; it++) {
+    int e0, e1, wide_row = -1;
+    if (it < 2 * nrows_reg) {
+      int r = q.ra + (it >> 1), seg = it & 1, base = r * b.nblon;
+      if (seg && !q.n1) continue;
+      e0 = seg ? slot_start[base] : slot_start[base + q.c_start];
+      e1 = seg ? slot_start[base + q.n1] : slot_start[base + q.c_start + q.n0];
+    } else {
+      wide_row = q.r0 + (it - 2 * nrows_reg);
+      e0 = slot_start[nbins + wide_row]; e1 = slot_start[nbins + wide_row + 1];
     }
-    const int wbase = FILL ? cand_off[t] : 0;
-    const int nbins = b.nblat * b.nblon;
-    for (int r = q.ra + sub; r <= q.rb; r += CAND_G) {
-      int base = r * b.nblon;
-      for (int seg = 0; seg < 2; seg++) {
-        if (seg && !q.n1) break;
-        int e0 = seg ? slot_start[base] : slot_start[base + q.c_start];
-        int e1 = seg ? slot_start[base + q.n1] : slot_start[base + q.c_start + q.n0];
-        e1 = min(e1, ecap);                              // a single-sync search may have outgrown its record buffer (it is then repeated)
+    e1 = min(e1, ecap);
+    for (int eb = e0; eb < e1; eb += 64) {
+      int e = eb + lane;
+      bool pass = false;
+      int dcell = 0;
+      if (e < e1) {
+        const FgBinEntry E = entries[e];
+        dcell = E.d;
+        pass = d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg);
+        if (wide_row >= 0 && wide_row != max(q.r0, E.row0)) pass = false;
+      }
+      unsigned long long m = __ballot(pass);
+      if (FILL && pass) {
+        const int k = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (k < limit) { pair_src[wbase + k] = s; pair_dst[wbase + k] = dcell; }
+      }
+      cnt += __popcll(m);
+    }
+  }
+  return cnt;
+}
+
+// Blocks [0, nbR): CAND_G lanes per source cell, each scanning every CAND_G-th bin row of the cell's query.  A lane keeps
+// the first four destination cells it finds (the common case: 5.2 pairs per source cell over four lanes); the wave then adds
+// up its lanes' counts, reserves that many entries of its region of the pair list with ONE atomic, and every lane writes its
+// pairs -- from registers, or, with more than four, by scanning its rows again (same order).  The pairs of a source cell
+// are contiguous: pair_beg / pair_cnt.  Blocks [nbR, nbR + HEAVY_BLOCKS): a wave per listed cell (count, reserve, fill).
+// (one wave per block: a block gives its slots back when its slowest wave is done, and the scan lengths vary a lot --
+// measured 256 / 128 / 64 threads: 0.240 / 0.230 / 0.224 ms for the old count pass)
+__global__ __launch_bounds__(64) void k_candidates1(int nsrc, int nbR, FgCells S, const double *mask, FgBins b, const int *slot_start,
+                                                     const FgBinEntry *entries, int ecap, FgPairSpace ps, int *pair_beg, int *pair_cnt,
+                                                     const int *heavy_list, const int *heavy_cnt)
+{
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= nbR) {
+    const int nheavy = *heavy_cnt, H = gridDim.x - nbR;
+    for (int h = blockIdx.x - nbR; h < nheavy; h += H) {
+      const int s = heavy_list[h];
+      const double lat_in_min = S.lat_min[s], lat_in_max = S.lat_max[s];
+      const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
+      const SrcQuery q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
+      const int cnt = d_heavy_scan<false>(q, b, slot_start, entries, ecap, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg,
+                                          s, nullptr, nullptr, 0, 0);
+      const int r = s % ps.nreg;                          // by cell, not by list position: the list order varies from run to run
+      unsigned base = 0;
+      if (lane == 0 && cnt) base = atomicAdd(&ps.fill[r * FG_FILL_STRIDE], (unsigned)cnt);
+      base = __shfl(base, 0);
+      const int loc0 = (int)min(base, (unsigned)ps.regcap), n_ok = min(cnt, ps.regcap - loc0);
+      const int wbase = r * ps.regcap + loc0;
+      if (n_ok > 0)
+        (void)d_heavy_scan<true>(q, b, slot_start, entries, ecap, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg,
+                                 s, ps.src, ps.dst, wbase, n_ok);
+      if (lane == 0) { pair_beg[s] = wbase; pair_cnt[s] = n_ok; }
+    }
+    return;
+  }
+  const long t = (long)blockIdx.x * 64 + lane;
+  const int s = (int)(t / CAND_G), sub = (int)(t % CAND_G);
+  int cnt = 0;
+  int id0 = -1, id1 = -1, id2 = -1, id3 = -1;
+  bool heavy = false;
+  double lat_in_min = 0, lat_in_max = 0, lon_in_min = 0, lon_in_max = 0, lon_in_avg = 0;
+  SrcQuery q{};
+  const int nbins = b.nblat * b.nblon;
+  if (s < nsrc && d_src_active(S, mask, s)) {
+    lat_in_min = S.lat_min[s]; lat_in_max = S.lat_max[s];
+    lon_in_min = S.lon_min[s]; lon_in_max = S.lon_max[s]; lon_in_avg = S.lon_avg[s];
+    q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
+    heavy = d_query_size(q, b, slot_start) > HEAVY_ENTRIES;       // listed by k_bin_fill; a whole wave writes its pairs
+    if (!heavy) {
+      for (int r = q.ra + sub; r <= q.rb; r += CAND_G) {
+        int base = r * b.nblon;
+        for (int seg = 0; seg < 2; seg++) {
+          if (seg && !q.n1) break;
+          int e0 = seg ? slot_start[base] : slot_start[base + q.c_start];
+          int e1 = seg ? slot_start[base + q.n1] : slot_start[base + q.c_start + q.n0];
+          e1 = min(e1, ecap);                              // a search may have outgrown its record buffer (it is then repeated)
+          for (int e = e0; e < e1; e++) {
+            const FgBinEntry E = entries[e];
+            if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
+            id0 = cnt == 0 ? E.d : id0; id1 = cnt == 1 ? E.d : id1; id2 = cnt == 2 ? E.d : id2; id3 = cnt == 3 ? E.d : id3;
+            cnt++;
+          }
+        }
+      }
+      for (int r = q.r0 + sub; r <= q.r1; r += CAND_G) {
+        int e0 = slot_start[nbins + r], e1 = min(slot_start[nbins + r + 1], ecap);
         for (int e = e0; e < e1; e++) {
           const FgBinEntry E = entries[e];
+          if (r != max(q.r0, E.row0)) continue;          // a wide cell sits in every row it spans
           if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
-          if (FILL && wbase + cnt < cap) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = E.d; }
-          if (!FILL) { id0 = cnt == 0 ? E.d : id0; id1 = cnt == 1 ? E.d : id1; id2 = cnt == 2 ? E.d : id2; id3 = cnt == 3 ? E.d : id3; }
+          id0 = cnt == 0 ? E.d : id0; id1 = cnt == 1 ? E.d : id1; id2 = cnt == 2 ? E.d : id2; id3 = cnt == 3 ? E.d : id3;
           cnt++;
         }
       }
     }
-    for (int r = q.r0 + sub; r <= q.r1; r += CAND_G) {
-      int e0 = slot_start[nbins + r], e1 = min(slot_start[nbins + r + 1], ecap);
+  }
+  // the wave's range in its region of the pair list
+  const unsigned incl = wave_incl_scan((unsigned)cnt, lane);
+  const unsigned total = __shfl(incl, 63);
+  const unsigned excl = incl - (unsigned)cnt;
+  const int r = blockIdx.x % ps.nreg;
+  unsigned base = 0;
+  if (lane == 0 && total) base = atomicAdd(&ps.fill[r * FG_FILL_STRIDE], total);
+  base = __shfl(base, 0);
+  // per source cell: first pair and number of pairs (entries beyond the region are dropped; the search is then repeated)
+  int c4 = cnt;
+  c4 += __shfl_xor(c4, 1); c4 += __shfl_xor(c4, 2);
+  const unsigned excl0 = __shfl(excl, lane & ~(CAND_G - 1));
+  if (sub == 0 && s < nsrc && !heavy) {
+    const unsigned first = base + excl0;
+    const int loc0 = (int)min(first, (unsigned)ps.regcap);
+    pair_beg[s] = r * ps.regcap + loc0;
+    pair_cnt[s] = min(c4, ps.regcap - loc0);
+  }
+  if (cnt == 0) return;
+  const unsigned wloc = base + excl;                    // this lane's first entry within the region
+  int *psrc = ps.src + (size_t)r * ps.regcap, *pdst = ps.dst + (size_t)r * ps.regcap;
+  if (cnt <= 4) {
+    const int ids[4] = {id0, id1, id2, id3};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < cnt && wloc + k < (unsigned)ps.regcap) { psrc[wloc + k] = s; pdst[wloc + k] = ids[k]; }
+    return;
+  }
+  int w = 0;
+  for (int rr = q.ra + sub; rr <= q.rb; rr += CAND_G) {
+    int rb = rr * b.nblon;
+    for (int seg = 0; seg < 2; seg++) {
+      if (seg && !q.n1) break;
+      int e0 = seg ? slot_start[rb] : slot_start[rb + q.c_start];
+      int e1 = seg ? slot_start[rb + q.n1] : slot_start[rb + q.c_start + q.n0];
+      e1 = min(e1, ecap);
       for (int e = e0; e < e1; e++) {
         const FgBinEntry E = entries[e];
-        if (r != max(q.r0, E.row0)) continue;          // a wide cell sits in every row it spans
         if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
-        if (FILL && wbase + cnt < cap) { pair_src[wbase + cnt] = s; pair_dst[wbase + cnt] = E.d; }
-        if (!FILL) { id0 = cnt == 0 ? E.d : id0; id1 = cnt == 1 ? E.d : id1; id2 = cnt == 2 ? E.d : id2; id3 = cnt == 3 ? E.d : id3; }
-        cnt++;
+        if (wloc + w < (unsigned)ps.regcap) { psrc[wloc + w] = s; pdst[wloc + w] = E.d; }
+        w++;
       }
     }
   }
-  if (!FILL) { cand_cnt[t] = cnt; stage[t] = make_int4(id0, id1, id2, id3); }
-}
-
-// One wave per heavy source cell (pole caps of the source grid: their longitude range covers
-// hundreds of bins); lanes stride the contiguous entry ranges, ballot + popcount compacts.
-template <bool FILL>
-__global__ __launch_bounds__(64) void k_candidates_heavy(FgCells S, FgBins b, const int *slot_start, const FgBinEntry *entries,
-                                                          int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                                                          const int *heavy_list, const int *heavy_cnt, int cap, int ecap)
-{
-  const int lane = threadIdx.x;
-  const int nheavy = *heavy_cnt;
-  const int nbins = b.nblat * b.nblon;
-  for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
-    const int s = heavy_list[h];
-    const double lat_in_min = S.lat_min[s], lat_in_max = S.lat_max[s];
-    const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
-    SrcQuery q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
-    const int wbase = FILL ? cand_off[s * CAND_G] : 0;
-    int cnt = 0;
-    const int nrows_reg = q.rb - q.ra + 1, nrows_wide = q.r1 - q.r0 + 1;
-    for (int it = 0; it < 2 * nrows_reg + nrows_wide; it++) {
-      int e0, e1, wide_row = -1;
-      if (it < 2 * nrows_reg) {
-        int r = q.ra + (it >> 1), seg = it & 1, base = r * b.nblon;
-        if (seg && !q.n1) continue;
-        e0 = seg ? slot_start[base] : slot_start[base + q.c_start];
-        e1 = seg ? slot_start[base + q.n1] : slot_start[base + q.c_start + q.n0];
-      } else {
-        wide_row = q.r0 + (it - 2 * nrows_reg);
-        e0 = slot_start[nbins + wide_row]; e1 = slot_start[nbins + wide_row + 1];
-      }
-      e1 = min(e1, ecap);
-      for (int eb = e0; eb < e1; eb += 64) {
-        int e = eb + lane;
-        bool pass = false;
-        int dcell = 0;
-        if (e < e1) {
-          const FgBinEntry E = entries[e];
-          dcell = E.d;
-          pass = d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg);
-          if (wide_row >= 0 && wide_row != max(q.r0, E.row0)) pass = false;
-        }
-        unsigned long long m = __ballot(pass);
-        if (FILL && pass) {
-          int pos = wbase + cnt + __popcll(m & ((1ull << lane) - 1ull));
-          if (pos < cap) { pair_src[pos] = s; pair_dst[pos] = dcell; }
-        }
-        cnt += __popcll(m);
-      }
+  for (int rr = q.r0 + sub; rr <= q.r1; rr += CAND_G) {
+    int e0 = slot_start[nbins + rr], e1 = min(slot_start[nbins + rr + 1], ecap);
+    for (int e = e0; e < e1; e++) {
+      const FgBinEntry E = entries[e];
+      if (rr != max(q.r0, E.row0)) continue;
+      if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
+      if (wloc + w < (unsigned)ps.regcap) { psrc[wloc + w] = s; pdst[wloc + w] = E.d; }
+      w++;
     }
-    if (!FILL && lane == 0) cand_cnt[s * CAND_G] = cnt;
   }
 }
 
@@ -594,48 +762,40 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
 }
 
 // Result encoding shared by the clip kernels and the compaction: an accepted pair keeps pair_dst[p] = d and
-// gets tmp_area/clon/clat[p]; a rejected pair gets pair_dst[p] = -1.  nacc[s] counts the accepted pairs of
-// source cell s: lanes are pair-ordered, so one atomic per (wave, source cell) run does it.
+// gets tmp_area/clon/clat[p]; a rejected pair gets pair_dst[p] = -1.
 template <int ORDER>
-__global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(int npairs, const int *pair_src, int *pair_dst,
-                                                            FgCells S, const double *mask, FgCells D,
+__global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
                                                             double *tmp_area, double *tmp_clon, double *tmp_clat,
-                                                            int *nacc, int *defer_list, int *defer_cnt,
-                                                            unsigned long long *stats, unsigned *err, const unsigned long long *np_dev)
+                                                            int *defer_list, int *defer_cnt,
+                                                            unsigned long long *stats, unsigned *err)
 {
   __shared__ double2 sh_poly[8][CLIP_THREADS];
   d_load_trig_table();
   const int tid = threadIdx.x, lane = tid & 63;
   const int p = blockIdx.x * CLIP_THREADS + tid;
-  if (np_dev) { const unsigned long long nd = *np_dev; if (nd < (unsigned long long)npairs) npairs = (int)nd; }   // launched for the capacity
-  int s = -1;
-  bool acc = false;
-  if (p < npairs) {
-    s = pair_src[p];
-    const int d = pair_dst[p];
+  bool defer = false, below = false;
+  if (d_pair_live(ps, p)) {
+    const int s = ps.src[p];
+    const int d = ps.dst[p];
     ClipOut o;
-    if (!d_clip_quad_pair<ORDER>(sh_poly, tid, s, d, S, mask, D, &o, stats, err)) {
-      int q = atomicAdd(defer_cnt, 1); defer_list[q] = p;      // rare; the general kernel finishes this pair
-    } else if (o.area >= 0) {
-      acc = true;
+    if (!d_clip_quad_pair<ORDER>(sh_poly, tid, s, d, S, mask, D, &o, stats, err)) defer = true;   // rare; the general kernel finishes this pair
+    else if (o.area >= 0) {
       tmp_area[p] = o.area;
       if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
     } else {
-      pair_dst[p] = -1;
-      if (o.area == -2.0) atomicAdd(&stats[FG_STAT_BELOW], 1ull);   // rare (slivers below the 1e-6 ratio)
+      ps.dst[p] = -1;
+      below = (o.area == -2.0);                                  // rare (slivers below the 1e-6 ratio)
     }
   }
-  // segmented count of accepted lanes per run of equal s inside the wave
-  const int s_prev = __shfl_up(s, 1, 64);
-  const bool head = (lane == 0) || (s != s_prev);
-  const unsigned long long hm = __ballot(head), am = __ballot(acc);
-  if (head && s >= 0) {
-    const unsigned long long above = (lane == 63) ? 0ull : (hm >> (lane + 1)) << (lane + 1);
-    const int end = above ? (__ffsll((long long)above) - 1) : 64;
-    const unsigned long long upto = (end == 64) ? ~0ull : ((1ull << end) - 1ull);
-    const int cnt = __popcll(am & upto & ~((1ull << lane) - 1ull));
-    if (cnt) atomicAdd(&nacc[s], cnt);
+  // one atomic per wave that has deferred pairs / slivers (value-returning same-address atomics serialise at ~12 ns each)
+  const unsigned long long dm = __ballot(defer), bm = __ballot(below);
+  if (dm) {
+    int q = 0;
+    if (lane == 0) q = atomicAdd(defer_cnt, __popcll(dm));
+    q = __shfl(q, 0);
+    if (defer) defer_list[q + __popcll(dm & ((1ull << lane) - 1ull))] = p;
   }
+  if (bm && lane == 0) atomicAdd(&stats[FG_STAT_BELOW], (unsigned long long)__popcll(bm));
 }
 
 // General path: up to 8 x 8 vertices, intermediate polygons up to 16.  One wave per block,
@@ -646,7 +806,7 @@ template <int ORDER>
 __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_list, const int *defer_cnt,
                                                               const int *pair_src, int *pair_dst,
                                                               FgCells S, const double *mask, FgCells D,
-                                                              double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
+                                                              double *tmp_area, double *tmp_clon, double *tmp_clat,
                                                               unsigned long long *stats, unsigned *err)
 {
   __shared__ double2 sh_a[GEN_CAP][GEN_THREADS];
@@ -728,7 +888,6 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
     if (o.area >= 0) {
       tmp_area[p] = o.area;
       if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
-      atomicAdd(&nacc[s], 1);
     } else {
       pair_dst[p] = -1;
       if (o.area == -2.0) atomicAdd(&stats[FG_STAT_BELOW], 1ull);
@@ -737,154 +896,223 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
 }
 
 // ---------------------------------------------------------------------------------------
-// compaction into canonical order
+// compaction into canonical order + per-source-cell sums
 // ---------------------------------------------------------------------------------------
-// Rank of every accepted pair of a heavy source cell among that cell's accepted pairs, by destination index (the canonical
-// order inside a source cell).  k_scatter_xcells ranks a pair by comparing it with all the others of its cell, which is
-// quadratic: fine for 5 pairs, but a source cell at a pole of the target grid holds thousands (great-circle search: ~3000 in
-// each of ~600 cells, which was 0.4 ms).  Here a block marks the cell's destination indices in an LDS bitmap over their span
-// and reads each rank off as a prefix population count: linear.  rank = -1 where the span does not fit (scatter falls back).
+// A block owns 256 consecutive source cells (tile = ticket order).  Phases:
+//   1. every cell counts its accepted pairs (pair_dst >= 0); cells with more than CP_SMALL pairs ("big": the cells around a
+//      pole of the target grid, every cell of a coarse -> fine remap) are counted by the block's waves in turn and appended
+//      to big_list for k_compact_big;
+//   2. block scan of the counts, look-back over the preceding tiles -> xoff[s] (the reference's running nxgrid);
+//   3. small cells: rank of each accepted pair among its cell's accepted pairs by destination index (the reference's ij
+//      loop), staged as a permutation in LDS so that the exchange cells leave in one coalesced sweep; the sweep also takes
+//      each exchange cell's slot in its destination row (x_rowpos) and thereby counts the CSR row sizes;
+//   4. small cells (order 2): sums of (area, clon, clat) in exchange-cell order, conserve_interp.c:216-221.
+// Nothing depends on the order in which the candidate kernel filled the pair list.
+#define CP_CAP 4096          // output positions staged per sweep
+#define CP_SMALL 32          // pairs per cell handled by the cell's own thread
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_compact(int nsrc, FgPairSpace ps, FgCompactIo io)
+{
+  __shared__ int sh_p[CP_CAP];
+  __shared__ unsigned short sh_c[CP_CAP];
+  __shared__ int sh_beg[256], sh_cnt[256], sh_nab[256], sh_bigl[256];
+  __shared__ int sh_tile, sh_nbig, sh_bigbase;
+  __shared__ unsigned long long sh_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { sh_tile = (int)atomicAdd(io.ticket, 1u); sh_nbig = 0; }
+  __syncthreads();
+  const int tile = sh_tile, s0 = tile * 256, s = s0 + tid;
+  if (tile == 0 && tid < 64) {                         // candidate totals for the host's capacity checks
+    unsigned long long f = 0; unsigned mx = 0;
+    for (int r = tid; r < ps.nreg; r += 64) { const unsigned v = ps.fill[r * FG_FILL_STRIDE]; f += v; mx = max(mx, v); }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { f += __shfl_xor(f, o); mx = max(mx, (unsigned)__shfl_xor((int)mx, o)); }
+    if (tid == 0) { io.dc->total[1] = f; io.dc->total[3] = mx; }
+  }
+  int beg = 0, cnt = 0;
+  if (s < nsrc) { beg = io.pair_beg[s]; cnt = io.pair_cnt[s]; }
+  const bool big = cnt > CP_SMALL;
+  int dv[8];
+  int na = 0;
+  if (!big) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { dv[k] = (k < cnt) ? ps.dst[beg + k] : -1; na += (dv[k] >= 0) ? 1 : 0; }
+    for (int k = 8; k < cnt; k++) na += (ps.dst[beg + k] >= 0) ? 1 : 0;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) dv[k] = -1;
+    const int q = atomicAdd(&sh_nbig, 1);
+    sh_bigl[q] = tid;
+  }
+  sh_beg[tid] = beg; sh_cnt[tid] = cnt;
+  __syncthreads();
+  const int nbig = sh_nbig;
+  for (int q = wave; q < nbig; q += 4) {
+    const int t = sh_bigl[q], b0 = sh_beg[t], c = sh_cnt[t];
+    int m = 0;
+    for (int k = lane; k < c; k += 64) m += (ps.dst[b0 + k] >= 0) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m += __shfl_xor(m, o);
+    if (lane == 0) sh_nab[t] = m;
+  }
+  if (tid == 0 && nbig) sh_bigbase = atomicAdd(&io.dc->big_cnt, nbig);
+  __syncthreads();
+  if (big) na = sh_nab[tid];
+  unsigned tot;
+  const int loc = (int)block_incl_scan((unsigned)na, &tot) - na;
+  if (wave == 0) {
+    const unsigned long long e = d_lookback_wave(io.lb_status, tile, (unsigned long long)tot, io.dc->err);
+    if (lane == 0) sh_base = e;
+  }
+  __syncthreads();
+  const unsigned long long base = sh_base;
+  if (s < nsrc) io.xoff[s] = (int)(base + loc);
+  if (tid == 0 && s0 + 256 >= nsrc) { io.xoff[nsrc] = (int)(base + tot); io.dc->total[2] = base + tot; }
+  for (int q = tid; q < nbig; q += 256) io.big_list[sh_bigbase + q] = s0 + sh_bigl[q];
+  // small cells: ranks -> permutation in LDS -> coalesced sweep; big cells leave holes for k_compact_big
+  for (int w0 = 0; w0 < (int)tot; w0 += CP_CAP) {
+    const int wn = min(CP_CAP, (int)tot - w0);
+    for (int j = tid; j < wn; j += 256) sh_p[j] = -1;
+    __syncthreads();
+    if (!big && na > 0 && loc < w0 + wn && loc + na > w0) {
+      if (cnt <= 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (dv[k] >= 0) {
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) rank += ((unsigned)dv[j] < (unsigned)dv[k]) ? 1 : 0;     // rejected entries are 0xffffffff
+            const int at = loc + rank - w0;
+            if (at >= 0 && at < wn) { sh_p[at] = beg + k; sh_c[at] = (unsigned short)tid; }
+          }
+        }
+      } else {
+        for (int k = 0; k < cnt; k++) {
+          const int d = ps.dst[beg + k];
+          if (d < 0) continue;
+          int rank = 0;
+          for (int j = 0; j < cnt; j++) rank += ((unsigned)ps.dst[beg + j] < (unsigned)d) ? 1 : 0;
+          const int at = loc + rank - w0;
+          if (at >= 0 && at < wn) { sh_p[at] = beg + k; sh_c[at] = (unsigned short)tid; }
+        }
+      }
+    }
+    __syncthreads();
+    for (int j = tid; j < wn; j += 256) {
+      const int p = sh_p[j];
+      if (p < 0) continue;
+      const long pos = (long)base + w0 + j;
+      if (pos >= io.xcap) continue;
+      const int d = ps.dst[p];
+      io.x_src[pos] = s0 + sh_c[j];
+      io.x_dst[pos] = d;
+      io.x_area[pos] = io.tmp_area[p];
+      if (ORDER == 2) { io.x_c1[pos] = io.tmp_clon[p]; io.x_c2[pos] = io.tmp_clat[p]; }
+      // destination-row sizes for the CSR build and this cell's slot in its row
+      io.x_rowpos[pos] = atomicAdd(&io.row_cnt[d], 1);
+    }
+    __syncthreads();
+  }
+  if (ORDER == 2 && io.sums && s < nsrc && !big) {
+    // the block's own stores, read back after the barrier above: additions in exchange-cell order, loads 8 ahead
+    double a = 0, l = 0, t = 0;
+    const long o = (long)base + loc;
+    const int c = (o + na <= io.xcap) ? na : 0;
+    int k = 0;
+    for (; k + 8 <= c; k += 8) {
+      double va[8], vl[8], vt[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { va[u] = io.x_area[o + k + u]; vl[u] = io.x_c1[o + k + u]; vt[u] = io.x_c2[o + k + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { a += va[u]; l += vl[u]; t += vt[u]; }
+    }
+    for (; k < c; k++) { a += io.x_area[o + k]; l += io.x_c1[o + k]; t += io.x_c2[o + k]; }
+    io.sums[s] = a; io.sums[nsrc + s] = l; io.sums[2 * (size_t)nsrc + s] = t;
+  }
+}
+
+// The big cells: a block per cell.  Ranking a pair by comparing it with all the others of its cell is quadratic (great-circle
+// search: ~3000 pairs in each of ~600 cells); here the block marks the cell's destination indices in an LDS bitmap over their
+// span and reads each rank off as a prefix population count: linear.  Spans that do not fit fall back to the comparison.
 #define RANK_WORDS 2048      // 131072 destination indices: 91 rows of a 1440-column grid
-#define RANK_MIN 64          // pairs of a heavy-list cell from which the bitmap pays (the list also holds cells with few pairs)
-__global__ __launch_bounds__(256) void k_rank_heavy(const int *heavy_list, const int *heavy_cnt, const int *cand_off,
-                                                    const int *pair_dst, int *pair_rank, int cap)
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_compact_big(int nsrc, FgPairSpace ps, FgCompactIo io)
 {
   __shared__ unsigned long long bits[RANK_WORDS];
   __shared__ int pref[RANK_WORDS];
   __shared__ int smin, smax;
-  const int nheavy = *heavy_cnt;
-  for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
-    const int s = heavy_list[h];
-    const int o = cand_off[s * CAND_G];
-    int c = cand_off[(s + 1) * CAND_G] - o;
-    if (o + c > cap) c = max(0, cap - o);                 // (an overflowing fast search is repeated anyway)
-    if (c <= RANK_MIN) continue;                          // short lists are ranked in place by k_scatter_xcells (block-uniform)
+  const int nb = io.dc->big_cnt;
+  for (int h = blockIdx.x; h < nb; h += gridDim.x) {
+    const int s = io.big_list[h];
+    const int o = io.pair_beg[s], c = io.pair_cnt[s];
+    const long x0 = io.xoff[s];
+    const int na = io.xoff[s + 1] - (int)x0;
     if (threadIdx.x == 0) { smin = 0x7fffffff; smax = -1; }
     __syncthreads();
     int lmin = 0x7fffffff, lmax = -1;
-    for (int k = threadIdx.x; k < c; k += 256) { const int d = pair_dst[o + k]; if (d >= 0) { lmin = min(lmin, d); lmax = max(lmax, d); } }
+    for (int k = threadIdx.x; k < c; k += 256) { const int d = ps.dst[o + k]; if (d >= 0) { lmin = min(lmin, d); lmax = max(lmax, d); } }
     if (lmax >= 0) { atomicMin(&smin, lmin); atomicMax(&smax, lmax); }
     __syncthreads();
     const int dmin = smin, dmax = smax;
     const long span = (long)dmax - dmin + 1;
-    if (dmax < 0 || span > (long)RANK_WORDS * 64) {
-      for (int k = threadIdx.x; k < c; k += 256) pair_rank[o + k] = -1;
+    const bool bitmap = dmax >= 0 && span <= (long)RANK_WORDS * 64;
+    if (bitmap) {
+      const int nw = (int)((span + 63) >> 6);
+      for (int w = threadIdx.x; w < nw; w += 256) bits[w] = 0ull;
       __syncthreads();
-      continue;
-    }
-    const int nw = (int)((span + 63) >> 6);
-    for (int w = threadIdx.x; w < nw; w += 256) bits[w] = 0ull;
-    __syncthreads();
-    for (int k = threadIdx.x; k < c; k += 256) {
-      const int d = pair_dst[o + k];
-      if (d >= 0) atomicOr(&bits[(d - dmin) >> 6], 1ull << ((d - dmin) & 63));
-    }
-    __syncthreads();
-    // exclusive prefix of the word populations: each thread owns a contiguous chunk of words
-    const int per = (nw + 255) / 256, w0 = threadIdx.x * per, w1 = min(nw, w0 + per);
-    int mine = 0;
-    for (int w = w0; w < w1; w++) mine += __popcll(bits[w]);
-    unsigned tot;
-    const int before = (int)block_incl_scan((unsigned)mine, &tot) - mine;
-    int run = before;
-    for (int w = w0; w < w1; w++) { pref[w] = run; run += __popcll(bits[w]); }
-    __syncthreads();
-    for (int k = threadIdx.x; k < c; k += 256) {
-      const int d = pair_dst[o + k];
-      if (d >= 0) {
-        const int w = (d - dmin) >> 6, b = (d - dmin) & 63;
-        pair_rank[o + k] = pref[w] + __popcll(bits[w] & ((1ull << b) - 1ull));
+      for (int k = threadIdx.x; k < c; k += 256) {
+        const int d = ps.dst[o + k];
+        if (d >= 0) atomicOr(&bits[(d - dmin) >> 6], 1ull << ((d - dmin) & 63));
       }
+      __syncthreads();
+      // exclusive prefix of the word populations: each thread owns a contiguous chunk of words
+      const int per = (nw + 255) / 256, w0 = threadIdx.x * per, w1 = min(nw, w0 + per);
+      int mine = 0;
+      for (int w = w0; w < w1; w++) mine += __popcll(bits[w]);
+      unsigned tot;
+      const int before = (int)block_incl_scan((unsigned)mine, &tot) - mine;
+      int run = before;
+      for (int w = w0; w < w1; w++) { pref[w] = run; run += __popcll(bits[w]); }
+      __syncthreads();
+    }
+    for (int k = threadIdx.x; k < c; k += 256) {
+      const int p = o + k;
+      const int d = ps.dst[p];
+      if (d < 0) continue;
+      int rank;
+      if (bitmap) { const int w = (d - dmin) >> 6, b = (d - dmin) & 63; rank = pref[w] + __popcll(bits[w] & ((1ull << b) - 1ull)); }
+      else { rank = 0; for (int j = 0; j < c; j++) rank += ((unsigned)ps.dst[o + j] < (unsigned)d) ? 1 : 0; }
+      const long pos = x0 + rank;
+      if (pos >= io.xcap) continue;
+      io.x_src[pos] = s; io.x_dst[pos] = d; io.x_area[pos] = io.tmp_area[p];
+      if (ORDER == 2) { io.x_c1[pos] = io.tmp_clon[p]; io.x_c2[pos] = io.tmp_clat[p]; }
+      io.x_rowpos[pos] = atomicAdd(&io.row_cnt[d], 1);
+    }
+    __syncthreads();
+    if (ORDER == 2 && io.sums && threadIdx.x < 3) {
+      // three lanes, one array each: hundreds to thousands of ordered additions, the loads 16 ahead of them
+      const double *v = (threadIdx.x == 0) ? io.x_area : ((threadIdx.x == 1) ? io.x_c1 : io.x_c2);
+      const int cc = (x0 + na <= io.xcap) ? na : 0;
+      double a = 0;
+      int k = 0;
+      for (; k + 16 <= cc; k += 16) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) t[u] = v[x0 + k + u];
+#pragma unroll
+        for (int u = 0; u < 16; u++) a += t[u];
+      }
+      for (; k < cc; k++) a += v[x0 + k];
+      io.sums[(size_t)threadIdx.x * nsrc + s] = a;
     }
     __syncthreads();
   }
-}
-
-template <int ORDER>
-__global__ __launch_bounds__(256) void k_scatter_xcells(int npairs, const int *pair_src, const int *pair_dst,
-                                                         const int *cand_off, const int *xoff,
-                                                         const double *tmp_area, const double *tmp_clon, const double *tmp_clat,
-                                                         int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                                                         int *row_cnt, int *x_rowpos, const unsigned long long *np_dev,
-                                                         const int4 *stage, const int *pair_rank)
-{
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const int cap = npairs;                           // entries the pair arrays hold
-  if (np_dev) { const unsigned long long nd = *np_dev; if (nd < (unsigned long long)npairs) npairs = (int)nd; }
-  if (p >= npairs) return;
-  const int d = pair_dst[p];                        // -1: rejected by the clip kernels
-  if (d < 0) return;
-  const int s = pair_src[p];
-  int o = cand_off[s * CAND_G], c = cand_off[(s + 1) * CAND_G] - o;
-  if (o + c > cap) c = cap - o;                       // a single-sync search that outgrew its buffers is repeated; stay inside them
-  int rank = (c > RANK_MIN && stage[(size_t)s * CAND_G].x == -2) ? pair_rank[p] : -1;    // long lists: ranked by k_rank_heavy
-  if (rank < 0) {
-    rank = 0;
-    for (int k = 0; k < c; k++)                       // destination index ascending == the reference's ij loop
-      rank += ((unsigned)pair_dst[o + k] < (unsigned)d) ? 1 : 0;    // rejected entries are 0xffffffff
-  }
-  int pos = xoff[s] + rank;
-  x_src[pos] = s; x_dst[pos] = d; x_area[pos] = tmp_area[p];
-  // destination-row sizes for the CSR build (fg_plan_finalize), and this cell's slot in its row: the value-returning atomic
-  // costs little here, where it overlaps the gathers, and saves the CSR fill pass its own (k_csr_fill_pos)
-  x_rowpos[pos] = atomicAdd(&row_cnt[d], 1);
-  if (ORDER == 2) { x_c1[pos] = tmp_clon[p]; x_c2[pos] = tmp_clat[p]; }
 }
 
 // ---------------------------------------------------------------------------------------
 // order-2 centroid pass
 // ---------------------------------------------------------------------------------------
-// sums[0..2][nsrc] over this plan's exchange cells, in exchange-cell order (conserve_interp.c:216-221)
-__global__ __launch_bounds__(256) void k_cell_sums(int nsrc, const int *xoff, const double *x_area,
-                                                    const double *x_c1, const double *x_c2, double *sums)
-{
-  // The xcells of a block's 256 consecutive source cells are one contiguous
-  // range: stage it through LDS with coalesced loads, then each thread adds
-  // its own cell's entries in canonical order (same order, same sums, as the
-  // direct loop kept below for ranges that do not fit).
-  constexpr int CAP = 2048;
-  __shared__ double sh[3][CAP];
-  int b0 = blockIdx.x * blockDim.x;
-  int b1 = min(b0 + (int)blockDim.x, nsrc);
-  int e0 = xoff[b0], n = xoff[b1] - e0;
-  int s = b0 + threadIdx.x;
-  bool staged = n <= CAP;
-  if (staged) {
-    for (int k = threadIdx.x; k < n; k += blockDim.x) {
-      sh[0][k] = x_area[e0 + k]; sh[1][k] = x_c1[e0 + k]; sh[2][k] = x_c2[e0 + k];
-    }
-    __syncthreads();
-  }
-  if (s >= nsrc) return;
-  double a = 0, l = 0, t = 0;
-  int o = xoff[s], c = xoff[s + 1] - o;
-  if (staged) {
-    int q = o - e0;
-    int k = 0;
-    for (; k + 8 <= c; k += 8) {                     // reads ahead of the ordered additions, as in the direct loop below
-      double va[8], vl[8], vt[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) { va[u] = sh[0][q + k + u]; vl[u] = sh[1][q + k + u]; vt[u] = sh[2][q + k + u]; }
-#pragma unroll
-      for (int u = 0; u < 8; u++) { a += va[u]; l += vl[u]; t += vt[u]; }
-    }
-    for (; k < c; k++) { a += sh[0][q + k]; l += sh[1][q + k]; t += sh[2][q + k]; }
-  } else {
-    // ranges that do not fit hold the cells around a pole of the target grid, with hundreds of exchange cells each: their
-    // serial chains set the duration of the whole launch, so the loads go out 16 entries ahead of the (ordered) additions
-    int k = 0;
-    for (; k + 16 <= c; k += 16) {
-      double va[16], vl[16], vt[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) { va[u] = x_area[o + k + u]; vl[u] = x_c1[o + k + u]; vt[u] = x_c2[o + k + u]; }
-#pragma unroll
-      for (int u = 0; u < 16; u++) { a += va[u]; l += vl[u]; t += vt[u]; }
-    }
-    for (; k < c; k++) { a += x_area[o + k]; l += x_c1[o + k]; t += x_c2[o + k]; }
-  }
-  sums[s] = a; sums[nsrc + s] = l; sums[2 * (size_t)nsrc + s] = t;
-}
-
 // cen[0][s], cen[1][s] = centroid lon/lat of source cell s (conserve_interp.c:327-348)
 __global__ __launch_bounds__(256) void k_centroids(int nsrc, FgCells S, const double *sums, double *cen)
 {
@@ -932,70 +1160,71 @@ void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c,
   if (ncells > 0) k_cell_struct<<<nblk(ncells, 256), 256, 0, st>>>(tiles_dev, ntiles, ncells, c, err);
 }
 
-void fgd_bin_build(bool fill, int ncells, FgCells c, FgBins b, int *slot_cnt, const int *slot_start, FgBinEntry *entries, int cap,
-                   hipStream_t st)
+void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, FgCells D,
+                      FgBins b, int *slot_cnt, int order, int *src_idx_f, unsigned *err, hipStream_t st)
 {
-  if (ncells <= 0) return;
-  if (fill) k_bin_build<true><<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, slot_cnt, slot_start, entries, cap);
-  else      k_bin_build<false><<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, slot_cnt, slot_start, entries, cap);
+  const int nbS = nblk(nsrc, 256), nbD = nblk(ndst, 256);
+  if (nbS + nbD > 0)
+    k_cell_struct2<<<nbS + nbD, 256, 0, st>>>(ts, tiles_in, tiles_out, ntiles, nsrc, ndst, nbS, S, D, b, slot_cnt, order, src_idx_f, err);
 }
 
-void fgd_candidates(bool fill, int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start,
-                    const FgBinEntry *entries, int *cand_cnt, const int *cand_off, int *pair_src, int *pair_dst,
-                    int *heavy_list, int *heavy_cnt, int cap, int *stage, int ecap, hipStream_t st)
+void fgd_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt, hipStream_t st)
+{
+  if (ncells > 0) k_bin_count<<<nblk(ncells, 256), 256, 0, st>>>(ncells, c, b, slot_cnt);
+}
+
+void fgd_bin_fill(int ndst, FgCells D, FgBins b, int *slot_fill, const int *slot_start, FgBinEntry *entries, int cap,
+                  int nsrc, FgCells S, const double *mask, int *heavy_list, int *heavy_cnt, hipStream_t st)
+{
+  const int nbD = nblk(ndst, 256), nbS = nblk(nsrc, 256);
+  if (nbD + nbS > 0)
+    k_bin_fill<<<nbD + nbS, 256, 0, st>>>(ndst, nbD, D, b, slot_fill, slot_start, entries, cap, nsrc, S, mask, heavy_list, heavy_cnt);
+}
+
+void fgd_candidates1(int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
+                     FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, hipStream_t st)
 {
   if (nsrc <= 0) return;
-  int hgrid = nblk(nsrc, 64); if (hgrid > 8192) hgrid = 8192;
-  if (fill) {
-    k_candidates<true><<<nblk((long)nsrc * CAND_G, 64), 64, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, (int4 *)stage, ecap);
-    k_candidates_heavy<true><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, ecap);
-  } else {
-    k_candidates<false><<<nblk((long)nsrc * CAND_G, 64), 64, 0, st>>>(nsrc, S, mask, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, (int4 *)stage, ecap);
-    k_candidates_heavy<false><<<hgrid, 64, 0, st>>>(S, b, slot_start, entries, cand_cnt, cand_off, pair_src, pair_dst, heavy_list, heavy_cnt, cap, ecap);
-  }
+  const int nbR = nblk((long)nsrc * CAND_G, 64);
+  const int H = min(HEAVY_BLOCKS, max(64, nblk(nsrc, 64)));
+  k_candidates1<<<nbR + H, 64, 0, st>>>(nsrc, nbR, S, mask, b, slot_start, entries, ecap, ps, pair_beg, pair_cnt, heavy_list, heavy_cnt);
 }
 
-void fgd_clip_quad(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
-                   double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-                   unsigned long long *stats, unsigned *err, const unsigned long long *np_dev, hipStream_t st)
+void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
+                   double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+                   unsigned long long *stats, unsigned *err, hipStream_t st)
 {
-  if (npairs <= 0) return;
+  const long np = fgd_pairs_total(ps);
+  if (np <= 0) return;
   if (order == 2)
-    k_clip_quad<2><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err, np_dev);
+    k_clip_quad<2><<<nblk(np, CLIP_THREADS), CLIP_THREADS, 0, st>>>(ps, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
   else
-    k_clip_quad<1><<<nblk(npairs, CLIP_THREADS), CLIP_THREADS, 0, st>>>(npairs, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err, np_dev);
+    k_clip_quad<1><<<nblk(np, CLIP_THREADS), CLIP_THREADS, 0, st>>>(ps, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
 }
 
-void fgd_clip_general(int order, int npairs, const int *pair_src, int *pair_dst, FgCells S, const double *mask, FgCells D,
-                      double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
+void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
+                      double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
                       unsigned long long *stats, unsigned *err, hipStream_t st)
 {
-  if (npairs <= 0) return;
-  int grid = nblk(npairs, GEN_THREADS); if (grid > 1024) grid = 1024;
+  const long np = fgd_pairs_total(ps);
+  if (np <= 0) return;
+  int grid = nblk(np, GEN_THREADS); if (grid > 1024) grid = 1024;
   if (order == 2)
-    k_clip_general<2><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
+    k_clip_general<2><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
   else
-    k_clip_general<1><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, pair_src, pair_dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
+    k_clip_general<1><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
 }
 
-int fgd_cand_group(void) { return CAND_G; }
-
-void fgd_scatter_xcells(int order, int npairs, const int *pair_src, const int *pair_dst, const int *cand_off,
-                        const int *xoff, const double *tmp_area, const double *tmp_clon,
-                        const double *tmp_clat, int *x_src, int *x_dst, double *x_area, double *x_c1, double *x_c2,
-                        int *row_cnt, int *x_rowpos, const unsigned long long *np_dev, const int *heavy_list, const int *heavy_cnt,
-                        const int *stage, int *pair_rank, hipStream_t st)
+void fgd_compact(int order, int nsrc, FgPairSpace ps, const FgCompactIo &io, hipStream_t st)
 {
-  if (npairs <= 0) return;
-  k_rank_heavy<<<1024, 256, 0, st>>>(heavy_list, heavy_cnt, cand_off, pair_dst, pair_rank, npairs);
-  if (order == 2) k_scatter_xcells<2><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, x_rowpos, np_dev, (const int4 *)stage, pair_rank);
-  else            k_scatter_xcells<1><<<nblk(npairs, 256), 256, 0, st>>>(npairs, pair_src, pair_dst, cand_off, xoff, tmp_area, tmp_clon, tmp_clat, x_src, x_dst, x_area, x_c1, x_c2, row_cnt, x_rowpos, np_dev, (const int4 *)stage, pair_rank);
-}
-
-void fgd_cell_sums(int nsrc, const int *xoff, const double *x_area, const double *x_c1,
-                   const double *x_c2, double *sums, hipStream_t st)
-{
-  if (nsrc > 0) k_cell_sums<<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, xoff, x_area, x_c1, x_c2, sums);
+  if (nsrc <= 0) return;
+  if (order == 2) {
+    k_compact<2><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, ps, io);
+    k_compact_big<2><<<1024, 256, 0, st>>>(nsrc, ps, io);
+  } else {
+    k_compact<1><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, ps, io);
+    k_compact_big<1><<<1024, 256, 0, st>>>(nsrc, ps, io);
+  }
 }
 
 void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st)

@@ -270,7 +270,7 @@ int fg_plan_sync(fg_plan *plan);
 
 /* Optional HIP-event timing of the library's own launches (on the plan's stream).
  * fg_plan_phase_ms: [0] cell records [1] binning [2] candidates [3] clip quad kernel
- * [4] clip general kernel [5] compaction [6] cell sums [7] whole search (device span, includes
+ * [4] clip general kernel [5] compaction (incl. cell sums) [6] destination rows [7] whole search (device span, includes
  * the two host round trips) [8] finalize [9] last sweep.  Milliseconds; zeros when profiling is off. */
 void fg_set_profiling(int on);
 int  fg_plan_phase_ms(fg_plan *plan, float *ms, int n);   /* [9] = mean over the sweeps since the last call */
