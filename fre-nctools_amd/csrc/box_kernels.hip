@@ -68,7 +68,7 @@ __device__ int d_clip_box(const double *lon_in, const double *lat_in, int n_in, 
 template <int ORDER>
 __global__ __launch_bounds__(128) void k_clip_box(FgPairSpace ps, FgBox box, FgTile quad, FgCells S, FgCells D,
                                                    const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon,
-                                                   double *tmp_clat, unsigned long long *stats, unsigned *err)
+                                                   double *tmp_clat, int *nacc, unsigned long long *stats, unsigned *err)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (!d_pair_live(ps, p)) return;
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(128) void k_clip_box(FgPairSpace ps, FgBox box, FgT
   if (ratio > 1.e-6) {
     tmp_area[p] = xarea;
     if (ORDER == 2) { tmp_clon[p] = d_poly_ctrlon<1>(x_out, y_out, n_out, lon_in_avg); tmp_clat[p] = d_poly_ctrlat<1>(x_out, y_out, n_out); }
+    atomicAdd(&nacc[s], 1);
   } else {
     pair_dst[p] = -1;
     atomicAdd(&stats[FG_STAT_BELOW], 1ull);
@@ -143,13 +144,13 @@ __global__ __launch_bounds__(256) void k_box_cell_boxes(FgBox box, FgCells c)
 static inline int box_nblk(long n, int t) { return (int)((n + t - 1) / t); }
 
 void fgd_clip_box(int order, FgPairSpace ps, FgBox box, FgTile quad, FgCells S, FgCells D,
-                  const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon, double *tmp_clat,
+                  const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
                   unsigned long long *stats, unsigned *err, hipStream_t st)
 {
   const long np = fgd_pairs_total(ps);
   if (np <= 0) return;
-  if (order == 2) k_clip_box<2><<<box_nblk(np, 128), 128, 0, st>>>(ps, box, quad, S, D, mask_box, mask_quad, tmp_area, tmp_clon, tmp_clat, stats, err);
-  else k_clip_box<1><<<box_nblk(np, 128), 128, 0, st>>>(ps, box, quad, S, D, mask_box, mask_quad, tmp_area, tmp_clon, tmp_clat, stats, err);
+  if (order == 2) k_clip_box<2><<<box_nblk(np, 128), 128, 0, st>>>(ps, box, quad, S, D, mask_box, mask_quad, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
+  else k_clip_box<1><<<box_nblk(np, 128), 128, 0, st>>>(ps, box, quad, S, D, mask_box, mask_quad, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
 }
 
 void fgd_box_area_no_adjust(FgBox box, double *area, hipStream_t st)

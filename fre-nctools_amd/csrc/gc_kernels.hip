@@ -786,7 +786,7 @@ __device__ bool gc_prefilter(const double *a, const double *b, double area1, dou
 }
 
 __device__ void gc_finish(int p, int s, int n_out, const double *poly, double m, double area1, double area2, int *pair_dst,
-                          double *tmp_area, unsigned long long *stats, unsigned *err)
+                          double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err)
 {
   if (n_out < 0) { atomicOr(err, G_ERRBIT_GC_CLIP); atomicMax((int *)(err + 1), -n_out); pair_dst[p] = -1; return; }
   if (n_out == 0) { pair_dst[p] = -1; return; }
@@ -794,12 +794,12 @@ __device__ void gc_finish(int p, int s, int n_out, const double *poly, double m,
   const double min_area = (area1 < area2) ? area1 : area2;
   const double ratio = xarea / min_area;
   if (fabs(ratio - 1.e-6) < 1.e-12) atomicAdd(&stats[FG_STAT_BORDERLINE], 1ull);
-  if (ratio > 1.e-6) tmp_area[p] = xarea;
+  if (ratio > 1.e-6) { tmp_area[p] = xarea; atomicAdd(&nacc[s], 1); }
   else { pair_dst[p] = -1; atomicAdd(&stats[FG_STAT_BELOW], 1ull); }
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_WAVES_PER_EU, GC_WAVES_PER_EU)))
-void k_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D, double *tmp_area,
+void k_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D, double *tmp_area, int *nacc,
                int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -812,12 +812,12 @@ void k_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D, double 
   double poly[16 * 3];
   const int n_out = gc_clip_fast(a, b, poly);
   if (n_out == GC_FALLBACK) { defer_list[atomicAdd(defer_cnt, 1)] = p; return; }
-  gc_finish(p, s, n_out, poly, mask ? mask[s] : 1.0, area1, area2, pair_dst, tmp_area, stats, err);
+  gc_finish(p, s, n_out, poly, mask ? mask[s] : 1.0, area1, area2, pair_dst, tmp_area, nacc, stats, err);
 }
 
 // pairs the compact version handed back: the array version (prefilter already passed)
 __global__ __launch_bounds__(64) void k_gc_clip_slow(const int *defer_list, const int *defer_cnt, const int *pair_src, int *pair_dst,
-                                                      FgCells S, const double *mask, FgCells D, double *tmp_area,
+                                                      FgCells S, const double *mask, FgCells D, double *tmp_area, int *nacc,
                                                       unsigned long long *stats, unsigned *err)
 {
   const int nd = *defer_cnt;
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(64) void k_gc_clip_slow(const int *defer_list, cons
     const double *a = S.verts + (size_t)s * 16, *b = D.verts + (size_t)d * 16;
     GcPoly out;
     const int n_out = gc_clip(a, b, out);
-    gc_finish(p, s, n_out, &out.p[0][0], mask ? mask[s] : 1.0, S.area[s], D.area[d], pair_dst, tmp_area, stats, err);
+    gc_finish(p, s, n_out, &out.p[0][0], mask ? mask[s] : 1.0, S.area[s], D.area[d], pair_dst, tmp_area, nacc, stats, err);
   }
 }
 
@@ -839,12 +839,12 @@ void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCe
 }
 
 void fgd_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
-                 double *tmp_area, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st)
+                 double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st)
 {
   const long np = fgd_pairs_total(ps);
   if (np <= 0) return;
-  k_gc_clip<<<gc_nblk(np, 64), 64, 0, st>>>(ps, S, mask, D, tmp_area, defer_list, defer_cnt, stats, err);
-  k_gc_clip_slow<<<64, 64, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, stats, err);
+  k_gc_clip<<<gc_nblk(np, 64), 64, 0, st>>>(ps, S, mask, D, tmp_area, nacc, defer_list, defer_cnt, stats, err);
+  k_gc_clip_slow<<<64, 64, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, nacc, stats, err);
 }
 
 // ------------------------------------------------------------------------------------------------ batch primitives

@@ -332,7 +332,7 @@ static const char *gc_clip_error(int code)
 // Capacities of one attempt: bin-table records and entries per region of the pair list.  The default capacities (bin records
 // 3*ndst, pairs 8*max(nsrc, ndst)) fit every remap between grids of comparable resolution; every kernel clamps its writes
 // AND reads to them, the counters keep counting, and an attempt that outgrew one is repeated with the counted sizes.
-struct SearchCaps { unsigned long long entries; int regcap; };
+struct SearchCaps { unsigned long long entries; int regcap, nreg; };
 #define FG_RETRY (-1000L)
 static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
@@ -396,19 +396,20 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   const unsigned long long nentries = caps->entries;
   const int ecap = (int)std::min<unsigned long long>(nentries, 2147483647ull);     // records the buffer holds: writes and reads stop there
   FgPairSpace ps{};
-  ps.nreg = FG_NREG; ps.regcap = caps->regcap;
+  ps.nreg = caps->nreg; ps.regcap = caps->regcap;
   const long npairs = fgd_pairs_total(ps);            // capacity of the pair list
   const long nx_alloc = npairs;                       // nxgrid <= candidate pairs <= capacity
 
   if (!alloc_cells(pl, &pl->S, nsrc) || !alloc_cells(pl, &pl->D, ndst)) return fail(FG_ERR_HIP, "out of device memory");
   // one zeroed block: [counters | region fill counters | tickets | look-back words of the three scans | bin counts |
-  //                    bin fill cursors | destination-row counts]
-  const long t_bins = fgd_scan_tiles(nslots), t_rows = fgd_scan_tiles(ndst), t_comp = ((long)nsrc + 255) / 256 + 1;
+  //                    bin fill cursors | destination-row counts | accepted pairs per source cell]
+  const long t_bins = fgd_scan_tiles(nslots), t_rows = fgd_scan_tiles(ndst), t_comp = fgd_scan_tiles(nsrc);
   const size_t zc = (sizeof(FgCounters) + 127) / 128 * 128;
-  const size_t zfill = (size_t)FG_NREG * FG_FILL_STRIDE * sizeof(unsigned);
+  const size_t zfill = (size_t)FG_NREG * FG_FILL_STRIDE * sizeof(unsigned);      // (nreg <= FG_NREG)
   const size_t ztick = 128;
   const size_t zlb = (size_t)(t_bins + t_rows + t_comp) * sizeof(unsigned long long);
-  const size_t zbytes = zc + zfill + ztick + zlb + (size_t)(2 * (nslots + 1) + ndst + 1) * sizeof(int);
+  const size_t zints = ((size_t)(2 * (nslots + 1) + ndst + 1 + nsrc + 1) * sizeof(int) + 15) / 16 * 16;
+  const size_t zbytes = zc + zfill + ztick + zlb + zints;
   char *zero_blk = pl->alloc<char>(zbytes);
   int *bin_start = pl->alloc<int>(nslots + 1);
   int *heavy_list = pl->alloc<int>(nsrc + 1);
@@ -437,6 +438,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   unsigned *tickets = (unsigned *)(zero_blk + zc + zfill);                 // [0] bins [1] rows [2] compaction
   unsigned long long *lb_bins = (unsigned long long *)(zero_blk + zc + zfill + ztick), *lb_rows = lb_bins + t_bins, *lb_comp = lb_rows + t_rows;
   int *bin_cnt = (int *)(zero_blk + zc + zfill + ztick + zlb), *bin_fill = bin_cnt + (nslots + 1), *row_cnt = bin_fill + (nslots + 1);
+  int *nacc = row_cnt + (ndst + 1);
   HIPCHK(hipMemsetAsync(zero_blk, 0, zbytes, st));
 
   PhaseTimer pt, ptot;
@@ -449,7 +451,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     fgd_gc_cell_struct(gct_dev + pl->ntiles, 1, ndst, pl->D, st);
     fgd_src_field_index(order, pl->tiles_dev, pl->ntiles, nsrc, pl->src_idx_f, st);
   } else
-    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, dc->err, st);
+    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st);
   if (boxm) fgd_box_cell_boxes(boxm->box, pl->S, st);
   if (boxm && boxm->no_adjust) fgd_box_area_no_adjust(boxm->box, pl->S.area, st);      // create_xgrid.c:239-242
   pt.end();
@@ -469,18 +471,18 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   // --- clip, area, centroid integrals
   if (boxm) {
     pt.begin(PH_CLIP_GENERAL);
-    fgd_clip_box(order, ps, boxm->box, th[pl->ntiles], pl->S, pl->D, pl->mask_dev, boxm->mask_quad, tmp_area, tmp_clon, tmp_clat, dc->stats, dc->err, st);
+    fgd_clip_box(order, ps, boxm->box, th[pl->ntiles], pl->S, pl->D, pl->mask_dev, boxm->mask_quad, tmp_area, tmp_clon, tmp_clat, nacc, dc->stats, dc->err, st);
     pt.end();
   } else if (gc) {
     pt.begin(PH_CLIP_GENERAL);
-    fgd_gc_clip(ps, pl->S, pl->mask_dev, pl->D, tmp_area, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
+    fgd_gc_clip(ps, pl->S, pl->mask_dev, pl->D, tmp_area, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
     pt.end();
   } else {
     pt.begin(PH_CLIP_QUAD);
-    fgd_clip_quad(order, ps, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
+    fgd_clip_quad(order, ps, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
     pt.end();
     pt.begin(PH_CLIP_GENERAL);
-    fgd_clip_general(order, ps, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
+    fgd_clip_general(order, ps, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
     pt.end();
   }
 
@@ -490,7 +492,8 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   io.pair_beg = pair_beg; io.pair_cnt = pair_cnt; io.tmp_area = tmp_area; io.tmp_clon = tmp_clon; io.tmp_clat = tmp_clat;
   io.xoff = pl->xoff; io.x_src = pl->x_src; io.x_dst = pl->x_dst; io.x_area = pl->x_area; io.x_c1 = pl->x_c1; io.x_c2 = pl->x_c2;
   io.row_cnt = row_cnt; io.x_rowpos = pl->x_rowpos; io.sums = pl->sums; io.big_list = big_list;
-  io.lb_status = lb_comp; io.ticket = &tickets[2]; io.dc = dc; io.xcap = nx_alloc;
+  io.dc = dc; io.xcap = nx_alloc;
+  fgd_exclusive_scan1(nacc, nsrc, pl->xoff, lb_comp, &tickets[2], &dc->total[2], dc->err, st);
   fgd_compact(order, nsrc, ps, io, st);
   pt.end();
   pt.begin(PH_ROWS);
@@ -505,7 +508,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   if (hc->total[0] > nentries) { caps->entries = hc->total[0]; return FG_RETRY; }
   if (hc->total[0] > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
   if (hc->total[3] > (unsigned long long)ps.regcap) {
-    if (hc->total[3] > 2000000000ull / FG_NREG) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
+    if (hc->total[3] > 2000000000ull / (unsigned long long)ps.nreg) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
     caps->regcap = (int)((hc->total[3] + 255) / 256 * 256);
     return FG_RETRY;
   }
@@ -556,7 +559,10 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   SearchCaps caps;
   caps.entries = exact ? 0ull : 3ull * (unsigned long long)pl->ndst + 4096ull;
   const unsigned long long cap_pairs = std::min<unsigned long long>(8ull * (unsigned long long)big + 65536ull, 2000000000ull);
-  caps.regcap = exact ? 0 : (int)((cap_pairs / FG_NREG + 255) / 256 * 256);
+  // regions of the pair list: a run of 256 source cells appends to one region; at least four such runs per region on average, so
+  // that small grids do not pile their pairs into a few small regions
+  caps.nreg = (int)std::max(1L, std::min((long)FG_NREG, ((long)pl->nsrc + 1023) / 1024));
+  caps.regcap = exact ? 0 : (int)((cap_pairs / caps.nreg + 255) / 256 * 256);
   const size_t keep = pl->owned.size();              // blocks the caller staged before the search stay
   long rc = FG_RETRY;
   int attempts = 0;

@@ -100,9 +100,9 @@ void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *st
                          unsigned long long *total_dev, unsigned *err, hipStream_t st);
 
 // per-cell records of the source tiles and of the destination tile in ONE launch; also counts the destination cells into
-// their bins (slot_cnt), fills src_idx_f and stores the tile descriptors at tiles_out
+// their bins (slot_cnt), fills src_idx_f, zeroes sums[3][nsrc] (may be null) and stores the tile descriptors at tiles_out
 void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, FgCells D,
-                      FgBins b, int *slot_cnt, int order, int *src_idx_f, unsigned *err, hipStream_t st);
+                      FgBins b, int *slot_cnt, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st);
 void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c, unsigned *err, hipStream_t st);
 void fgd_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt, hipStream_t st);
 // bin fill + list of the source cells whose candidate scan gets a whole wave
@@ -111,22 +111,22 @@ void fgd_bin_fill(int ndst, FgCells D, FgBins b, int *slot_fill, const int *slot
 void fgd_candidates1(int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
                      FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, hipStream_t st);
 void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
-              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+              double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);
 void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
-              double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+              double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);
-// accepted pairs -> exchange cells in canonical order, per-source-cell offsets (xoff) and sums, destination-row sizes and slots
+// accepted pairs -> exchange cells in canonical order (xoff = scan of the clip kernels' nacc), per-source-cell sums,
+// destination-row sizes and slots
 struct FgCompactIo {
   const int *pair_beg, *pair_cnt;
   const double *tmp_area, *tmp_clon, *tmp_clat;
-  int *xoff, *x_src, *x_dst;
+  const int *xoff;
+  int *x_src, *x_dst;
   double *x_area, *x_c1, *x_c2;
   int *row_cnt, *x_rowpos;
-  double *sums;                      // [3][nsrc] (order 2) or null
+  double *sums;                      // [3][nsrc] (order 2, zeroed: cells without exchange cells are not visited) or null
   int *big_list;                     // [nsrc] scratch
-  unsigned long long *lb_status;     // zeroed, one word per 256 source cells
-  unsigned *ticket;                  // zeroed
   FgCounters *dc;
   long xcap;                         // entries the x_* arrays hold
 };
@@ -201,7 +201,7 @@ void fgd_mono_limit(long nx, FgCsr csr, const double *f, double missing, const d
 // ---- 1-D x 2-D variants (box_kernels.hip): the regular grid given by its 1-D bounds (device pointers)
 struct FgBox { const double *lon, *lat; int nx, ny; };
 void fgd_clip_box(int order, FgPairSpace ps, FgBox box, FgTile quad, FgCells S, FgCells D,
-                  const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon, double *tmp_clat,
+                  const double *mask_box, const double *mask_quad, double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
                   unsigned long long *stats, unsigned *err, hipStream_t st);
 void fgd_box_area_no_adjust(FgBox box, double *area, hipStream_t st);
 void fgd_box_cell_boxes(FgBox box, FgCells c, hipStream_t st);
@@ -213,7 +213,7 @@ void fgd_grid_area_no_adjust(int nx, int ny, const double *lon, const double *la
 // ---- great-circle path (gc_kernels.hip)
 void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st);
 void fgd_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
-                 double *tmp_area, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st);
+                 double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st);
 #define FG_GC_POLY_CAP 16
 void fgd_gc_clip_batch(int n, const double *a, const double *b, double *out, int *n_out, double *area, hipStream_t st);
 void fgd_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *n, double *area, hipStream_t st);

@@ -332,7 +332,7 @@ __device__ __forceinline__ void d_bin_insert(bool live, int d, double lat_min, d
 // fregrid_util.c:2137-2145); destination blocks count their cells into the bins; block 0 stores the tile descriptors.
 __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst,
                                                        int nbS, FgCells S, FgCells D, FgBins b, int *slot_cnt, int order, int *src_idx_f,
-                                                       unsigned *err)
+                                                       double *sums, unsigned *err)
 {
   __shared__ double vtile[256 * 17];
   __shared__ FgTile sh_tiles[FG_TILESET_MAX];
@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
   if (!isD) {
     const int s0 = blockIdx.x * 256, s = s0 + threadIdx.x;
     (void)d_cell_record(tiles, ntiles, nsrc, S, err, s0, vtile, box, &tl);
+    if (s < nsrc && sums) { sums[s] = 0.0; sums[nsrc + s] = 0.0; sums[2 * (size_t)nsrc + s] = 0.0; }   // k_compact visits cells with exchange cells only
     if (s < nsrc && src_idx_f) {
       if (order != 2) src_idx_f[s] = s;
       else {
@@ -422,6 +423,7 @@ __device__ __forceinline__ bool d_box_pass(const FgBinEntry &E, double lat_in_mi
                               // give 0.31 / 0.27 / 0.28 / 0.305 / 0.38 ms for the candidate phase at C384 -> 0.25 deg; the lanes with the
                               // longest scans set the duration of the four-lanes-per-cell path)
 #define CAND_G 4          // lanes per source cell in the candidate scan (one bin row each)
+#define CAND_CHUNK 16    // consecutive waves (of 16 cells) that append to the same region
 #define HEAVY_BLOCKS 2048 // waves serving the listed cells, appended to the grid of the four-lanes-per-cell blocks
 
 __device__ __forceinline__ bool d_src_active(const FgCells &S, const double *mask, int s)
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(64) void k_candidates1(int nsrc, int nbR, FgCells S
   const unsigned incl = wave_incl_scan((unsigned)cnt, lane);
   const unsigned total = __shfl(incl, 63);
   const unsigned excl = incl - (unsigned)cnt;
-  const int r = blockIdx.x % ps.nreg;
+  const int r = (blockIdx.x / CAND_CHUNK) % ps.nreg;   // 256 consecutive cells share a region: neighbouring pairs stay neighbours for the clip
   unsigned base = 0;
   if (lane == 0 && total) base = atomicAdd(&ps.fill[r * FG_FILL_STRIDE], total);
   base = __shfl(base, 0);
@@ -765,7 +767,7 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
 // gets tmp_area/clon/clat[p]; a rejected pair gets pair_dst[p] = -1.
 template <int ORDER>
 __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
-                                                            double *tmp_area, double *tmp_clon, double *tmp_clat,
+                                                            double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
                                                             int *defer_list, int *defer_cnt,
                                                             unsigned long long *stats, unsigned *err)
 {
@@ -773,18 +775,33 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCe
   d_load_trig_table();
   const int tid = threadIdx.x, lane = tid & 63;
   const int p = blockIdx.x * CLIP_THREADS + tid;
-  bool defer = false, below = false;
+  bool defer = false, below = false, acc = false;
+  int s = -1;
   if (d_pair_live(ps, p)) {
-    const int s = ps.src[p];
+    s = ps.src[p];
     const int d = ps.dst[p];
     ClipOut o;
     if (!d_clip_quad_pair<ORDER>(sh_poly, tid, s, d, S, mask, D, &o, stats, err)) defer = true;   // rare; the general kernel finishes this pair
     else if (o.area >= 0) {
+      acc = true;
       tmp_area[p] = o.area;
       if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
     } else {
       ps.dst[p] = -1;
       below = (o.area == -2.0);                                  // rare (slivers below the 1e-6 ratio)
+    }
+  }
+  // nacc[s]: accepted pairs of source cell s.  Lanes are pair-ordered, so one atomic per (wave, source cell) run does it.
+  {
+    const int s_prev = __shfl_up(s, 1, 64);
+    const bool head = (lane == 0) || (s != s_prev);
+    const unsigned long long hm = __ballot(head), am = __ballot(acc);
+    if (head && s >= 0) {
+      const unsigned long long above = (lane == 63) ? 0ull : (hm >> (lane + 1)) << (lane + 1);
+      const int end = above ? (__ffsll((long long)above) - 1) : 64;
+      const unsigned long long upto = (end == 64) ? ~0ull : ((1ull << end) - 1ull);
+      const int cnt = __popcll(am & upto & ~((1ull << lane) - 1ull));
+      if (cnt) atomicAdd(&nacc[s], cnt);
     }
   }
   // one atomic per wave that has deferred pairs / slivers (value-returning same-address atomics serialise at ~12 ns each)
@@ -806,7 +823,7 @@ template <int ORDER>
 __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_list, const int *defer_cnt,
                                                               const int *pair_src, int *pair_dst,
                                                               FgCells S, const double *mask, FgCells D,
-                                                              double *tmp_area, double *tmp_clon, double *tmp_clat,
+                                                              double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
                                                               unsigned long long *stats, unsigned *err)
 {
   __shared__ double2 sh_a[GEN_CAP][GEN_THREADS];
@@ -888,6 +905,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
     if (o.area >= 0) {
       tmp_area[p] = o.area;
       if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
+      atomicAdd(&nacc[s], 1);
     } else {
       pair_dst[p] = -1;
       if (o.area == -2.0) atomicAdd(&stats[FG_STAT_BELOW], 1ull);
@@ -898,150 +916,113 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
 // ---------------------------------------------------------------------------------------
 // compaction into canonical order + per-source-cell sums
 // ---------------------------------------------------------------------------------------
-// A block owns 256 consecutive source cells (tile = ticket order).  Phases:
-//   1. every cell counts its accepted pairs (pair_dst >= 0); cells with more than CP_SMALL pairs ("big": the cells around a
-//      pole of the target grid, every cell of a coarse -> fine remap) are counted by the block's waves in turn and appended
-//      to big_list for k_compact_big;
-//   2. block scan of the counts, look-back over the preceding tiles -> xoff[s] (the reference's running nxgrid);
-//   3. small cells: rank of each accepted pair among its cell's accepted pairs by destination index (the reference's ij
-//      loop), staged as a permutation in LDS so that the exchange cells leave in one coalesced sweep; the sweep also takes
-//      each exchange cell's slot in its destination row (x_rowpos) and thereby counts the CSR row sizes;
-//   4. small cells (order 2): sums of (area, clon, clat) in exchange-cell order, conserve_interp.c:216-221.
-// Nothing depends on the order in which the candidate kernel filled the pair list.
-#define CP_CAP 4096          // output positions staged per sweep
-#define CP_SMALL 32          // pairs per cell handled by the cell's own thread
+// The clip kernels count the accepted pairs of every source cell (nacc, one atomic per run of equal cells in a wave, hidden
+// behind the clip arithmetic); a scan of nacc gives xoff[s], the reference's running nxgrid.  k_compact then works with ONE
+// LANE PER PAIR, so that every array of the pair list is read once, fully coalesced:
+//   * a block takes the source cells whose FIRST pair lies among its 256 pairs; such a cell (at most CP_SMALL pairs) ends
+//     within the next CP_SMALL pairs, which the first lanes of the block handle as well ("halo");
+//   * the destination indices of those 256 + CP_SMALL pairs are staged in LDS; a pair's rank among the accepted pairs of its
+//     source cell by destination index (the reference's ij loop) is a handful of LDS reads;
+//   * the exchange cell is stored at xoff[s] + rank (neighbouring lanes store neighbouring cells) and takes its slot in its
+//     destination row (x_rowpos), which also counts the CSR row sizes;
+//   * order 2: the values go to LDS at the cell's first pair + rank, and the lane holding the cell's first pair adds them up
+//     in that order = exchange-cell order (conserve_interp.c:216-221).
+// Cells with more than CP_SMALL pairs ("big": the cells around a pole of the target grid, every cell of a coarse -> fine
+// remap) are listed for k_compact_big.  Nothing depends on the order in which the candidate kernel filled the pair list.
+// (Measured at C384 -> 0.25 deg: 109 us.  A first version gave each block 256 source cells and found xoff by look-back inside the
+// kernel: 320-430 us -- its per-cell loads of the pair list are strided, and a chain of dependent round trips per block does not
+// hide behind five blocks per CU; a lane-per-pair version that left the cells cut by a block boundary to one lane: 245 us.)
+#define CP_SMALL 32          // pairs per cell up to which the lanes of k_compact rank by comparison
+#define CP_SPAN (256 + CP_SMALL)
+
+struct CpPair { int s, d, beg, cnt, li; long x0; int na; double a, l, t; bool mine; };
+
+template <int ORDER>
+__device__ __forceinline__ CpPair d_cp_load(const FgPairSpace &ps, const FgCompactIo &io, int p, int p0, unsigned live_end, bool halo)
+{
+  CpPair c;
+  c.s = 0; c.d = -1; c.beg = 0; c.cnt = 0; c.x0 = 0; c.na = 0; c.a = 0; c.l = 0; c.t = 0; c.mine = false; c.li = p - p0;
+  if ((unsigned)p < live_end) {
+    c.s = ps.src[p]; c.d = ps.dst[p];
+    c.beg = io.pair_beg[c.s]; c.cnt = io.pair_cnt[c.s];
+    // this block's cell: its first pair is one of the block's 256 (halo lanes: ... and it is not a big cell's)
+    c.mine = c.cnt <= CP_SMALL && c.beg >= p0 && c.beg < p0 + 256;
+    if (c.mine) {
+      c.x0 = io.xoff[c.s]; c.na = io.xoff[c.s + 1] - (int)c.x0;
+      if (c.d >= 0) { c.a = io.tmp_area[p]; if (ORDER == 2) { c.l = io.tmp_clon[p]; c.t = io.tmp_clat[p]; } }
+    }
+  }
+  (void)halo;
+  return c;
+}
+
+template <int ORDER>
+__device__ __forceinline__ void d_cp_place(const FgCompactIo &io, const CpPair &c, int p0, const int *sh_d, double (*sh_v)[CP_SPAN])
+{
+  if (!c.mine || c.d < 0 || c.x0 + c.na > io.xcap) return;
+  int rank = 0;
+  const int lb = c.beg - p0;
+  for (int j = 0; j < c.cnt; j++) rank += ((unsigned)sh_d[lb + j] < (unsigned)c.d) ? 1 : 0;       // rejected entries are 0xffffffff
+  const long pos = c.x0 + rank;
+  io.x_src[pos] = c.s; io.x_dst[pos] = c.d; io.x_area[pos] = c.a;
+  if (ORDER == 2) { io.x_c1[pos] = c.l; io.x_c2[pos] = c.t; sh_v[0][lb + rank] = c.a; sh_v[1][lb + rank] = c.l; sh_v[2][lb + rank] = c.t; }
+  io.x_rowpos[pos] = atomicAdd(&io.row_cnt[c.d], 1);
+}
 
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_compact(int nsrc, FgPairSpace ps, FgCompactIo io)
 {
-  __shared__ int sh_p[CP_CAP];
-  __shared__ unsigned short sh_c[CP_CAP];
-  __shared__ int sh_beg[256], sh_cnt[256], sh_nab[256], sh_bigl[256];
-  __shared__ int sh_tile, sh_nbig, sh_bigbase;
-  __shared__ unsigned long long sh_base;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { sh_tile = (int)atomicAdd(io.ticket, 1u); sh_nbig = 0; }
+  __shared__ int sh_d[CP_SPAN];
+  __shared__ double sh_v[3][CP_SPAN];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int p0 = blockIdx.x * 256;
+  const unsigned r = (unsigned)p0 / (unsigned)ps.regcap;          // block-uniform
+  const unsigned rfill = ps.fill[r * FG_FILL_STRIDE];
+  const unsigned live_end = r * (unsigned)ps.regcap + (rfill < (unsigned)ps.regcap ? rfill : (unsigned)ps.regcap);   // end of the region's pairs
+  if ((unsigned)p0 >= live_end) return;
+  const CpPair c = d_cp_load<ORDER>(ps, io, p0 + tid, p0, live_end, false);
+  CpPair h; h.mine = false; h.d = -1;
+  if (tid < CP_SMALL) { h = d_cp_load<ORDER>(ps, io, p0 + 256 + tid, p0, live_end, true); sh_d[256 + tid] = h.d; }
+  sh_d[tid] = c.d;
   __syncthreads();
-  const int tile = sh_tile, s0 = tile * 256, s = s0 + tid;
-  if (tile == 0 && tid < 64) {                         // candidate totals for the host's capacity checks
-    unsigned long long f = 0; unsigned mx = 0;
-    for (int r = tid; r < ps.nreg; r += 64) { const unsigned v = ps.fill[r * FG_FILL_STRIDE]; f += v; mx = max(mx, v); }
-#pragma unroll
-    for (int o = 32; o; o >>= 1) { f += __shfl_xor(f, o); mx = max(mx, (unsigned)__shfl_xor((int)mx, o)); }
-    if (tid == 0) { io.dc->total[1] = f; io.dc->total[3] = mx; }
+  const bool first = (unsigned)(p0 + tid) < live_end && p0 + tid == c.beg;
+  const unsigned long long bm = __ballot(first && c.cnt > CP_SMALL);
+  if (bm) {
+    int q = 0;
+    if (lane == 0) q = atomicAdd(&io.dc->big_cnt, __popcll(bm));
+    q = __shfl(q, 0);
+    if (first && c.cnt > CP_SMALL) io.big_list[q + __popcll(bm & ((1ull << lane) - 1ull))] = c.s;
   }
-  int beg = 0, cnt = 0;
-  if (s < nsrc) { beg = io.pair_beg[s]; cnt = io.pair_cnt[s]; }
-  const bool big = cnt > CP_SMALL;
-  int dv[8];
-  int na = 0;
-  if (!big) {
-#pragma unroll
-    for (int k = 0; k < 8; k++) { dv[k] = (k < cnt) ? ps.dst[beg + k] : -1; na += (dv[k] >= 0) ? 1 : 0; }
-    for (int k = 8; k < cnt; k++) na += (ps.dst[beg + k] >= 0) ? 1 : 0;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 8; k++) dv[k] = -1;
-    const int q = atomicAdd(&sh_nbig, 1);
-    sh_bigl[q] = tid;
-  }
-  sh_beg[tid] = beg; sh_cnt[tid] = cnt;
+  d_cp_place<ORDER>(io, c, p0, sh_d, sh_v);
+  if (tid < CP_SMALL) d_cp_place<ORDER>(io, h, p0, sh_d, sh_v);
+  if (ORDER != 2 || !io.sums) return;
   __syncthreads();
-  const int nbig = sh_nbig;
-  for (int q = wave; q < nbig; q += 4) {
-    const int t = sh_bigl[q], b0 = sh_beg[t], c = sh_cnt[t];
-    int m = 0;
-    for (int k = lane; k < c; k += 64) m += (ps.dst[b0 + k] >= 0) ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o; o >>= 1) m += __shfl_xor(m, o);
-    if (lane == 0) sh_nab[t] = m;
-  }
-  if (tid == 0 && nbig) sh_bigbase = atomicAdd(&io.dc->big_cnt, nbig);
-  __syncthreads();
-  if (big) na = sh_nab[tid];
-  unsigned tot;
-  const int loc = (int)block_incl_scan((unsigned)na, &tot) - na;
-  if (wave == 0) {
-    const unsigned long long e = d_lookback_wave(io.lb_status, tile, (unsigned long long)tot, io.dc->err);
-    if (lane == 0) sh_base = e;
-  }
-  __syncthreads();
-  const unsigned long long base = sh_base;
-  if (s < nsrc) io.xoff[s] = (int)(base + loc);
-  if (tid == 0 && s0 + 256 >= nsrc) { io.xoff[nsrc] = (int)(base + tot); io.dc->total[2] = base + tot; }
-  for (int q = tid; q < nbig; q += 256) io.big_list[sh_bigbase + q] = s0 + sh_bigl[q];
-  // small cells: ranks -> permutation in LDS -> coalesced sweep; big cells leave holes for k_compact_big
-  for (int w0 = 0; w0 < (int)tot; w0 += CP_CAP) {
-    const int wn = min(CP_CAP, (int)tot - w0);
-    for (int j = tid; j < wn; j += 256) sh_p[j] = -1;
-    __syncthreads();
-    if (!big && na > 0 && loc < w0 + wn && loc + na > w0) {
-      if (cnt <= 8) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          if (dv[k] >= 0) {
-            int rank = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) rank += ((unsigned)dv[j] < (unsigned)dv[k]) ? 1 : 0;     // rejected entries are 0xffffffff
-            const int at = loc + rank - w0;
-            if (at >= 0 && at < wn) { sh_p[at] = beg + k; sh_c[at] = (unsigned short)tid; }
-          }
-        }
-      } else {
-        for (int k = 0; k < cnt; k++) {
-          const int d = ps.dst[beg + k];
-          if (d < 0) continue;
-          int rank = 0;
-          for (int j = 0; j < cnt; j++) rank += ((unsigned)ps.dst[beg + j] < (unsigned)d) ? 1 : 0;
-          const int at = loc + rank - w0;
-          if (at >= 0 && at < wn) { sh_p[at] = beg + k; sh_c[at] = (unsigned short)tid; }
-        }
-      }
-    }
-    __syncthreads();
-    for (int j = tid; j < wn; j += 256) {
-      const int p = sh_p[j];
-      if (p < 0) continue;
-      const long pos = (long)base + w0 + j;
-      if (pos >= io.xcap) continue;
-      const int d = ps.dst[p];
-      io.x_src[pos] = s0 + sh_c[j];
-      io.x_dst[pos] = d;
-      io.x_area[pos] = io.tmp_area[p];
-      if (ORDER == 2) { io.x_c1[pos] = io.tmp_clon[p]; io.x_c2[pos] = io.tmp_clat[p]; }
-      // destination-row sizes for the CSR build and this cell's slot in its row
-      io.x_rowpos[pos] = atomicAdd(&io.row_cnt[d], 1);
-    }
-    __syncthreads();
-  }
-  if (ORDER == 2 && io.sums && s < nsrc && !big) {
-    // the block's own stores, read back after the barrier above: additions in exchange-cell order, loads 8 ahead
-    double a = 0, l = 0, t = 0;
-    const long o = (long)base + loc;
-    const int c = (o + na <= io.xcap) ? na : 0;
-    int k = 0;
-    for (; k + 8 <= c; k += 8) {
-      double va[8], vl[8], vt[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) { va[u] = io.x_area[o + k + u]; vl[u] = io.x_c1[o + k + u]; vt[u] = io.x_c2[o + k + u]; }
-#pragma unroll
-      for (int u = 0; u < 8; u++) { a += va[u]; l += vl[u]; t += vt[u]; }
-    }
-    for (; k < c; k++) { a += io.x_area[o + k]; l += io.x_c1[o + k]; t += io.x_c2[o + k]; }
-    io.sums[s] = a; io.sums[nsrc + s] = l; io.sums[2 * (size_t)nsrc + s] = t;
-  }
+  if (!first || !c.mine || c.x0 + c.na > io.xcap) return;
+  double sa = 0, sl = 0, st = 0;
+  const int lb = c.beg - p0;
+  for (int k = 0; k < c.na; k++) { sa += sh_v[0][lb + k]; sl += sh_v[1][lb + k]; st += sh_v[2][lb + k]; }
+  io.sums[c.s] = sa; io.sums[nsrc + c.s] = sl; io.sums[2 * (size_t)nsrc + c.s] = st;
 }
 
 // The big cells: a block per cell.  Ranking a pair by comparing it with all the others of its cell is quadratic (great-circle
 // search: ~3000 pairs in each of ~600 cells); here the block marks the cell's destination indices in an LDS bitmap over their
 // span and reads each rank off as a prefix population count: linear.  Spans that do not fit fall back to the comparison.
 #define RANK_WORDS 2048      // 131072 destination indices: 91 rows of a 1440-column grid
+#define BIG_STAGE 1024
 template <int ORDER>
 __global__ __launch_bounds__(256) void k_compact_big(int nsrc, FgPairSpace ps, FgCompactIo io)
 {
   __shared__ unsigned long long bits[RANK_WORDS];
   __shared__ int pref[RANK_WORDS];
   __shared__ int smin, smax;
+  __shared__ double sval[3][BIG_STAGE];
+  if (blockIdx.x == 0 && threadIdx.x < 64) {           // candidate totals for the host's capacity checks
+    unsigned long long f = 0; unsigned mx = 0;
+    for (int r = threadIdx.x; r < ps.nreg; r += 64) { const unsigned v = ps.fill[r * FG_FILL_STRIDE]; f += v; mx = max(mx, v); }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { f += __shfl_xor(f, o); mx = max(mx, (unsigned)__shfl_xor((int)mx, o)); }
+    if (threadIdx.x == 0) { io.dc->total[1] = f; io.dc->total[3] = mx; }
+  }
   const int nb = io.dc->big_cnt;
   for (int h = blockIdx.x; h < nb; h += gridDim.x) {
     const int s = io.big_list[h];
@@ -1076,37 +1057,47 @@ __global__ __launch_bounds__(256) void k_compact_big(int nsrc, FgPairSpace ps, F
       for (int w = w0; w < w1; w++) { pref[w] = run; run += __popcll(bits[w]); }
       __syncthreads();
     }
-    for (int k = threadIdx.x; k < c; k += 256) {
-      const int p = o + k;
-      const int d = ps.dst[p];
-      if (d < 0) continue;
-      int rank;
-      if (bitmap) { const int w = (d - dmin) >> 6, b = (d - dmin) & 63; rank = pref[w] + __popcll(bits[w] & ((1ull << b) - 1ull)); }
-      else { rank = 0; for (int j = 0; j < c; j++) rank += ((unsigned)ps.dst[o + j] < (unsigned)d) ? 1 : 0; }
-      const long pos = x0 + rank;
-      if (pos >= io.xcap) continue;
-      io.x_src[pos] = s; io.x_dst[pos] = d; io.x_area[pos] = io.tmp_area[p];
-      if (ORDER == 2) { io.x_c1[pos] = io.tmp_clon[p]; io.x_c2[pos] = io.tmp_clat[p]; }
-      io.x_rowpos[pos] = atomicAdd(&io.row_cnt[d], 1);
-    }
-    __syncthreads();
-    if (ORDER == 2 && io.sums && threadIdx.x < 3) {
-      // three lanes, one array each: hundreds to thousands of ordered additions, the loads 16 ahead of them
-      const double *v = (threadIdx.x == 0) ? io.x_area : ((threadIdx.x == 1) ? io.x_c1 : io.x_c2);
-      const int cc = (x0 + na <= io.xcap) ? na : 0;
-      double a = 0;
-      int k = 0;
-      for (; k + 16 <= cc; k += 16) {
-        double t[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) t[u] = v[x0 + k + u];
-#pragma unroll
-        for (int u = 0; u < 16; u++) a += t[u];
+    // exchange cells to their places; order 2: the values also go to LDS in rank order, 1024 ranks at a time, where three
+    // lanes (one array each) add them up in exchange-cell order -- hundreds to thousands of ordered additions per cell, which
+    // from global memory (even with the loads 16 ahead) set the duration of the whole compaction
+    double acc = 0;
+    for (int c0 = 0; c0 < max(na, 1); c0 += BIG_STAGE) {
+      for (int k = threadIdx.x; k < c; k += 256) {
+        const int p = o + k;
+        const int d = ps.dst[p];
+        if (d < 0) continue;
+        int rank;
+        if (bitmap) { const int w = (d - dmin) >> 6, b = (d - dmin) & 63; rank = pref[w] + __popcll(bits[w] & ((1ull << b) - 1ull)); }
+        else { rank = 0; for (int j = 0; j < c; j++) rank += ((unsigned)ps.dst[o + j] < (unsigned)d) ? 1 : 0; }
+        if (rank < c0 || rank >= c0 + BIG_STAGE) continue;
+        const long pos = x0 + rank;
+        if (pos >= io.xcap) continue;
+        const double a = io.tmp_area[p];
+        io.x_src[pos] = s; io.x_dst[pos] = d; io.x_area[pos] = a;
+        if (ORDER == 2) {
+          const double l = io.tmp_clon[p], t = io.tmp_clat[p];
+          io.x_c1[pos] = l; io.x_c2[pos] = t;
+          sval[0][rank - c0] = a; sval[1][rank - c0] = l; sval[2][rank - c0] = t;
+        }
+        io.x_rowpos[pos] = atomicAdd(&io.row_cnt[d], 1);
       }
-      for (; k < cc; k++) a += v[x0 + k];
-      io.sums[(size_t)threadIdx.x * nsrc + s] = a;
+      __syncthreads();
+      if (ORDER == 2 && threadIdx.x < 3 && x0 + na <= io.xcap) {
+        const double *v = sval[threadIdx.x];
+        const int n = min(BIG_STAGE, na - c0);
+        int k = 0;
+        for (; k + 8 <= n; k += 8) {
+          double t[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) t[u] = v[k + u];
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc += t[u];
+        }
+        for (; k < n; k++) acc += v[k];
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    if (ORDER == 2 && io.sums && threadIdx.x < 3) io.sums[(size_t)threadIdx.x * nsrc + s] = acc;
   }
 }
 
@@ -1161,11 +1152,11 @@ void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c,
 }
 
 void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, FgCells D,
-                      FgBins b, int *slot_cnt, int order, int *src_idx_f, unsigned *err, hipStream_t st)
+                      FgBins b, int *slot_cnt, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st)
 {
   const int nbS = nblk(nsrc, 256), nbD = nblk(ndst, 256);
   if (nbS + nbD > 0)
-    k_cell_struct2<<<nbS + nbD, 256, 0, st>>>(ts, tiles_in, tiles_out, ntiles, nsrc, ndst, nbS, S, D, b, slot_cnt, order, src_idx_f, err);
+    k_cell_struct2<<<nbS + nbD, 256, 0, st>>>(ts, tiles_in, tiles_out, ntiles, nsrc, ndst, nbS, S, D, b, slot_cnt, order, src_idx_f, sums, err);
 }
 
 void fgd_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt, hipStream_t st)
@@ -1191,38 +1182,39 @@ void fgd_candidates1(int nsrc, FgCells S, const double *mask, FgBins b, const in
 }
 
 void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
-                   double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+                   double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
                    unsigned long long *stats, unsigned *err, hipStream_t st)
 {
   const long np = fgd_pairs_total(ps);
   if (np <= 0) return;
   if (order == 2)
-    k_clip_quad<2><<<nblk(np, CLIP_THREADS), CLIP_THREADS, 0, st>>>(ps, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
+    k_clip_quad<2><<<nblk(np, CLIP_THREADS), CLIP_THREADS, 0, st>>>(ps, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err);
   else
-    k_clip_quad<1><<<nblk(np, CLIP_THREADS), CLIP_THREADS, 0, st>>>(ps, S, mask, D, tmp_area, tmp_clon, tmp_clat, defer_list, defer_cnt, stats, err);
+    k_clip_quad<1><<<nblk(np, CLIP_THREADS), CLIP_THREADS, 0, st>>>(ps, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err);
 }
 
 void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
-                      double *tmp_area, double *tmp_clon, double *tmp_clat, int *defer_list, int *defer_cnt,
+                      double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
                       unsigned long long *stats, unsigned *err, hipStream_t st)
 {
   const long np = fgd_pairs_total(ps);
   if (np <= 0) return;
   int grid = nblk(np, GEN_THREADS); if (grid > 1024) grid = 1024;
   if (order == 2)
-    k_clip_general<2><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
+    k_clip_general<2><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
   else
-    k_clip_general<1><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, stats, err);
+    k_clip_general<1><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
 }
 
 void fgd_compact(int order, int nsrc, FgPairSpace ps, const FgCompactIo &io, hipStream_t st)
 {
   if (nsrc <= 0) return;
+  const long np = fgd_pairs_total(ps);
   if (order == 2) {
-    k_compact<2><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, ps, io);
+    if (np > 0) k_compact<2><<<nblk(np, 256), 256, 0, st>>>(nsrc, ps, io);
     k_compact_big<2><<<1024, 256, 0, st>>>(nsrc, ps, io);
   } else {
-    k_compact<1><<<nblk(nsrc, 256), 256, 0, st>>>(nsrc, ps, io);
+    if (np > 0) k_compact<1><<<nblk(np, 256), 256, 0, st>>>(nsrc, ps, io);
     k_compact_big<1><<<1024, 256, 0, st>>>(nsrc, ps, io);
   }
 }
