@@ -40,7 +40,7 @@ EXPORTS = [
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
     "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_gradient_records", "fg_c2l_records", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
     "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
-    "fg_plan_stats", "fg_set_search_mode", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
+    "fg_plan_stats", "fg_set_search_mode", "fg_set_search_chunks", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
 
 
@@ -194,6 +194,8 @@ def lib():
     L.fg_plan_stats.restype = C.c_int
     L.fg_set_search_mode.argtypes = [C.c_int]
     L.fg_set_search_mode.restype = None
+    L.fg_set_search_chunks.argtypes = [C.c_int]
+    L.fg_set_search_chunks.restype = None
     L.fg_set_profiling.argtypes = [C.c_int]
     L.fg_set_profiling.restype = None
     L.fg_plan_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]

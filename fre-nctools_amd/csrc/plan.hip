@@ -145,6 +145,25 @@ struct HandleCache {
     std::lock_guard<std::mutex> lk(mu);
     events[current_device()].push_back(e);
   }
+  // ordering-only events (stream A -> stream B dependencies of the chunked search)
+  std::map<int, std::vector<hipEvent_t>> sync_events;
+  hipEvent_t get_sync_event()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto &v = sync_events[current_device()];
+      if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    return e;
+  }
+  void put_sync_event(hipEvent_t e)
+  {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(mu);
+    sync_events[current_device()].push_back(e);
+  }
 };
 static HandleCache g_handles;
 
@@ -185,6 +204,7 @@ struct fg_plan {
   int order = 0, device = 0;
   bool great_circle = false;   // exchange cells from create_xgrid_great_circle semantics (order 1 only)
   hipStream_t stream = nullptr;
+  hipStream_t stream_b = nullptr;   // second stream of the chunked search (always ours)
   bool own_stream = true;
   int ntiles = 0;
   std::vector<int> nx_in, ny_in, cell_off;
@@ -279,6 +299,7 @@ extern "C" void fg_plan_destroy(fg_plan *pl)
   (void)hipSetDevice(pl->device);
   if (pl->stream || !pl->own_stream) (void)hipStreamSynchronize(pl->stream);
   if (pl->stream && pl->own_stream) g_handles.put_stream(pl->device, pl->stream);
+  if (pl->stream_b) { (void)hipStreamSynchronize(pl->stream_b); g_handles.put_stream(pl->device, pl->stream_b); }
   { float junk[PH_COUNT] = {0}; pl->apply_pt.collect(junk); }
   for (void *p : pl->owned) g_pool.put(p);
   delete pl;
@@ -333,6 +354,20 @@ static const char *gc_clip_error(int code)
 // 3*ndst, pairs 8*max(nsrc, ndst)) fit every remap between grids of comparable resolution; every kernel clamps its writes
 // AND reads to them, the counters keep counting, and an attempt that outgrew one is repeated with the counted sizes.
 struct SearchCaps { unsigned long long entries; int regcap, nreg; };
+// Chunks of source cells per search (1 = everything on one stream, in sequence; fg_set_search_chunks / FREGRID_HIP_CHUNKS).  Measured at C384 -> 0.25 deg with 4 chunks: the
+// kernels slow each other down by more than the overlap wins (clip 4 x 184 us against 482, step 1.48 ms against 1.30), so the
+// default is ONE chunk; the machinery stays for grids where the balance differs.
+static int g_search_chunks = 0;
+extern "C" void fg_set_search_chunks(int k) { g_search_chunks = k < 0 ? 0 : (k > FG_MAX_CHUNKS ? FG_MAX_CHUNKS : k); }
+static int choose_chunks(int nsrc, int nreg)
+{
+  static const int env_k = getenv("FREGRID_HIP_CHUNKS") ? atoi(getenv("FREGRID_HIP_CHUNKS")) : 0;
+  int k = g_search_chunks ? g_search_chunks : (env_k > 0 ? env_k : 1);
+  if (k > FG_MAX_CHUNKS) k = FG_MAX_CHUNKS;
+  const bool forced = g_search_chunks > 0 || env_k > 0;
+  while (k > 1 && (nreg / k < 1 || (!forced && nsrc / k < 4096))) k--;
+  return k;
+}
 #define FG_RETRY (-1000L)
 static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
@@ -403,7 +438,8 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   if (!alloc_cells(pl, &pl->S, nsrc) || !alloc_cells(pl, &pl->D, ndst)) return fail(FG_ERR_HIP, "out of device memory");
   // one zeroed block: [counters | region fill counters | tickets | look-back words of the three scans | bin counts |
   //                    bin fill cursors | destination-row counts | accepted pairs per source cell]
-  const long t_bins = fgd_scan_tiles(nslots), t_rows = fgd_scan_tiles(ndst), t_comp = fgd_scan_tiles(nsrc);
+  const int K = choose_chunks(nsrc, ps.nreg);
+  const long t_bins = fgd_scan_tiles(nslots), t_rows = fgd_scan_tiles(ndst), t_comp = fgd_scan_tiles(nsrc) + K;
   const size_t zc = (sizeof(FgCounters) + 127) / 128 * 128;
   const size_t zfill = (size_t)FG_NREG * FG_FILL_STRIDE * sizeof(unsigned);      // (nreg <= FG_NREG)
   const size_t ztick = 128;
@@ -435,7 +471,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     return fail(FG_ERR_HIP, "out of device memory");
   FgCounters *dc = (FgCounters *)zero_blk;
   ps.fill = (unsigned *)(zero_blk + zc);
-  unsigned *tickets = (unsigned *)(zero_blk + zc + zfill);                 // [0] bins [1] rows [2] compaction
+  unsigned *tickets = (unsigned *)(zero_blk + zc + zfill);                 // [0] bins [1] rows [2 + k] xoff scan of chunk k
   unsigned long long *lb_bins = (unsigned long long *)(zero_blk + zc + zfill + ztick), *lb_rows = lb_bins + t_bins, *lb_comp = lb_rows + t_rows;
   int *bin_cnt = (int *)(zero_blk + zc + zfill + ztick + zlb), *bin_fill = bin_cnt + (nslots + 1), *row_cnt = bin_fill + (nslots + 1);
   int *nacc = row_cnt + (ndst + 1);
@@ -463,47 +499,82 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   fgd_bin_fill(ndst, pl->D, bins, bin_fill, bin_start, bin_entries, ecap, nsrc, pl->S, pl->mask_dev, heavy_list, &dc->heavy_cnt, st);
   pt.end();
 
-  // --- candidate pairs (one pass)
+  // --- per chunk of source cells: candidates (stream A) -> clip (stream B) -> scan + compaction (stream A again).  The clip of
+  // chunk k is VALU bound, its neighbours in the schedule wait on memory: side by side they fill each other's gaps.
+  hipStream_t sb = st;
+  if (K > 1) {
+    if (!pl->stream_b) pl->stream_b = g_handles.get_stream(pl->device);
+    if (!pl->stream_b) return fail(FG_ERR_HIP, "hipStreamCreate failed");
+    sb = pl->stream_b;
+  }
+  std::vector<hipEvent_t> ev_c(K, nullptr), ev_q(K, nullptr);
+  PhaseTimer ptb; ptb.start(g_profiling != 0, sb);
+  int cb[FG_MAX_CHUNKS + 1];
+  for (int k = 0; k <= K; k++) cb[k] = (k == K) ? nsrc : (int)(((long)nsrc * k / K) / 256 * 256);
+  const int nreg_k = ps.nreg / K;                     // regions per chunk (choose_chunks keeps this >= 1)
+  const long pcap_k = (long)nreg_k * ps.regcap;       // pairs per chunk
+  auto chunk_ps = [&](int k) { FgPairSpace q = ps; q.nreg = nreg_k; q.src = ps.src + k * pcap_k; q.dst = ps.dst + k * pcap_k;
+                               q.fill = ps.fill + (size_t)k * nreg_k * FG_FILL_STRIDE; return q; };
   pt.begin(PH_CANDIDATES);
-  fgd_candidates1(nsrc, pl->S, pl->mask_dev, bins, bin_start, bin_entries, ecap, ps, pair_beg, pair_cnt, heavy_list, &dc->heavy_cnt, st);
+  for (int k = 0; k < K; k++) {
+    fgd_candidates1(cb[k], cb[k + 1], pl->S, pl->mask_dev, bins, bin_start, bin_entries, ecap, chunk_ps(k), pair_beg, pair_cnt, heavy_list,
+                    &dc->heavy_cnt, st);
+    if (K > 1) { ev_c[k] = g_handles.get_sync_event(); HIPCHK(hipEventRecord(ev_c[k], st)); }
+  }
   pt.end();
-
   // --- clip, area, centroid integrals
-  if (boxm) {
-    pt.begin(PH_CLIP_GENERAL);
-    fgd_clip_box(order, ps, boxm->box, th[pl->ntiles], pl->S, pl->D, pl->mask_dev, boxm->mask_quad, tmp_area, tmp_clon, tmp_clat, nacc, dc->stats, dc->err, st);
-    pt.end();
-  } else if (gc) {
-    pt.begin(PH_CLIP_GENERAL);
-    fgd_gc_clip(ps, pl->S, pl->mask_dev, pl->D, tmp_area, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
-    pt.end();
-  } else {
-    pt.begin(PH_CLIP_QUAD);
-    fgd_clip_quad(order, ps, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
-    pt.end();
-    pt.begin(PH_CLIP_GENERAL);
-    fgd_clip_general(order, ps, pl->S, pl->mask_dev, pl->D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, &dc->defer_cnt, dc->stats, dc->err, st);
+  for (int k = 0; k < K; k++) {
+    const FgPairSpace q = chunk_ps(k);
+    double *ta = tmp_area + k * pcap_k, *tl = tmp_clon ? tmp_clon + k * pcap_k : nullptr, *tt = tmp_clat ? tmp_clat + k * pcap_k : nullptr;
+    int *dl = defer_list + k * pcap_k;
+    if (K > 1) HIPCHK(hipStreamWaitEvent(sb, ev_c[k], 0));
+    if (boxm) {
+      ptb.begin(PH_CLIP_GENERAL);
+      fgd_clip_box(order, q, boxm->box, th[pl->ntiles], pl->S, pl->D, pl->mask_dev, boxm->mask_quad, ta, tl, tt, nacc, dc->stats, dc->err, sb);
+      ptb.end();
+    } else if (gc) {
+      ptb.begin(PH_CLIP_GENERAL);
+      fgd_gc_clip(q, pl->S, pl->mask_dev, pl->D, ta, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb);
+      ptb.end();
+    } else {
+      ptb.begin(PH_CLIP_QUAD);
+      fgd_clip_quad(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb);
+      ptb.end();
+      ptb.begin(PH_CLIP_GENERAL);
+      fgd_clip_general(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb);
+      ptb.end();
+    }
+    if (K > 1) { ev_q[k] = g_handles.get_sync_event(); HIPCHK(hipEventRecord(ev_q[k], sb)); }
+  }
+  // --- compaction into canonical order, per-source-cell sums, destination-row slots
+  long tile0 = 0;
+  for (int k = 0; k < K; k++) {
+    const FgPairSpace q = chunk_ps(k);
+    if (K > 1) HIPCHK(hipStreamWaitEvent(st, ev_q[k], 0));
+    pt.begin(PH_COMPACT);
+    FgCompactIo io{};
+    io.pair_beg = pair_beg; io.pair_cnt = pair_cnt;
+    io.tmp_area = tmp_area + k * pcap_k; io.tmp_clon = tmp_clon ? tmp_clon + k * pcap_k : nullptr; io.tmp_clat = tmp_clat ? tmp_clat + k * pcap_k : nullptr;
+    io.xoff = pl->xoff; io.x_src = pl->x_src; io.x_dst = pl->x_dst; io.x_area = pl->x_area; io.x_c1 = pl->x_c1; io.x_c2 = pl->x_c2;
+    io.row_cnt = row_cnt; io.x_rowpos = pl->x_rowpos; io.sums = pl->sums; io.big_list = big_list + cb[k]; io.big_cnt = &dc->big_cnt[k];
+    io.fill_all = (k == K - 1) ? ps.fill : nullptr; io.nreg_all = nreg_k * K;
+    io.dc = dc; io.xcap = nx_alloc;
+    const int nk = cb[k + 1] - cb[k];
+    fgd_exclusive_scan1(nacc + cb[k], nk, pl->xoff + cb[k], lb_comp + tile0, &tickets[2 + k], &dc->xtot[k], dc->err, st, k ? &dc->xtot[k - 1] : nullptr);
+    tile0 += fgd_scan_tiles(nk);
+    fgd_compact(order, nsrc, q, io, st);
     pt.end();
   }
-
-  // --- compaction into canonical order, per-source-cell sums, destination rows
-  pt.begin(PH_COMPACT);
-  FgCompactIo io{};
-  io.pair_beg = pair_beg; io.pair_cnt = pair_cnt; io.tmp_area = tmp_area; io.tmp_clon = tmp_clon; io.tmp_clat = tmp_clat;
-  io.xoff = pl->xoff; io.x_src = pl->x_src; io.x_dst = pl->x_dst; io.x_area = pl->x_area; io.x_c1 = pl->x_c1; io.x_c2 = pl->x_c2;
-  io.row_cnt = row_cnt; io.x_rowpos = pl->x_rowpos; io.sums = pl->sums; io.big_list = big_list;
-  io.dc = dc; io.xcap = nx_alloc;
-  fgd_exclusive_scan1(nacc, nsrc, pl->xoff, lb_comp, &tickets[2], &dc->total[2], dc->err, st);
-  fgd_compact(order, nsrc, ps, io, st);
-  pt.end();
   pt.begin(PH_ROWS);
   fgd_exclusive_scan1(row_cnt, ndst, pl->csr.row_ptr, lb_rows, &tickets[1], &dc->rows_total, dc->err, st);
-  fgd_csr_fill_pos(nx_alloc, &dc->total[2], pl->x_dst, pl->csr.row_ptr, pl->x_rowpos, pl->perm, st);
+  fgd_csr_fill_pos(nx_alloc, &dc->xtot[K - 1], pl->x_dst, pl->csr.row_ptr, pl->x_rowpos, pl->perm, st);
   pt.end();
   ptot.end();
   HIPCHK(hipMemcpyAsync(hc, dc, sizeof(FgCounters), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));                              // the one synchronisation of a search
-  pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms);          // (also hands the timing events back on every exit below)
+  HIPCHK(hipStreamSynchronize(st));                              // the one synchronisation of a search (stream B's work is ordered before it)
+  pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms); ptb.collect(pl->phase_ms);   // (also hands the timing events back on every exit below)
+  for (hipEvent_t e : ev_c) g_handles.put_sync_event(e);
+  for (hipEvent_t e : ev_q) g_handles.put_sync_event(e);
   HIPCHK(hipGetLastError());
   if (hc->total[0] > nentries) { caps->entries = hc->total[0]; return FG_RETRY; }
   if (hc->total[0] > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
@@ -521,14 +592,15 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   if (hc->err[0] & G_ERRBIT_GC_CONVEX2) return fail(FG_ERR_GEOM, "create_xgrid.c(clip_2dx2d_great_circle): grid box 2 is not convex");
   if (hc->err[0] & G_ERRBIT_GC_CLIP) return fail(FG_ERR_GEOM, "%s", gc_clip_error((int)hc->err[1]));
   if (hc->err[0] & G_ERRBIT_LOOKBACK) return fail(FG_ERR_HIP, "single-pass scan: a tile waited too long for its predecessor");
-  pl->nx = (long)hc->total[2];
+  pl->nx = (long)hc->xtot[K - 1];
   pl->stats[FG_STAT_PAIRS] = (long)hc->total[1];
-  pl->stats[FG_STAT_NONEMPTY] = (long)(hc->total[2] + hc->stats[FG_STAT_BELOW]);
+  pl->stats[FG_STAT_NONEMPTY] = (long)(hc->xtot[K - 1] + hc->stats[FG_STAT_BELOW]);
   pl->stats[FG_STAT_NXGRID] = pl->nx;
   pl->stats[FG_STAT_BORDERLINE] = (long)hc->stats[FG_STAT_BORDERLINE];
   pl->stats[FG_STAT_BINS] = nbins;
   pl->stats[FG_STAT_BIN_ENTRIES] = (long)hc->total[0];
-  pl->stats[FG_STAT_DEFERRED] = hc->defer_cnt;
+  pl->stats[FG_STAT_DEFERRED] = 0;
+  for (int k = 0; k < K; k++) pl->stats[FG_STAT_DEFERRED] += hc->defer_cnt[k];
   pl->stats[FG_STAT_HEAVY] = hc->heavy_cnt;
   pl->stats[FG_STAT_BELOW] = (long)hc->stats[FG_STAT_BELOW];
 
@@ -1845,6 +1917,7 @@ extern "C" int fg_halo_map(int ntiles, const int *nx, const int *ny, int ncontac
 struct fg_c2l {
   int device = 0, ntiles = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_b = nullptr;   // second stream of the chunked search (always ours)
   bool own_stream = true;
   long ncells = 0, F = 0;
   std::vector<int> nx, ny;

@@ -83,12 +83,17 @@ static inline long fgd_pairs_total(const FgPairSpace &ps) { return (long)ps.regc
 #define FG_TILESET_MAX 8
 struct FgTileSet { FgTile t[FG_TILESET_MAX]; int n; };
 
+// The source cells are searched in up to FG_MAX_CHUNKS chunks so that the VALU-bound clip of one chunk runs (on a second
+// stream) beside the latency-bound candidate scan of the next and the compaction of the previous one.
+#define FG_MAX_CHUNKS 8
 // device-side counters of one search (plan.hip reads them back once)
 struct FgCounters {
-  unsigned long long total[4];     // [0] bin-table entries  [1] candidate pairs  [2] nxgrid  [3] largest region fill
+  unsigned long long total[4];     // [0] bin-table entries  [1] candidate pairs  [2] (unused)  [3] largest region fill
   unsigned long long rows_total;   // total of the destination-row scan (= nxgrid)
+  unsigned long long xtot[FG_MAX_CHUNKS];   // running nxgrid after chunk k of the source cells (the last one is nxgrid)
   unsigned err[4];
-  int defer_cnt, heavy_cnt, big_cnt, pad1;
+  int heavy_cnt, pad0;
+  int defer_cnt[FG_MAX_CHUNKS], big_cnt[FG_MAX_CHUNKS];
   unsigned long long stats[FG_NSTATS];
 };
 #define G_ERRBIT_LOOKBACK 128u     // a single-pass scan waited too long for its predecessor tile (never observed)
@@ -96,8 +101,9 @@ struct FgCounters {
 // single-pass exclusive scan (decoupled look-back): n inputs -> n+1 prefixes (out[n] = total, also 64-bit in *total_dev).
 // status: zeroed words, one per tile of 2048 inputs (fgd_scan_tiles); ticket: zeroed word
 long fgd_scan_tiles(long n);
+// base_dev (may be null): a device value added to every prefix and to the total (chunked scans)
 void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *status, unsigned *ticket,
-                         unsigned long long *total_dev, unsigned *err, hipStream_t st);
+                         unsigned long long *total_dev, unsigned *err, hipStream_t st, const unsigned long long *base_dev = nullptr);
 
 // per-cell records of the source tiles and of the destination tile in ONE launch; also counts the destination cells into
 // their bins (slot_cnt), fills src_idx_f, zeroes sums[3][nsrc] (may be null) and stores the tile descriptors at tiles_out
@@ -108,7 +114,8 @@ void fgd_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt, hipStream_t s
 // bin fill + list of the source cells whose candidate scan gets a whole wave
 void fgd_bin_fill(int ndst, FgCells D, FgBins b, int *slot_fill, const int *slot_start, FgBinEntry *entries, int cap,
                   int nsrc, FgCells S, const double *mask, int *heavy_list, int *heavy_cnt, hipStream_t st);
-void fgd_candidates1(int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
+// source cells [c0, c1) only (one chunk); ps, pair_beg are the chunk's
+void fgd_candidates1(int c0, int c1, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
                      FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, hipStream_t st);
 void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
@@ -126,7 +133,10 @@ struct FgCompactIo {
   double *x_area, *x_c1, *x_c2;
   int *row_cnt, *x_rowpos;
   double *sums;                      // [3][nsrc] (order 2, zeroed: cells without exchange cells are not visited) or null
-  int *big_list;                     // [nsrc] scratch
+  int *big_list;                     // scratch for the chunk's big cells
+  int *big_cnt;                      // zeroed counter of big_list
+  const unsigned *fill_all;          // last chunk only: fill counters of ALL regions, summed up into dc->total[1] / [3]; else null
+  int nreg_all;
   FgCounters *dc;
   long xcap;                         // entries the x_* arrays hold
 };

@@ -124,14 +124,14 @@ __device__ inline unsigned long long d_lookback_wave(unsigned long long *status,
 
 // out[i] = exclusive prefix for i in [0, n] (n inputs, n+1 outputs; 32-bit offsets, 64-bit total for the host's checks)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan1(const int *in, long n, int *out, unsigned long long *status, unsigned *ticket,
-                                                        unsigned long long *total_out, unsigned *err)
+                                                        unsigned long long *total_out, unsigned *err, const unsigned long long *base_in)
 {
   __shared__ unsigned tile[SCAN_CHUNK];
   __shared__ int sh_t;
   __shared__ unsigned long long sh_excl;
-  if (threadIdx.x == 0) sh_t = (int)atomicAdd(ticket, 1u);
-  __syncthreads();
-  const int t = sh_t;
+  // ticket == null: the grid is small enough to be resident all at once, so no tile can wait for one that has not started
+  if (ticket) { if (threadIdx.x == 0) sh_t = (int)atomicAdd(ticket, 1u); __syncthreads(); }
+  const int t = ticket ? sh_t : (int)blockIdx.x;
   const long base = (long)t * SCAN_CHUNK;
   // thread k owns items k*SCAN_ITEMS .. +SCAN_ITEMS-1 of the chunk (blocked arrangement via LDS, coalesced global accesses)
 #pragma unroll
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan1(const int *in, long n, i
   const unsigned inc = block_incl_scan(s, &tot);
   if (threadIdx.x < 64) {
     const unsigned long long e = d_lookback_wave(status, t, (unsigned long long)tot, err);
-    if (threadIdx.x == 0) sh_excl = e;
+    if (threadIdx.x == 0) sh_excl = e + (base_in ? *base_in : 0ull);
   }
   __syncthreads();
   const unsigned long long excl = sh_excl;
@@ -169,10 +169,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan1(const int *in, long n, i
 long fgd_scan_tiles(long n) { if (n < 0) n = 0; return (n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK; }
 
 void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *status, unsigned *ticket,
-                         unsigned long long *total_dev, unsigned *err, hipStream_t st)
+                         unsigned long long *total_dev, unsigned *err, hipStream_t st, const unsigned long long *base_dev)
 {
   if (n < 0) n = 0;
-  k_scan1<<<(int)fgd_scan_tiles(n), SCAN_THREADS, 0, st>>>(in, n, out, status, ticket, total_dev, err);
+  const int nt = (int)fgd_scan_tiles(n);
+  k_scan1<<<nt, SCAN_THREADS, 0, st>>>(in, n, out, status, nt <= 1024 ? nullptr : ticket, total_dev, err, base_dev);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -507,6 +508,43 @@ __device__ __forceinline__ int d_heavy_scan(const SrcQuery &q, FgBins b, const i
   return cnt;
 }
 
+// One lane's share of a source cell's query: every CAND_G-th bin row, the <= 2 contiguous record ranges of each row, then the
+// wide lists of its rows.  Records are loaded four at a time ahead of their tests: the loop is a chain of L2 round trips
+// otherwise (one per record).  FILL = false counts and keeps the first four hits in ids[]; FILL = true writes the pairs
+// (same order) at psrc/pdst[wloc ...] while inside the region.
+template <bool FILL>
+__device__ __forceinline__ int d_lane_scan(const SrcQuery &q, int sub, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
+                                           double lat_in_min, double lat_in_max, double lon_in_min, double lon_in_max, double lon_in_avg,
+                                           int *ids, int s, int *psrc, int *pdst, unsigned wloc, unsigned regcap)
+{
+  const int nbins = b.nblat * b.nblon;
+  int cnt = 0;
+  auto visit = [&](const FgBinEntry &E, bool ok) {
+    if (!ok || !d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) return;
+    if (FILL) { if (wloc + cnt < regcap) { psrc[wloc + cnt] = s; pdst[wloc + cnt] = E.d; } }
+    else { ids[0] = cnt == 0 ? E.d : ids[0]; ids[1] = cnt == 1 ? E.d : ids[1]; ids[2] = cnt == 2 ? E.d : ids[2]; ids[3] = cnt == 3 ? E.d : ids[3]; }
+    cnt++;
+  };
+  auto range = [&](int e0, int e1, int wide_row) {
+    for (int eb = e0; eb < e1; eb += 4) {
+      FgBinEntry E[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) E[k] = entries[min(eb + k, e1 - 1)];
+#pragma unroll
+      for (int k = 0; k < 4; k++) visit(E[k], eb + k < e1 && (wide_row < 0 || wide_row == max(q.r0, E[k].row0)));   // a wide cell sits in every row it spans
+    }
+  };
+  for (int r = q.ra + sub; r <= q.rb; r += CAND_G) {
+    const int base = r * b.nblon;
+    const int a0 = slot_start[base + q.c_start], a1 = slot_start[base + q.c_start + q.n0];
+    const int b0 = q.n1 ? slot_start[base] : 0, b1 = q.n1 ? slot_start[base + q.n1] : 0;
+    range(a0, min(a1, ecap), -1);                        // a search may have outgrown its record buffer (it is then repeated)
+    range(b0, min(b1, ecap), -1);
+  }
+  for (int r = q.r0 + sub; r <= q.r1; r += CAND_G) range(slot_start[nbins + r], min(slot_start[nbins + r + 1], ecap), r);
+  return cnt;
+}
+
 // Blocks [0, nbR): CAND_G lanes per source cell, each scanning every CAND_G-th bin row of the cell's query.  A lane keeps
 // the first four destination cells it finds (the common case: 5.2 pairs per source cell over four lanes); the wave then adds
 // up its lanes' counts, reserves that many entries of its region of the pair list with ONE atomic, and every lane writes its
@@ -514,15 +552,17 @@ __device__ __forceinline__ int d_heavy_scan(const SrcQuery &q, FgBins b, const i
 // are contiguous: pair_beg / pair_cnt.  Blocks [nbR, nbR + HEAVY_BLOCKS): a wave per listed cell (count, reserve, fill).
 // (one wave per block: a block gives its slots back when its slowest wave is done, and the scan lengths vary a lot --
 // measured 256 / 128 / 64 threads: 0.240 / 0.230 / 0.224 ms for the old count pass)
-__global__ __launch_bounds__(64) void k_candidates1(int nsrc, int nbR, FgCells S, const double *mask, FgBins b, const int *slot_start,
+// The listed cells come FIRST in the grid: their waves run long and should start with the others, not after them.
+__global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCells S, const double *mask, FgBins b, const int *slot_start,
                                                      const FgBinEntry *entries, int ecap, FgPairSpace ps, int *pair_beg, int *pair_cnt,
                                                      const int *heavy_list, const int *heavy_cnt)
 {
   const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= nbR) {
-    const int nheavy = *heavy_cnt, H = gridDim.x - nbR;
-    for (int h = blockIdx.x - nbR; h < nheavy; h += H) {
+  if ((int)blockIdx.x < H) {
+    const int nheavy = *heavy_cnt;
+    for (int h = blockIdx.x; h < nheavy; h += H) {
       const int s = heavy_list[h];
+      if (s < c0 || s >= c1) continue;                    // another chunk's
       const double lat_in_min = S.lat_min[s], lat_in_max = S.lat_max[s];
       const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
       const SrcQuery q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
@@ -541,52 +581,29 @@ __global__ __launch_bounds__(64) void k_candidates1(int nsrc, int nbR, FgCells S
     }
     return;
   }
-  const long t = (long)blockIdx.x * 64 + lane;
-  const int s = (int)(t / CAND_G), sub = (int)(t % CAND_G);
+  const int bR = (int)blockIdx.x - H;                  // block among the four-lanes-per-cell blocks
+  const long t = (long)bR * 64 + lane;
+  const int s = c0 + (int)(t / CAND_G), sub = (int)(t % CAND_G);
+  const int nsrc = c1;
   int cnt = 0;
-  int id0 = -1, id1 = -1, id2 = -1, id3 = -1;
+  int ids[4] = {-1, -1, -1, -1};
   bool heavy = false;
   double lat_in_min = 0, lat_in_max = 0, lon_in_min = 0, lon_in_max = 0, lon_in_avg = 0;
   SrcQuery q{};
-  const int nbins = b.nblat * b.nblon;
   if (s < nsrc && d_src_active(S, mask, s)) {
     lat_in_min = S.lat_min[s]; lat_in_max = S.lat_max[s];
     lon_in_min = S.lon_min[s]; lon_in_max = S.lon_max[s]; lon_in_avg = S.lon_avg[s];
     q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
     heavy = d_query_size(q, b, slot_start) > HEAVY_ENTRIES;       // listed by k_bin_fill; a whole wave writes its pairs
-    if (!heavy) {
-      for (int r = q.ra + sub; r <= q.rb; r += CAND_G) {
-        int base = r * b.nblon;
-        for (int seg = 0; seg < 2; seg++) {
-          if (seg && !q.n1) break;
-          int e0 = seg ? slot_start[base] : slot_start[base + q.c_start];
-          int e1 = seg ? slot_start[base + q.n1] : slot_start[base + q.c_start + q.n0];
-          e1 = min(e1, ecap);                              // a search may have outgrown its record buffer (it is then repeated)
-          for (int e = e0; e < e1; e++) {
-            const FgBinEntry E = entries[e];
-            if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
-            id0 = cnt == 0 ? E.d : id0; id1 = cnt == 1 ? E.d : id1; id2 = cnt == 2 ? E.d : id2; id3 = cnt == 3 ? E.d : id3;
-            cnt++;
-          }
-        }
-      }
-      for (int r = q.r0 + sub; r <= q.r1; r += CAND_G) {
-        int e0 = slot_start[nbins + r], e1 = min(slot_start[nbins + r + 1], ecap);
-        for (int e = e0; e < e1; e++) {
-          const FgBinEntry E = entries[e];
-          if (r != max(q.r0, E.row0)) continue;          // a wide cell sits in every row it spans
-          if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
-          id0 = cnt == 0 ? E.d : id0; id1 = cnt == 1 ? E.d : id1; id2 = cnt == 2 ? E.d : id2; id3 = cnt == 3 ? E.d : id3;
-          cnt++;
-        }
-      }
-    }
+    if (!heavy)
+      cnt = d_lane_scan<false>(q, sub, b, slot_start, entries, ecap, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg,
+                               ids, s, nullptr, nullptr, 0u, 0u);
   }
   // the wave's range in its region of the pair list
   const unsigned incl = wave_incl_scan((unsigned)cnt, lane);
   const unsigned total = __shfl(incl, 63);
   const unsigned excl = incl - (unsigned)cnt;
-  const int r = (blockIdx.x / CAND_CHUNK) % ps.nreg;   // 256 consecutive cells share a region: neighbouring pairs stay neighbours for the clip
+  const int r = (bR / CAND_CHUNK) % ps.nreg;           // 256 consecutive cells share a region: neighbouring pairs stay neighbours for the clip
   unsigned base = 0;
   if (lane == 0 && total) base = atomicAdd(&ps.fill[r * FG_FILL_STRIDE], total);
   base = __shfl(base, 0);
@@ -604,38 +621,13 @@ __global__ __launch_bounds__(64) void k_candidates1(int nsrc, int nbR, FgCells S
   const unsigned wloc = base + excl;                    // this lane's first entry within the region
   int *psrc = ps.src + (size_t)r * ps.regcap, *pdst = ps.dst + (size_t)r * ps.regcap;
   if (cnt <= 4) {
-    const int ids[4] = {id0, id1, id2, id3};
 #pragma unroll
     for (int k = 0; k < 4; k++)
       if (k < cnt && wloc + k < (unsigned)ps.regcap) { psrc[wloc + k] = s; pdst[wloc + k] = ids[k]; }
     return;
   }
-  int w = 0;
-  for (int rr = q.ra + sub; rr <= q.rb; rr += CAND_G) {
-    int rb = rr * b.nblon;
-    for (int seg = 0; seg < 2; seg++) {
-      if (seg && !q.n1) break;
-      int e0 = seg ? slot_start[rb] : slot_start[rb + q.c_start];
-      int e1 = seg ? slot_start[rb + q.n1] : slot_start[rb + q.c_start + q.n0];
-      e1 = min(e1, ecap);
-      for (int e = e0; e < e1; e++) {
-        const FgBinEntry E = entries[e];
-        if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
-        if (wloc + w < (unsigned)ps.regcap) { psrc[wloc + w] = s; pdst[wloc + w] = E.d; }
-        w++;
-      }
-    }
-  }
-  for (int rr = q.r0 + sub; rr <= q.r1; rr += CAND_G) {
-    int e0 = slot_start[nbins + rr], e1 = min(slot_start[nbins + rr + 1], ecap);
-    for (int e = e0; e < e1; e++) {
-      const FgBinEntry E = entries[e];
-      if (rr != max(q.r0, E.row0)) continue;
-      if (!d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg)) continue;
-      if (wloc + w < (unsigned)ps.regcap) { psrc[wloc + w] = s; pdst[wloc + w] = E.d; }
-      w++;
-    }
-  }
+  (void)d_lane_scan<true>(q, sub, b, slot_start, entries, ecap, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg,
+                          ids, s, psrc, pdst, wloc, (unsigned)ps.regcap);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -765,6 +757,9 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
 
 // Result encoding shared by the clip kernels and the compaction: an accepted pair keeps pair_dst[p] = d and
 // gets tmp_area/clon/clat[p]; a rejected pair gets pair_dst[p] = -1.
+// (The integrals loop over the polygon's edges and a wave runs as many iterations as its largest polygon has.  Re-binning the
+// block's 256 polygons by vertex count through LDS before the integrals, so that a wave sees polygons of equal size, was
+// measured: 502 us against 482 -- the extra barriers and the scattered LDS columns cost more than the divergence.)
 template <int ORDER>
 __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
                                                             double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
@@ -989,7 +984,7 @@ __global__ __launch_bounds__(256) void k_compact(int nsrc, FgPairSpace ps, FgCom
   const unsigned long long bm = __ballot(first && c.cnt > CP_SMALL);
   if (bm) {
     int q = 0;
-    if (lane == 0) q = atomicAdd(&io.dc->big_cnt, __popcll(bm));
+    if (lane == 0) q = atomicAdd(io.big_cnt, __popcll(bm));
     q = __shfl(q, 0);
     if (first && c.cnt > CP_SMALL) io.big_list[q + __popcll(bm & ((1ull << lane) - 1ull))] = c.s;
   }
@@ -1016,14 +1011,14 @@ __global__ __launch_bounds__(256) void k_compact_big(int nsrc, FgPairSpace ps, F
   __shared__ int pref[RANK_WORDS];
   __shared__ int smin, smax;
   __shared__ double sval[3][BIG_STAGE];
-  if (blockIdx.x == 0 && threadIdx.x < 64) {           // candidate totals for the host's capacity checks
+  if (io.fill_all && blockIdx.x == 0 && threadIdx.x < 64) {           // candidate totals for the host's capacity checks
     unsigned long long f = 0; unsigned mx = 0;
-    for (int r = threadIdx.x; r < ps.nreg; r += 64) { const unsigned v = ps.fill[r * FG_FILL_STRIDE]; f += v; mx = max(mx, v); }
+    for (int r = threadIdx.x; r < io.nreg_all; r += 64) { const unsigned v = io.fill_all[r * FG_FILL_STRIDE]; f += v; mx = max(mx, v); }
 #pragma unroll
     for (int o = 32; o; o >>= 1) { f += __shfl_xor(f, o); mx = max(mx, (unsigned)__shfl_xor((int)mx, o)); }
     if (threadIdx.x == 0) { io.dc->total[1] = f; io.dc->total[3] = mx; }
   }
-  const int nb = io.dc->big_cnt;
+  const int nb = *io.big_cnt;
   for (int h = blockIdx.x; h < nb; h += gridDim.x) {
     const int s = io.big_list[h];
     const int o = io.pair_beg[s], c = io.pair_cnt[s];
@@ -1172,13 +1167,13 @@ void fgd_bin_fill(int ndst, FgCells D, FgBins b, int *slot_fill, const int *slot
     k_bin_fill<<<nbD + nbS, 256, 0, st>>>(ndst, nbD, D, b, slot_fill, slot_start, entries, cap, nsrc, S, mask, heavy_list, heavy_cnt);
 }
 
-void fgd_candidates1(int nsrc, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
+void fgd_candidates1(int c0, int c1, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
                      FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, hipStream_t st)
 {
-  if (nsrc <= 0) return;
-  const int nbR = nblk((long)nsrc * CAND_G, 64);
-  const int H = min(HEAVY_BLOCKS, max(64, nblk(nsrc, 64)));
-  k_candidates1<<<nbR + H, 64, 0, st>>>(nsrc, nbR, S, mask, b, slot_start, entries, ecap, ps, pair_beg, pair_cnt, heavy_list, heavy_cnt);
+  if (c1 <= c0) return;
+  const int nbR = nblk((long)(c1 - c0) * CAND_G, 64);
+  const int H = min(HEAVY_BLOCKS, max(64, nblk(c1 - c0, 64)));
+  k_candidates1<<<nbR + H, 64, 0, st>>>(c0, c1, H, S, mask, b, slot_start, entries, ecap, ps, pair_beg, pair_cnt, heavy_list, heavy_cnt);
 }
 
 void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,

@@ -280,11 +280,15 @@ int  fg_plan_phase_ms(fg_plan *plan, float *ms, int n);   /* [9] = mean over the
  * [2]=nxgrid, [3]=pairs whose area ratio is within 1e-9 (relative) of the 1e-6 threshold,
  * [4]=bins, [5]=bin entries.  n = capacity of stats. */
 int fg_plan_stats(const fg_plan *plan, long *stats, int n);
-/* Search buffer sizing.  Default (0): single-synchronisation search -- buffers sized by capacity (bin entries 2*ndst,
- * candidate pairs and exchange cells 8*max(nsrc, ndst)), counts stay on the device, one readback at the end; a search
- * that overflows a capacity is repeated transparently in exact mode.  1: always size every buffer exactly (three
- * readbacks; smaller plans).  Also selectable with the environment variable FREGRID_HIP_EXACT_SEARCH=1. */
+/* Search mode.  0 (default): every buffer of the search is sized by capacity (bin records 3*ndst, candidate pairs and
+ * exchange cells 8*max(nsrc, ndst)), counts stay on the device and the host synchronises once, at the end; a search that
+ * outgrows a capacity is repeated transparently with the sizes its counters report.  1: size every buffer by counting
+ * first (extra passes; smallest plans).  Also selectable with the environment variable FREGRID_HIP_EXACT_SEARCH=1. */
 void fg_set_search_mode(int exact);
+/* Chunks of source cells per search: the clip of one chunk runs on a second stream beside the candidate scan of the next and
+ * the compaction of the previous one.  0 (default) = 1: one stream, in sequence -- at C384 -> 0.25 deg the overlapped kernels
+ * slow each other down by more than the overlap wins.  Results do not depend on it.  Also FREGRID_HIP_CHUNKS. */
+void fg_set_search_chunks(int chunks);
 
 /* Batched polygon primitives on the device.  Polygons are rows of host arrays [npoly][24];
  * inputs have at most 12 vertices (8 for fix_lon).  fg_clip_2dx2d_batch: n_out[p] = vertex count,

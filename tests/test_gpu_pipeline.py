@@ -372,6 +372,23 @@ def test_fast_search_overflow_falls_back_to_exact_mode(fg, gpu_ok):
     assert st2["exact_mode"] == 1 and n1 == n2 and st1["pairs"] == st2["pairs"]
 
 
+def test_chunked_search_gives_the_same_plan(fg, gpu_ok):
+    """Large grids are searched in chunks of source cells (clip of one chunk on a second stream beside the candidate scan of
+    the next): force 1, 3 and 8 chunks on a small case -- exchange cells, order-2 integrals and the sweep must not change."""
+    lon, lat = fg.gnomonic_ed_corners(24)
+    lo, la = fg.latlon_corners(72, 36)
+    gin, gout = [(24, 24, lon[t], lat[t]) for t in range(6)], (72, 36, lo, la)
+    res = []
+    try:
+        for k in (1, 3, 8):
+            fg.lib().fg_set_search_chunks(k)
+            res.append(_plan_vs_oracle(fg, 2, gin, gout))
+    finally:
+        fg.lib().fg_set_search_chunks(0)
+    assert res[0][0] == res[1][0] == res[2][0] > 0
+    assert res[0][1]["pairs"] == res[1][1]["pairs"] == res[2][1]["pairs"]
+
+
 def test_bin_record_overflow_falls_back_to_exact_mode(fg, gpu_ok):
     """Bins no larger than the target cells (the caller's mean cell size is an input): every target cell then spans four bin
     rows, lands in the per-row wide lists four times and the single-sync search's record buffer (3 per target cell) is too
