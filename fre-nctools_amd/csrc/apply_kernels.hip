@@ -64,7 +64,7 @@ template <int ORDER, int RPW, bool DIST>
 __global__ __launch_bounds__(64) void k_csr_sortgather(int ndst, int *perm, const int *x_src, const double *x_area, const double *x_c1,
                                                         const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr)
 {
-  constexpr int SHORT = 12, CAP = (RPW >= 64) ? 1024 : 2048, BT = 64;     // 8 KB of LDS per wave in the short-row case: 20 waves per CU
+  constexpr int SHORT = 12, CAP = (RPW >= 64) ? 512 : 2048, BT = 64;      // 4 KB of LDS per wave in the short-row case
   __shared__ int sh[CAP], sh2[CAP];
   __shared__ int long_b[RPW], long_n[RPW];
   __shared__ int nlong;

@@ -518,7 +518,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pt.begin(PH_CANDIDATES);
   for (int k = 0; k < K; k++) {
     fgd_candidates1(cb[k], cb[k + 1], pl->S, pl->mask_dev, bins, bin_start, bin_entries, ecap, chunk_ps(k), pair_beg, pair_cnt, heavy_list,
-                    &dc->heavy_cnt, st);
+                    &dc->heavy_cnt, big_list + cb[k], &dc->big_cnt[k], st);
     if (K > 1) { ev_c[k] = g_handles.get_sync_event(); HIPCHK(hipEventRecord(ev_c[k], st)); }
   }
   pt.end();

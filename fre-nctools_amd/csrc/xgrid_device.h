@@ -116,7 +116,8 @@ void fgd_bin_fill(int ndst, FgCells D, FgBins b, int *slot_fill, const int *slot
                   int nsrc, FgCells S, const double *mask, int *heavy_list, int *heavy_cnt, hipStream_t st);
 // source cells [c0, c1) only (one chunk); ps, pair_beg are the chunk's
 void fgd_candidates1(int c0, int c1, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
-                     FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, hipStream_t st);
+                     FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, int *big_list, int *big_cnt,
+                     hipStream_t st);
 void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
               unsigned long long *stats, unsigned *err, hipStream_t st);
@@ -133,8 +134,8 @@ struct FgCompactIo {
   double *x_area, *x_c1, *x_c2;
   int *row_cnt, *x_rowpos;
   double *sums;                      // [3][nsrc] (order 2, zeroed: cells without exchange cells are not visited) or null
-  int *big_list;                     // scratch for the chunk's big cells
-  int *big_cnt;                      // zeroed counter of big_list
+  const int *big_list;               // the chunk's cells with more than CP_SMALL pairs (from the candidate kernel)
+  const int *big_cnt;
   const unsigned *fill_all;          // last chunk only: fill counters of ALL regions, summed up into dc->total[1] / [3]; else null
   int nreg_all;
   FgCounters *dc;

@@ -424,6 +424,7 @@ __device__ __forceinline__ bool d_box_pass(const FgBinEntry &E, double lat_in_mi
                               // give 0.31 / 0.27 / 0.28 / 0.305 / 0.38 ms for the candidate phase at C384 -> 0.25 deg; the lanes with the
                               // longest scans set the duration of the four-lanes-per-cell path)
 #define CAND_G 4          // lanes per source cell in the candidate scan (one bin row each)
+#define CP_SMALL 32       // pairs per cell up to which the lanes of k_compact rank by comparison; cells with more are "big"
 #define CAND_CHUNK 16    // consecutive waves (of 16 cells) that append to the same region
 #define HEAVY_BLOCKS 2048 // waves serving the listed cells, appended to the grid of the four-lanes-per-cell blocks
 
@@ -555,7 +556,7 @@ __device__ __forceinline__ int d_lane_scan(const SrcQuery &q, int sub, FgBins b,
 // The listed cells come FIRST in the grid: their waves run long and should start with the others, not after them.
 __global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCells S, const double *mask, FgBins b, const int *slot_start,
                                                      const FgBinEntry *entries, int ecap, FgPairSpace ps, int *pair_beg, int *pair_cnt,
-                                                     const int *heavy_list, const int *heavy_cnt)
+                                                     const int *heavy_list, const int *heavy_cnt, int *big_list, int *big_cnt)
 {
   const int lane = threadIdx.x;
   if ((int)blockIdx.x < H) {
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCel
       if (n_ok > 0)
         (void)d_heavy_scan<true>(q, b, slot_start, entries, ecap, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg,
                                  s, ps.src, ps.dst, wbase, n_ok);
-      if (lane == 0) { pair_beg[s] = wbase; pair_cnt[s] = n_ok; }
+      if (lane == 0) { pair_beg[s] = wbase; pair_cnt[s] = n_ok; if (n_ok > CP_SMALL) big_list[atomicAdd(big_cnt, 1)] = s; }
     }
     return;
   }
@@ -590,6 +591,9 @@ __global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCel
   bool heavy = false;
   double lat_in_min = 0, lat_in_max = 0, lon_in_min = 0, lon_in_max = 0, lon_in_avg = 0;
   SrcQuery q{};
+  // (Issuing the loads of each link of the chain -- cell box, slot offsets, first records of every range -- together, ahead of
+  // the branches that may not need them, was measured: 223 us against 165.  The kernel is bound by the number of 48-byte record
+  // requests its lanes make, not by their latency, and speculation adds requests.)
   if (s < nsrc && d_src_active(S, mask, s)) {
     lat_in_min = S.lat_min[s]; lat_in_max = S.lat_max[s];
     lon_in_min = S.lon_min[s]; lon_in_max = S.lon_max[s]; lon_in_avg = S.lon_avg[s];
@@ -616,6 +620,16 @@ __global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCel
     const int loc0 = (int)min(first, (unsigned)ps.regcap);
     pair_beg[s] = r * ps.regcap + loc0;
     pair_cnt[s] = min(c4, ps.regcap - loc0);
+  }
+  {                                                     // cells for the big-cell blocks of the compaction (rare here)
+    const bool bigc = sub == 0 && s < nsrc && !heavy && min(c4, ps.regcap - (int)min(base + excl0, (unsigned)ps.regcap)) > CP_SMALL;
+    const unsigned long long bm = __ballot(bigc);
+    if (bm) {
+      int q = 0;
+      if (lane == 0) q = atomicAdd(big_cnt, __popcll(bm));
+      q = __shfl(q, 0);
+      if (bigc) big_list[q + __popcll(bm & ((1ull << lane) - 1ull))] = s;
+    }
   }
   if (cnt == 0) return;
   const unsigned wloc = base + excl;                    // this lane's first entry within the region
@@ -923,11 +937,10 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
 //   * order 2: the values go to LDS at the cell's first pair + rank, and the lane holding the cell's first pair adds them up
 //     in that order = exchange-cell order (conserve_interp.c:216-221).
 // Cells with more than CP_SMALL pairs ("big": the cells around a pole of the target grid, every cell of a coarse -> fine
-// remap) are listed for k_compact_big.  Nothing depends on the order in which the candidate kernel filled the pair list.
+// remap; listed by the candidate kernel) are done by the big-cell blocks of the same launch.  Nothing depends on the order in which the candidate kernel filled the pair list.
 // (Measured at C384 -> 0.25 deg: 109 us.  A first version gave each block 256 source cells and found xoff by look-back inside the
 // kernel: 320-430 us -- its per-cell loads of the pair list are strided, and a chain of dependent round trips per block does not
 // hide behind five blocks per CU; a lane-per-pair version that left the cells cut by a block boundary to one lane: 245 us.)
-#define CP_SMALL 32          // pairs per cell up to which the lanes of k_compact rank by comparison
 #define CP_SPAN (256 + CP_SMALL)
 
 struct CpPair { int s, d, beg, cnt, li; long x0; int na; double a, l, t; bool mine; };
@@ -964,53 +977,21 @@ __device__ __forceinline__ void d_cp_place(const FgCompactIo &io, const CpPair &
   io.x_rowpos[pos] = atomicAdd(&io.row_cnt[c.d], 1);
 }
 
-template <int ORDER>
-__global__ __launch_bounds__(256) void k_compact(int nsrc, FgPairSpace ps, FgCompactIo io)
-{
-  __shared__ int sh_d[CP_SPAN];
-  __shared__ double sh_v[3][CP_SPAN];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int p0 = blockIdx.x * 256;
-  const unsigned r = (unsigned)p0 / (unsigned)ps.regcap;          // block-uniform
-  const unsigned rfill = ps.fill[r * FG_FILL_STRIDE];
-  const unsigned live_end = r * (unsigned)ps.regcap + (rfill < (unsigned)ps.regcap ? rfill : (unsigned)ps.regcap);   // end of the region's pairs
-  if ((unsigned)p0 >= live_end) return;
-  const CpPair c = d_cp_load<ORDER>(ps, io, p0 + tid, p0, live_end, false);
-  CpPair h; h.mine = false; h.d = -1;
-  if (tid < CP_SMALL) { h = d_cp_load<ORDER>(ps, io, p0 + 256 + tid, p0, live_end, true); sh_d[256 + tid] = h.d; }
-  sh_d[tid] = c.d;
-  __syncthreads();
-  const bool first = (unsigned)(p0 + tid) < live_end && p0 + tid == c.beg;
-  const unsigned long long bm = __ballot(first && c.cnt > CP_SMALL);
-  if (bm) {
-    int q = 0;
-    if (lane == 0) q = atomicAdd(io.big_cnt, __popcll(bm));
-    q = __shfl(q, 0);
-    if (first && c.cnt > CP_SMALL) io.big_list[q + __popcll(bm & ((1ull << lane) - 1ull))] = c.s;
-  }
-  d_cp_place<ORDER>(io, c, p0, sh_d, sh_v);
-  if (tid < CP_SMALL) d_cp_place<ORDER>(io, h, p0, sh_d, sh_v);
-  if (ORDER != 2 || !io.sums) return;
-  __syncthreads();
-  if (!first || !c.mine || c.x0 + c.na > io.xcap) return;
-  double sa = 0, sl = 0, st = 0;
-  const int lb = c.beg - p0;
-  for (int k = 0; k < c.na; k++) { sa += sh_v[0][lb + k]; sl += sh_v[1][lb + k]; st += sh_v[2][lb + k]; }
-  io.sums[c.s] = sa; io.sums[nsrc + c.s] = sl; io.sums[2 * (size_t)nsrc + c.s] = st;
-}
+#define RANK_WORDS 1024      // 65536 destination indices: 45 rows of a 1440-column grid
+#define BIG_STAGE 512
+#define BIG_BLOCKS 512       // blocks of the big-cell role, in front of the lane-per-pair blocks
+#define CP_LDS_DOUBLES (RANK_WORDS + RANK_WORDS / 2 + 3 * BIG_STAGE)   // the larger of the two roles' LDS needs (24 KB)
 
 // The big cells: a block per cell.  Ranking a pair by comparing it with all the others of its cell is quadratic (great-circle
 // search: ~3000 pairs in each of ~600 cells); here the block marks the cell's destination indices in an LDS bitmap over their
 // span and reads each rank off as a prefix population count: linear.  Spans that do not fit fall back to the comparison.
-#define RANK_WORDS 2048      // 131072 destination indices: 91 rows of a 1440-column grid
-#define BIG_STAGE 1024
 template <int ORDER>
-__global__ __launch_bounds__(256) void k_compact_big(int nsrc, FgPairSpace ps, FgCompactIo io)
+__device__ __forceinline__ void d_compact_big(int nsrc, const FgPairSpace &ps, const FgCompactIo &io, double *lds)
 {
-  __shared__ unsigned long long bits[RANK_WORDS];
-  __shared__ int pref[RANK_WORDS];
+  unsigned long long *bits = (unsigned long long *)lds;              // [RANK_WORDS]
+  int *pref = (int *)(lds + RANK_WORDS);                             // [RANK_WORDS]
+  double (*sval)[BIG_STAGE] = (double (*)[BIG_STAGE])(lds + RANK_WORDS + RANK_WORDS / 2);   // [3][BIG_STAGE]
   __shared__ int smin, smax;
-  __shared__ double sval[3][BIG_STAGE];
   if (io.fill_all && blockIdx.x == 0 && threadIdx.x < 64) {           // candidate totals for the host's capacity checks
     unsigned long long f = 0; unsigned mx = 0;
     for (int r = threadIdx.x; r < io.nreg_all; r += 64) { const unsigned v = io.fill_all[r * FG_FILL_STRIDE]; f += v; mx = max(mx, v); }
@@ -1019,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_compact_big(int nsrc, FgPairSpace ps, F
     if (threadIdx.x == 0) { io.dc->total[1] = f; io.dc->total[3] = mx; }
   }
   const int nb = *io.big_cnt;
-  for (int h = blockIdx.x; h < nb; h += gridDim.x) {
+  for (int h = blockIdx.x; h < nb; h += BIG_BLOCKS) {
     const int s = io.big_list[h];
     const int o = io.pair_beg[s], c = io.pair_cnt[s];
     const long x0 = io.xoff[s];
@@ -1052,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_compact_big(int nsrc, FgPairSpace ps, F
       for (int w = w0; w < w1; w++) { pref[w] = run; run += __popcll(bits[w]); }
       __syncthreads();
     }
-    // exchange cells to their places; order 2: the values also go to LDS in rank order, 1024 ranks at a time, where three
+    // exchange cells to their places; order 2: the values also go to LDS in rank order, BIG_STAGE ranks at a time, where three
     // lanes (one array each) add them up in exchange-cell order -- hundreds to thousands of ordered additions per cell, which
     // from global memory (even with the loads 16 ahead) set the duration of the whole compaction
     double acc = 0;
@@ -1094,6 +1075,38 @@ __global__ __launch_bounds__(256) void k_compact_big(int nsrc, FgPairSpace ps, F
     }
     if (ORDER == 2 && io.sums && threadIdx.x < 3) io.sums[(size_t)threadIdx.x * nsrc + s] = acc;
   }
+}
+
+// Blocks [0, BIG_BLOCKS): the big cells (listed by the candidate kernel); the rest: one lane per pair.  One launch, so that the
+// few long-running big-cell blocks start first and run beside the others instead of after them.
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_compact(int nsrc, FgPairSpace ps, FgCompactIo io)
+{
+  __shared__ double lds[CP_LDS_DOUBLES];
+  if ((int)blockIdx.x < BIG_BLOCKS) { d_compact_big<ORDER>(nsrc, ps, io, lds); return; }
+  int *sh_d = (int *)lds;                                            // [CP_SPAN]
+  double (*sh_v)[CP_SPAN] = (double (*)[CP_SPAN])(lds + CP_SPAN / 2 + 8);   // [3][CP_SPAN]
+  const int tid = threadIdx.x;
+  const int p0 = ((int)blockIdx.x - BIG_BLOCKS) * 256;
+  const unsigned r = (unsigned)p0 / (unsigned)ps.regcap;          // block-uniform
+  const unsigned rfill = ps.fill[r * FG_FILL_STRIDE];
+  const unsigned live_end = r * (unsigned)ps.regcap + (rfill < (unsigned)ps.regcap ? rfill : (unsigned)ps.regcap);   // end of the region's pairs
+  if ((unsigned)p0 >= live_end) return;
+  const CpPair c = d_cp_load<ORDER>(ps, io, p0 + tid, p0, live_end, false);
+  CpPair h; h.mine = false; h.d = -1;
+  if (tid < CP_SMALL) { h = d_cp_load<ORDER>(ps, io, p0 + 256 + tid, p0, live_end, true); sh_d[256 + tid] = h.d; }
+  sh_d[tid] = c.d;
+  __syncthreads();
+  const bool first = (unsigned)(p0 + tid) < live_end && p0 + tid == c.beg;
+  d_cp_place<ORDER>(io, c, p0, sh_d, sh_v);
+  if (tid < CP_SMALL) d_cp_place<ORDER>(io, h, p0, sh_d, sh_v);
+  if (ORDER != 2 || !io.sums) return;
+  __syncthreads();
+  if (!first || !c.mine || c.x0 + c.na > io.xcap) return;
+  double sa = 0, sl = 0, st = 0;
+  const int lb = c.beg - p0;
+  for (int k = 0; k < c.na; k++) { sa += sh_v[0][lb + k]; sl += sh_v[1][lb + k]; st += sh_v[2][lb + k]; }
+  io.sums[c.s] = sa; io.sums[nsrc + c.s] = sl; io.sums[2 * (size_t)nsrc + c.s] = st;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1168,12 +1181,13 @@ void fgd_bin_fill(int ndst, FgCells D, FgBins b, int *slot_fill, const int *slot
 }
 
 void fgd_candidates1(int c0, int c1, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
-                     FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, hipStream_t st)
+                     FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, int *big_list, int *big_cnt,
+                     hipStream_t st)
 {
   if (c1 <= c0) return;
   const int nbR = nblk((long)(c1 - c0) * CAND_G, 64);
   const int H = min(HEAVY_BLOCKS, max(64, nblk(c1 - c0, 64)));
-  k_candidates1<<<nbR + H, 64, 0, st>>>(c0, c1, H, S, mask, b, slot_start, entries, ecap, ps, pair_beg, pair_cnt, heavy_list, heavy_cnt);
+  k_candidates1<<<nbR + H, 64, 0, st>>>(c0, c1, H, S, mask, b, slot_start, entries, ecap, ps, pair_beg, pair_cnt, heavy_list, heavy_cnt, big_list, big_cnt);
 }
 
 void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
@@ -1205,13 +1219,8 @@ void fgd_compact(int order, int nsrc, FgPairSpace ps, const FgCompactIo &io, hip
 {
   if (nsrc <= 0) return;
   const long np = fgd_pairs_total(ps);
-  if (order == 2) {
-    if (np > 0) k_compact<2><<<nblk(np, 256), 256, 0, st>>>(nsrc, ps, io);
-    k_compact_big<2><<<1024, 256, 0, st>>>(nsrc, ps, io);
-  } else {
-    if (np > 0) k_compact<1><<<nblk(np, 256), 256, 0, st>>>(nsrc, ps, io);
-    k_compact_big<1><<<1024, 256, 0, st>>>(nsrc, ps, io);
-  }
+  if (order == 2) k_compact<2><<<BIG_BLOCKS + nblk(np, 256), 256, 0, st>>>(nsrc, ps, io);
+  else            k_compact<1><<<BIG_BLOCKS + nblk(np, 256), 256, 0, st>>>(nsrc, ps, io);
 }
 
 void fgd_centroids(int nsrc, FgCells S, const double *sums, double *cen, hipStream_t st)
