@@ -23,6 +23,8 @@ from ._lib import FregridHipError, lib, lib_path  # noqa: F401
 from .grids import gnomonic_ed_corners, gnomonic_ed_grid, latlon_corners, tripolar_corners  # noqa: F401
 from .c2l import C2lPrep, find_contacts, c2l_grid_info, halo_map  # noqa: F401
 from .remap_file import write_remap_file, read_remap_file  # noqa: F401
+from .field_io import NcFile, Sweep, HostBuffer, read_field_levels  # noqa: F401
+from . import field_io  # noqa: F401
 from .parallel import (band_rows, allreduce_cell_sums, allreduce_scalar_sum, allreduce_minmax,  # noqa: F401
                        boundary_source_cells, allreduce_cell_sums_sparse)
 from .conserve_interp import (  # noqa: F401

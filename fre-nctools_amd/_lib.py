@@ -20,7 +20,7 @@ def lib_path():
     return os.path.join(_HERE, "libfregrid_hip.so")
 
 
-# every symbol include/fregrid_hip.h declares (checked by tests/test_capi_symbols.py)
+# every symbol include/fregrid_hip.h declares (tests/test_cpu_capi_and_oracle.py::test_library_exports_every_declared_symbol)
 EXPORTS = [
     "get_maxxgrid", "get_grid_area", "create_xgrid_2dx2d_order1", "create_xgrid_2dx2d_order2", "conserve_interp",
     "clip_2dx2d", "poly_area", "poly_ctrlon", "poly_ctrlat", "fix_lon", "pimod",
@@ -40,6 +40,11 @@ EXPORTS = [
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
     "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_gradient_records", "fg_c2l_records", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
     "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
+    "fg_plan_ncells_out", "fg_plan_order", "fg_plan_device",
+    "fg_nc_open", "fg_nc_create", "fg_nc_def_dim", "fg_nc_def_var", "fg_nc_put_att_text", "fg_nc_put_att_double", "fg_nc_enddef",
+    "fg_nc_inq_ndims", "fg_nc_inq_nvars", "fg_nc_inq_numrecs", "fg_nc_inq_dimid", "fg_nc_inq_dim", "fg_nc_inq_varid", "fg_nc_inq_var",
+    "fg_nc_get_att_double", "fg_nc_get_att_text", "fg_nc_get_vara", "fg_nc_get_vara_double", "fg_nc_put_vara", "fg_nc_put_vara_double",
+    "fg_nc_close", "fg_nc_last_error", "fg_sweep_create", "fg_sweep_run", "fg_sweep_destroy", "fg_host_alloc", "fg_host_free",
     "fg_plan_stats", "fg_set_search_mode", "fg_set_search_chunks", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
 
@@ -196,6 +201,36 @@ def lib():
     L.fg_set_search_mode.restype = None
     L.fg_set_search_chunks.argtypes = [C.c_int]
     L.fg_set_search_chunks.restype = None
+    for fn in ("fg_plan_ncells_out",):
+        getattr(L, fn).argtypes = [vp]; getattr(L, fn).restype = C.c_long
+    for fn in ("fg_plan_order", "fg_plan_device"):
+        getattr(L, fn).argtypes = [vp]; getattr(L, fn).restype = C.c_int
+    lp, cp = C.POINTER(C.c_long), C.c_char_p
+    L.fg_nc_open.argtypes = [cp, C.POINTER(vp)]; L.fg_nc_open.restype = C.c_int
+    L.fg_nc_create.argtypes = [cp, C.c_int, C.POINTER(vp)]; L.fg_nc_create.restype = C.c_int
+    L.fg_nc_def_dim.argtypes = [vp, cp, C.c_long]; L.fg_nc_def_dim.restype = C.c_int
+    L.fg_nc_def_var.argtypes = [vp, cp, C.c_int, C.c_int, ip]; L.fg_nc_def_var.restype = C.c_int
+    L.fg_nc_put_att_text.argtypes = [vp, C.c_int, cp, cp]; L.fg_nc_put_att_text.restype = C.c_int
+    L.fg_nc_put_att_double.argtypes = [vp, C.c_int, cp, C.c_int, C.c_int, dp]; L.fg_nc_put_att_double.restype = C.c_int
+    L.fg_nc_enddef.argtypes = [vp]; L.fg_nc_enddef.restype = C.c_int
+    L.fg_nc_inq_ndims.argtypes = [vp]; L.fg_nc_inq_ndims.restype = C.c_int
+    L.fg_nc_inq_nvars.argtypes = [vp]; L.fg_nc_inq_nvars.restype = C.c_int
+    L.fg_nc_inq_numrecs.argtypes = [vp]; L.fg_nc_inq_numrecs.restype = C.c_long
+    L.fg_nc_inq_dimid.argtypes = [vp, cp]; L.fg_nc_inq_dimid.restype = C.c_int
+    L.fg_nc_inq_dim.argtypes = [vp, C.c_int, cp, C.c_int, lp]; L.fg_nc_inq_dim.restype = C.c_int
+    L.fg_nc_inq_varid.argtypes = [vp, cp]; L.fg_nc_inq_varid.restype = C.c_int
+    L.fg_nc_inq_var.argtypes = [vp, C.c_int, cp, C.c_int, ip, ip, ip, lp]; L.fg_nc_inq_var.restype = C.c_int
+    L.fg_nc_get_att_double.argtypes = [vp, C.c_int, cp, dp, C.c_int]; L.fg_nc_get_att_double.restype = C.c_int
+    L.fg_nc_get_att_text.argtypes = [vp, C.c_int, cp, cp, C.c_int]; L.fg_nc_get_att_text.restype = C.c_int
+    for fn in ("fg_nc_get_vara", "fg_nc_get_vara_double", "fg_nc_put_vara", "fg_nc_put_vara_double"):
+        getattr(L, fn).argtypes = [vp, C.c_int, lp, lp, vp]; getattr(L, fn).restype = C.c_int
+    L.fg_nc_close.argtypes = [vp]; L.fg_nc_close.restype = C.c_int
+    L.fg_nc_last_error.restype = cp
+    L.fg_sweep_create.argtypes = [C.c_int, C.POINTER(vp), vp, C.c_int, C.c_int, C.POINTER(vp)]; L.fg_sweep_create.restype = C.c_int
+    L.fg_sweep_run.argtypes = [vp, vp, C.c_long, C.c_double, C.c_double, C.c_double, C.POINTER(vp)]; L.fg_sweep_run.restype = C.c_int
+    L.fg_sweep_destroy.argtypes = [vp]; L.fg_sweep_destroy.restype = None
+    L.fg_host_alloc.argtypes = [C.c_size_t]; L.fg_host_alloc.restype = vp
+    L.fg_host_free.argtypes = [vp]; L.fg_host_free.restype = None
     L.fg_set_profiling.argtypes = [C.c_int]
     L.fg_set_profiling.restype = None
     L.fg_plan_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_int]

@@ -32,6 +32,7 @@ static int fail(int code, const char *fmt, ...)
   return fail(FG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 extern "C" const char *fg_last_error(void) { return g_err.c_str(); }
+void fg_set_last_error(const char *msg) { g_err = msg ? msg : ""; }      // for the other translation units (sweep.hip)
 
 extern "C" int fg_device_count(void)
 {
@@ -891,6 +892,9 @@ extern "C" int fg_plan_create_empty(int order, int ntiles_in, const int *nx_in, 
 
 extern "C" long fg_plan_nxgrid(const fg_plan *pl) { return pl ? pl->nx : FG_ERR_ARG; }
 extern "C" long fg_plan_ncells_in(const fg_plan *pl) { return pl ? pl->nsrc : FG_ERR_ARG; }
+extern "C" long fg_plan_ncells_out(const fg_plan *pl) { return pl ? pl->ndst : FG_ERR_ARG; }
+extern "C" int fg_plan_order(const fg_plan *pl) { return pl ? pl->order : FG_ERR_ARG; }
+extern "C" int fg_plan_device(const fg_plan *pl) { return pl ? pl->device : FG_ERR_ARG; }
 extern "C" double *fg_plan_cell_sums_dev(fg_plan *pl) { return (pl && pl->order == 2) ? pl->sums : nullptr; }
 extern "C" int fg_plan_copy_cell_sums(fg_plan *pl, double *dst_dev)
 {
@@ -1157,7 +1161,7 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
     pl->row_sum_cap = ndst;
   }
   if (nz > 1) { int rc = ensure_il_scratch(pl, gsum_out != nullptr); if (rc) return rc; }
-  pl->apply_pt.start(g_profiling != 0, st);
+  pl->apply_pt.start(g_profiling != 0 && pl->apply_spans < 256, st);     // (a long sweep loop must not pile up timing events)
   pl->apply_pt.begin(PH_APPLY);
   int nred = 0;
   for (int k0 = 0; k0 < nz; k0 += 8) {
@@ -1214,7 +1218,7 @@ extern "C" int fg_plan_apply_records(fg_plan *pl, int nz, const double *rec, dou
     pl->il_rs = pl->alloc<double>((size_t)ndst * 16);
     if (!pl->il_rs) return fail(FG_ERR_HIP, "out of device memory");
   }
-  pl->apply_pt.start(g_profiling != 0, st);
+  pl->apply_pt.start(g_profiling != 0 && pl->apply_spans < 256, st);     // (a long sweep loop must not pile up timing events)
   pl->apply_pt.begin(PH_APPLY);
   fgd_apply_il_merged(nbp, ndst, pl->csr, rec, -1.e20, out, gsum_out ? pl->il_rs : nullptr, (long)ndst, nz, st);
   if (gsum_out) fgd_reduce_sum(pl->il_rs, (long)ndst * nbp, pl->red_partial, pl->red_result, st);
@@ -1388,7 +1392,7 @@ extern "C" int fg_plan_apply_interleaved(fg_plan *pl, int nb, const double *data
   if (pl->order == 2 && (!grad_x_il || !grad_y_il)) return fail(FG_ERR_ARG, "order 2 needs grad_x and grad_y");
   HIPCHK(hipSetDevice(pl->device));
   if (gsum_out) { int rc = ensure_il_scratch(pl, true); if (rc) return rc; }
-  pl->apply_pt.start(g_profiling != 0, pl->stream);
+  pl->apply_pt.start(g_profiling != 0 && pl->apply_spans < 256, pl->stream);
   pl->apply_pt.begin(PH_APPLY);
   fgd_apply_il(pl->order, nb, pl->ndst, pl->csr, data_il, grad_x_il, grad_y_il, -1.e20, out_il,
                gsum_out ? pl->il_rs : nullptr, 0, nb, pl->stream);

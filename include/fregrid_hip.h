@@ -56,6 +56,8 @@ extern "C" {
 #define FG_ERR_CAPACITY   (-5)   /* caller's output arrays too small (reference: MAXXGRID fatal, :1087) */
 #define FG_ERR_STATE      (-6)   /* call made in the wrong plan state                          */
 #define FG_ERR_GEOM       (-8)   /* the great-circle clip hit one of the reference's fatal geometry checks (create_xgrid.c:1575-1834) */
+#define FG_ERR_IO         (-9)   /* file I/O (fg_nc_*, fg_remap_*)                            */
+#define FG_ERR_NOTFOUND   (-10)  /* attribute / variable not present                          */
 #define FG_ERR_DATA       (-7)   /* the field data hit one of the reference's fatal checks (conserve_interp.c:584,:697,:709) */
 
 /* option bits, same values as tools/libfrencutils/globals.h:46-61 where they exist */
@@ -144,6 +146,9 @@ void fg_pool_release(void);
 
 long fg_plan_nxgrid(const fg_plan *plan);
 long fg_plan_ncells_in(const fg_plan *plan);      /* sum over source tiles of nx*ny */
+long fg_plan_ncells_out(const fg_plan *plan);     /* nx_out*ny_out */
+int  fg_plan_order(const fg_plan *plan);
+int  fg_plan_device(const fg_plan *plan);
 
 /*
  * Order 2 only.  Device pointer to the per-source-cell partial sums
@@ -362,6 +367,65 @@ long fg_remap_read_size(const char *path);                                      
 int  fg_remap_read(const char *path, int order, long ncells, int *t_in, int *i_in, int *j_in, int *i_out, int *j_out,
                    double *area, double *di_in, double *dj_in);                                       /* 0-based, reference conversions applied */
 const char *fg_remap_last_error(void);
+
+/* ------------------------------------------------- field / grid files without libnetcdf -- */
+/* The operations fregrid performs on its files through tools/libfrencutils/mpp_io.c (mpp_open, mpp_get_varid,
+ * mpp_get_var_att, mpp_get_var_value_block :443, mpp_def_dim / mpp_def_var / mpp_def_*_att / mpp_end_def,
+ * mpp_put_var_value_block :1349, mpp_close), directly on classic netCDF files (CDF-1, CDF-2, CDF-5; csrc/field_file.c).
+ * Host functions.  Types follow netCDF's numbering. */
+#define FG_NC_BYTE 1
+#define FG_NC_CHAR 2
+#define FG_NC_SHORT 3
+#define FG_NC_INT 4
+#define FG_NC_FLOAT 5
+#define FG_NC_DOUBLE 6
+typedef struct fg_ncfile fg_ncfile;
+int  fg_nc_open(const char *path, fg_ncfile **out);                                  /* read only */
+int  fg_nc_create(const char *path, int version /* 1, 2 or 5 */, fg_ncfile **out);   /* define mode */
+int  fg_nc_def_dim(fg_ncfile *f, const char *name, long len /* 0: unlimited */);     /* returns the dimension id */
+int  fg_nc_def_var(fg_ncfile *f, const char *name, int type, int ndims, const int *dimids);   /* returns the variable id */
+int  fg_nc_put_att_text(fg_ncfile *f, int varid /* -1: global */, const char *name, const char *val);
+int  fg_nc_put_att_double(fg_ncfile *f, int varid, const char *name, int type, int n, const double *vals);
+int  fg_nc_enddef(fg_ncfile *f);
+int  fg_nc_inq_ndims(const fg_ncfile *f);
+int  fg_nc_inq_nvars(const fg_ncfile *f);
+long fg_nc_inq_numrecs(const fg_ncfile *f);
+int  fg_nc_inq_dimid(const fg_ncfile *f, const char *name);                          /* -1 if absent */
+int  fg_nc_inq_dim(const fg_ncfile *f, int dimid, char *name, int cap, long *len);
+int  fg_nc_inq_varid(const fg_ncfile *f, const char *name);                          /* -1 if absent */
+int  fg_nc_inq_var(const fg_ncfile *f, int varid, char *name, int cap, int *type, int *ndims, int *dimids, long *shape);
+int  fg_nc_get_att_double(const fg_ncfile *f, int varid, const char *name, double *val, int cap);   /* elements copied, or FG_ERR_NOTFOUND */
+int  fg_nc_get_att_text(const fg_ncfile *f, int varid, const char *name, char *buf, int cap);       /* length, or FG_ERR_NOTFOUND */
+int  fg_nc_get_vara(fg_ncfile *f, int varid, const long *start, const long *count, void *out);      /* the variable's own type */
+int  fg_nc_get_vara_double(fg_ncfile *f, int varid, const long *start, const long *count, double *out);
+int  fg_nc_put_vara(fg_ncfile *f, int varid, const long *start, const long *count, const void *data);
+int  fg_nc_put_vara_double(fg_ncfile *f, int varid, const long *start, const long *count, const double *data);
+int  fg_nc_close(fg_ncfile *f);
+const char *fg_nc_last_error(void);
+
+/* ------------------------------------------------- streamed sweep: fields from host memory through the plans ---- */
+/* fregrid's per-field loop (fregrid.c:1001-1075): get_input_data (read a hyperslab, widen NC_FLOAT / NC_SHORT / NC_INT to
+ * double, scale and offset, fregrid_util.c:2036-2165), [halo update + grad_c2l,] do_scalar_conserve_interp per output tile,
+ * write_field_data (offset, scale, cast to the file type, :2339-2418).  fg_sweep keeps that loop's data path on the device
+ * and the PCIe link busy: levels cross the link in their FILE type (a float level is half the bytes), in chunks of up to 8
+ * levels, through pinned double buffers on a copy-in stream / compute stream / copy-out stream, so that the upload of
+ * chunk k+1 and the download of chunk k-1 run beside the sweep of chunk k.  Widening, scaling and the inverse conversions
+ * run on the device with the reference's operations (exact: float -> double is exact, (float)double is the C cast
+ * nc_put_vara_double applies).
+ *   plans[nplans]: finalized plans sharing the source grid, one per output tile.  c2l: gradient preparation for
+ *   conserve_order2 plans (NULL for order 1).  in_type / out_type: FG_NC_SHORT, FG_NC_INT, FG_NC_FLOAT or FG_NC_DOUBLE.
+ * fg_sweep_run: host_in [nlev][ncells_in] of in_type (tiles back to back, no halo), host_out[p] [nlev][ndst_p] of out_type.
+ *   scale / offset: the variable's scale_factor / add_offset (0 = absent, as the reference treats them); applied to values
+ *   != missing.  Levels carry no missing values (conserve_interp.c:544 requires nz == 1 for those: use fg_plan_apply_ex).
+ * Buffers from fg_host_alloc are page-locked: copies go straight from / to them; other host memory is staged through the
+ * object's own pinned buffers with one extra host copy. */
+typedef struct fg_sweep fg_sweep;
+int  fg_sweep_create(int nplans, fg_plan *const *plans, fg_c2l *c2l, int in_type, int out_type, fg_sweep **out);
+int  fg_sweep_run(fg_sweep *sw, const void *host_in, long nlev, double scale, double offset, double missing,
+                  void *const *host_out);
+void fg_sweep_destroy(fg_sweep *sw);
+void *fg_host_alloc(size_t bytes);      /* page-locked host memory (hipHostMalloc), NULL on failure */
+void fg_host_free(void *p);
 
 /* ---------------------------------------------------------------- (G) ----- */
 /* Equal-distance gnomonic cubed sphere ("gnomonic_ed"), C<ni>: cell corners of the six
