@@ -38,9 +38,10 @@ def synth_fields(lont, latt, nz):
 
 
 def cpu_baseline(fg, lon, lat, lo, la, ni, nlon, nlat, rows):
-    """The reference algorithm (brute-force pair scan) on the host, single thread, on a bounded sample:
-    `rows` source rows of tile 1 against the full target.  Uses the reference's own code compiled in
-    place (oracle/_ref) when that library is present, else our bit-identical C port (oracle/)."""
+    """The reference algorithm (brute-force pair scan) on the host on a bounded sample: `rows` source rows of tile 1
+    against the full target on ONE thread (the reference's default build); the reference's own OpenMP build on all host
+    cores gets a sample sized for >= 5 s.  Uses the reference's own code compiled in place (oracle/_ref) when that library
+    is present, else our bit-identical C port (oracle/)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     j0 = ni // 2 - rows // 2
@@ -72,18 +73,151 @@ def cpu_baseline(fg, lon, lat, lo, la, ni, nlon, nlat, rows):
         ints = [np.empty(cap, dtype=np.int32) for _ in range(4)]
         dbl = [np.empty(cap) for _ in range(3)]
         f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64).ravel()
-        arrs = [f64(sub_lon), f64(sub_lat), f64(lo), f64(la), np.ones(ni * rows)]
+        # sample sized from the one-thread rate for ~6 s on all cores (at most the whole tile)
+        orows = int(min(ni, max(rows, rows * 6.0 / max(dt, 1e-3) * ncores * 0.04)))
+        oj0 = (ni - orows) // 2
+        o_lon = np.ascontiguousarray(lon[0][oj0:oj0 + orows + 1]); o_lat = np.ascontiguousarray(lat[0][oj0:oj0 + orows + 1])
+        arrs = [f64(o_lon), f64(o_lat), f64(lo), f64(la), np.ones(ni * orows)]
         t1 = time.time()
-        n_omp = L.create_xgrid_2dx2d_order2(C.byref(C.c_int(ni)), C.byref(C.c_int(rows)), C.byref(C.c_int(nlon)), C.byref(C.c_int(nlat)),
+        n_omp = L.create_xgrid_2dx2d_order2(C.byref(C.c_int(ni)), C.byref(C.c_int(orows)), C.byref(C.c_int(nlon)), C.byref(C.c_int(nlat)),
                                             *[a.ctypes.data_as(dp) for a in arrs], *[a.ctypes.data_as(ip) for a in ints],
                                             *[a.ctypes.data_as(dp) for a in dbl])
         dto = time.time() - t1
         omp = {"value": n_omp / dto, "unit": "exchange-cells/s", "cores": ncores, "kind": "reference (OpenMP build)",
-               "seconds": dto, "nxgrid": int(n_omp)}
+               "seconds": dto, "nxgrid": int(n_omp), "sample": f"rows {oj0}..{oj0 + orows - 1} of tile 1 ({orows}x{ni} source cells)"}
     return {"value": r["n"] / dt, "unit": "exchange-cells/s", "cores": 1, "kind": kind, "all_cores": omp,
             "sample": f"create_xgrid_2dx2d_order2, C{ni} tile 1 rows {j0}..{j0 + rows - 1} ({rows}x{ni} source cells) "
                       f"x full {nlon}x{nlat} target: {r['n']} exchange cells in {dt:.2f} s",
             "seconds": dt}, r, j0
+
+
+def pcie_leg(fg, ni, nlon, nlat, lon, lat, lo, la, device):
+    """The same job through the HOST-pointer API (what a B1 / B2 caller with host arrays pays): corner arrays up, search,
+    finalize, and the exchange cells (8 arrays, indices decomposed on the device) back into host memory."""
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    gout = fg.GridConfig(nlon, nlat, lo, la)
+    best = None
+    for it in range(3):
+        t0 = time.perf_counter()
+        p = fg.XgridPlan.create(2, grids, gout, device=device)
+        p.finalize(); p.sync()
+        t1 = time.perf_counter()
+        xg = p.get_xgrid()
+        t2 = time.perf_counter()
+        n = p.nxgrid
+        p.destroy()
+        if best is None or t2 - t0 < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1, n, len(xg["area"]))
+    return {"workload": f"C{ni} -> {nlon}x{nlat} order 2, host corner arrays in, exchange cells out to host memory",
+            "ms_upload_search_finalize": best[1] * 1e3, "ms_exchange_cells_to_host": best[2] * 1e3, "ms_total": best[0] * 1e3,
+            "exchange_cells_per_s": best[3] / best[0], "nxgrid": best[3],
+            "note": "best of 3; pageable host arrays (the reference's malloc'ed Interp_config arrays)"}
+
+
+def config4_leg(fg, torch, dev, device):
+    """BASELINE config 4: C768 -> 2880x1440.  (4a) create_xgrid_great_circle semantics, first order (the reference refuses
+    order 2 with great circle, fregrid.c:763-765); (4b) legacy clip, second order.  Search + finalize, inputs resident."""
+    ni, nlon, nlat = 768, 2880, 1440
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    h2d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = {"workload": f"C{ni} (6 tiles) -> {nlon}x{nlat} lat-lon"}
+    lon_t = [h2d(lon[t]) for t in range(6)]; lat_t = [h2d(lat[t]) for t in range(6)]
+    lo_t, la_t = h2d(lo), h2d(la)
+    ts = []
+    for it in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        p = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, nlat, lo_t, la_t, np.pi / nlat, 2 * np.pi / nlon, device=device)
+        p.finalize(); p.sync()
+        ts.append(time.perf_counter() - t0); n = p.nxgrid
+        p.destroy()
+    out["4b_legacy_order2"] = {"nxgrid": n, "ms_per_step": min(ts[1:]) * 1e3, "exchange_cells_per_s": n / min(ts[1:])}
+    th = time.perf_counter()
+    xin = [tuple(h2d(a) for a in fg.latlon2xyz(lon[t], lat[t])) for t in range(6)]
+    xout = tuple(h2d(a) for a in fg.latlon2xyz(lo, la))
+    t_xyz = time.perf_counter() - th
+    ts = []
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        p = fg.XgridPlan.create_great_circle_dev([ni] * 6, [ni] * 6, xin, nlon, nlat, xout, np.pi / nlat, 2 * np.pi / nlon, device=device)
+        p.finalize(); p.sync()
+        ts.append(time.perf_counter() - t0); n = p.nxgrid
+        p.destroy()
+    out["4a_great_circle_order1"] = {"nxgrid": n, "ms_per_step": min(ts[1:]) * 1e3, "exchange_cells_per_s": n / min(ts[1:]),
+                                     "host_latlon2xyz_and_upload_ms": t_xyz * 1e3}
+    del lon_t, lat_t, lo_t, la_t, xin, xout
+    fg.lib().fg_pool_release()
+    return out
+
+
+def config5_leg(fg, torch, dev, device, nz=50, nt=20, nfields=3):
+    """BASELINE config 5: tripolar ocean 1440x1080 -> C384 mosaic (6 output tiles), conservative_order1 (order 2 is illegal
+    for a one-tile input mosaic, fregrid.c:695-696), weights READ from cached remap files, then `nfields` 3-D fields x `nt`
+    time steps x `nz` levels streamed from page-locked host memory as NC_FLOAT through the six plans and back as NC_FLOAT
+    (fg_sweep): remapped-points/s INCLUDING both PCIe directions."""
+    import tempfile
+    nxs, nys, no = 1440, 1080, 384
+    lon_s, lat_s = fg.tripolar_corners(nxs, nys)
+    lon_d, lat_d = fg.gnomonic_ed_corners(no)
+    gin = [fg.GridConfig(nxs, nys, lon_s, lat_s)]
+    tmp = tempfile.mkdtemp(prefix="fg_remap_")
+    t0 = time.perf_counter()
+    nx_tot = 0
+    for t in range(6):                                           # WRITE pass: search once, cache the weights
+        p = fg.XgridPlan.create(1, gin, fg.GridConfig(no, no, lon_d[t], lat_d[t]), device=device)
+        x = p.get_xgrid()
+        fg.write_remap_file(os.path.join(tmp, f"remap.tile{t + 1}.nc"), 1, x["t_in"], x["i_in"], x["j_in"], x["i_out"], x["j_out"], x["area"])
+        nx_tot += p.nxgrid
+        p.destroy()
+    t_write = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    plans = []
+    for t in range(6):                                           # READ pass (conserve_interp.c:62-126)
+        r = fg.read_remap_file(os.path.join(tmp, f"remap.tile{t + 1}.nc"), 1)
+        p = fg.XgridPlan.create_empty(1, [nxs], [nys], no, no, device=device)
+        p.set_xgrid(r["t_in"], r["i_in"], r["j_in"], r["i_out"], r["j_out"], r["area"])
+        plans.append(p)
+    t_read = time.perf_counter() - t0
+    ncell = nxs * nys
+    hin = fg.HostBuffer((nz, ncell), np.float32)
+    houts = [fg.HostBuffer((nz, no * no), np.float32) for _ in range(6)]
+    base = (280.0 + 15.0 * np.cos(np.linspace(0, 8 * np.pi, ncell))).astype(np.float32)
+    for k in range(nz):
+        hin.array[k] = base * np.float32(1.0 - 0.004 * k)
+    sw = fg.Sweep(plans, None, np.float32, np.float32)
+    outs = [h.array for h in houts]
+    sw.run(hin.array, outs)                                       # warm-up (allocations, first touch)
+    t0 = time.perf_counter()
+    for _ in range(nt * nfields):
+        sw.run(hin.array, outs)
+    dtw = time.perf_counter() - t0
+    pts = 6 * no * no * nz * nt * nfields
+    bytes_in, bytes_out = ncell * nz * 4 * nt * nfields, 6 * no * no * nz * 4 * nt * nfields
+    chk = float(np.mean(outs[2][0]))
+    # the same sweep with everything resident (no transfers), for the ratio
+    src_t = torch.from_numpy(np.ascontiguousarray(hin.array[:8].astype(np.float64))).to(dev)
+    out_t = torch.empty(8, no * no, dtype=torch.float64, device=dev)
+    for p in plans:
+        p.apply(src_t, out_t, nz=8)
+    torch.cuda.synchronize(); [p.sync() for p in plans]
+    t0 = time.perf_counter()
+    for _ in range(20):
+        for p in plans:
+            p.apply(src_t, out_t, nz=8)
+    [p.sync() for p in plans]
+    dtr = (time.perf_counter() - t0) / 20
+    sw.destroy(); hin.free(); [h.free() for h in houts]
+    for p in plans:
+        p.destroy()
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    os.rmdir(tmp)
+    return {"workload": f"tripolar {nxs}x{nys} -> C{no} (6 tiles), conservative_order1, cached remap files, {nfields} fields x {nt} steps x {nz} levels, NC_FLOAT in / out",
+            "nxgrid": nx_tot, "remapped_points_per_s_incl_transfers": pts / dtw, "seconds": dtw,
+            "pcie_GBps_in": bytes_in / dtw / 1e9, "pcie_GBps_out": bytes_out / dtw / 1e9,
+            "remapped_points_per_s_resident": 6 * no * no * 8 / dtr,
+            "weights_search_and_write_s": t_write, "weights_read_and_csr_s": t_read, "check_mean_tile3_level0": chk,
+            "note": "page-locked host buffers (fg_host_alloc); levels cross the link as float and are widened / narrowed on the device"}
 
 
 def main():
@@ -96,7 +230,9 @@ def main():
     ap.add_argument("--nlat", type=int, default=720)
     ap.add_argument("--nz", type=int, default=8, help="levels per sweep launch")
     ap.add_argument("--apply-steps", type=int, default=50)
-    ap.add_argument("--no-phase-timing", action="store_true", help="do not record per-phase HIP events in the timed region")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each (median reported)")
+    ap.add_argument("--no-phase-timing", action="store_true", help="skip the separate pass that records per-phase HIP events")
+    ap.add_argument("--legs", default="all", help="comma list of extra legs: gc,pcie,config4,config5,cpu (or all / none)")
     ap.add_argument("--cpu-rows", type=int, default=32, help="source rows in the CPU baseline sample (0 = skip)")
     ap.add_argument("--gc-steps", type=int, default=3, help="timed great-circle searches of the same grids (N=1 only; 0 = skip)")
     args = ap.parse_args()
@@ -163,7 +299,7 @@ def main():
     total_sums = torch.empty(3 * ncell_in, dtype=torch.float64, device=dev)
     mean_dlat, mean_dlon = np.pi / nlat, 2 * np.pi / nlon
     stream = torch.cuda.current_stream().cuda_stream
-    fg.lib().fg_set_profiling(0 if args.no_phase_timing else 1)
+    legs = {"gc", "pcie", "config4", "config5", "cpu"} if args.legs == "all" else set(x for x in args.legs.split(",") if x and x != "none")
 
     def barrier():
         if world > 1:
@@ -196,20 +332,36 @@ def main():
         plan[0] = p
         return p
 
+    # ---- headline: K steps per timed region, profiling events OFF; the region is repeated to show the spread
+    fg.lib().fg_set_profiling(0)
     for _ in range(args.warmup):
         step()
-    barrier(); torch.cuda.synchronize()
-    phase_acc = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        p = step()
-        for k, v in p.phase_ms().items():
-            phase_acc[k] = phase_acc.get(k, 0.0) + v
-    torch.cuda.synchronize(); barrier()
-    dt = time.perf_counter() - t0
+    reps = []
+    for rep in range(max(1, args.repeats)):
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            p = step()
+        torch.cuda.synchronize(); barrier()
+        reps.append(time.perf_counter() - t0)
     p = plan[0]
     nx_local = p.nxgrid
     stats = p.stats()
+    # ---- per-phase device times: a separate pass with HIP events on the plan's streams (they cost ~0.1 ms per step)
+    phase_acc = {}
+    if not args.no_phase_timing:
+        fg.lib().fg_set_profiling(1)
+        for it in range(6):
+            p = step()
+            if it:
+                for k, v in p.phase_ms().items():
+                    phase_acc[k] = phase_acc.get(k, 0.0) + v / 5.0
+    fg.lib().fg_set_profiling(1)
+    reps_t = torch.tensor(reps, dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(reps_t, op=dist.ReduceOp.MAX)
+    reps = [float(v) for v in reps_t.cpu()]
+    dt = float(np.median(reps))
 
     # ---- sweep leg
     apply_steps = args.apply_steps
@@ -288,12 +440,12 @@ def main():
     gsum_xgrid = float(np.sum(f0 * xg["area"]))
 
     # ---- reductions over ranks
-    red = torch.tensor([dt, dta, dtb, dtl, dtf, dtr], dtype=torch.float64, device=dev)
+    red = torch.tensor([0.0, dta, dtb, dtl, dtf, dtr], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(nx_local), float(gsum_out), gsum_xgrid], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt, dta, dtb, dtl, dtf, dtr = (float(red[k]) for k in range(6))
+    _, dta, dtb, dtl, dtf, dtr = (float(red[k]) for k in range(6))
     nx_total, gsum_out, gsum_xgrid = int(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if rank == 0:
@@ -301,20 +453,23 @@ def main():
         ndst = nlon * nlat
         remap_pts = apply_steps * ndst * nz / dta
         nsteps = max(args.steps, 1)
-        phases = {k: v / nsteps for k, v in phase_acc.items()}
+        phases = dict(phase_acc)
         # algorithmic bytes (destination corners counted once because all six source
         # tiles are searched in one pass): 16 B per corner read, 8 B per source cell (mask), 40 B per xcell written
         nx_rank0 = nx_local
         alg_search = 16.0 * (6 * (ni + 1) ** 2 + (nlon + 1) * (ny_band + 1)) + 8.0 * ncell_in + 40.0 * nx_rank0
         clip_ms = phases.get("clip_quad", 0.0)
-        roof = {"kernel": "k_clip_quad<2>", "bound": "hbm",
-                "achieved": (alg_search / 1e9) / (clip_ms / 1e3) if clip_ms > 0 else None,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                "algorithmic_bytes_per_launch": alg_search, "kernel_ms": clip_ms,
-                "note": "FP64-VALU bound polygon clipping, not HBM bound (SURVEY.md §8d): 2.03e8 wave VALU instructions x 4 issue "
-                        "cycles = 77 % of the SIMD cycles of the launch (profiles/r01_summary.md); "
-                        "the HBM-bound kernel of the path is the sweep, see roofline_apply"}
-        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
+        # The dominant kernel of the search is FP64-VALU bound (SURVEY.md §8d predicted it): its roofline is the vector issue
+        # rate -- a wave64 FP64 instruction occupies its SIMD for 4 cycles, 1024 SIMDs at 2.4 GHz -- and the HBM view is secondary.
+        valu_peak = 1024 * 2.4e9
+        roof = {"kernel": "k_clip_quad<2>", "bound": "valu", "achieved": None, "peak": valu_peak, "unit": "SIMD issue cycles/s",
+                "frac": None, "traffic": None,
+                "kernel_ms": clip_ms, "algorithmic_bytes_per_launch": alg_search,
+                "hbm": {"achieved": (alg_search / 1e9) / (clip_ms / 1e3) if clip_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+                "note": "achieved = 4 issue cycles x wave VALU instructions of one launch (SQ_INSTS_VALU, PMC pass) / live kernel time; "
+                        "hbm.achieved = algorithmic bytes of the whole search / this kernel's time (the figure SURVEY.md 8d asks for); "
+                        "the HBM-bound kernel of the path is the sweep: roofline_apply"}
+        roof["hbm"]["frac"] = roof["hbm"]["achieved"] / HBM_PEAK_GBS if roof["hbm"]["achieved"] else None
         # sweep: weights streamed once per launch of nz levels + per level the source fields and the output
         alg_apply = 32.0 * nx_rank0 + nb * (24.0 * ncell_in + 8.0 * nlon * ny_band)
         sweep_ms = rec_kernel_ms if rec_kernel_ms > 0 else apply_kernel_ms
@@ -328,12 +483,13 @@ def main():
         if os.path.exists(pmc) and world == 1:      # the PMC passes were taken on the single-GPU launch sizes
             try:
                 tr = json.load(open(pmc))
-                roof["traffic"] = tr.get("k_clip_quad")
-                roof_a["traffic"] = tr.get("k_apply")
-                # the clip kernel's own bound: wave VALU instructions (PMC) x 4 issue cycles on SIMD16, over the SIMD
-                # cycles of the live launch duration (1024 SIMDs at 2.4 GHz)
+                src = f"profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of {tr.get('round', 'an earlier round')}, not collected in this run)"
+                roof["traffic"] = tr.get("k_clip_quad"); roof["traffic_source"] = src
+                roof_a["traffic"] = tr.get("k_apply"); roof_a["traffic_source"] = src
                 if tr.get("k_clip_quad_valu_insts") and clip_ms > 0:
-                    roof["valu_issue_frac"] = 4.0 * tr["k_clip_quad_valu_insts"] / (clip_ms * 1e-3 * 2.4e9 * 1024)
+                    roof["achieved"] = 4.0 * tr["k_clip_quad_valu_insts"] / (clip_ms * 1e-3)
+                    roof["frac"] = roof["achieved"] / valu_peak
+                    roof["valu_insts_source"] = src
             except Exception:
                 pass
         # mass conservation (conserve_interp.c:874-907): input flux uses get_grid_area cell areas
@@ -342,11 +498,14 @@ def main():
         line = {
             "metric": "exchange-cells/s", "value": value, "unit": "exchange-cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / nsteps * 1e3,
+            "repeats": len(reps), "ms_per_step_min": min(reps) / nsteps * 1e3, "ms_per_step_all": [r / nsteps * 1e3 for r in reps],
+            "timing_note": "median over `repeats` timed regions of `steps` steps each (max over ranks per region); HIP-event phase "
+                           "timing is OFF in them, phase_ms comes from a separate pass",
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"C{ni} cubed sphere (6 tiles) -> {nlon}x{nlat} lat-lon, conservative_order2: "
                                    "exchange-grid search + centroid pass + CSR build per step",
-                       "nxgrid": nx_total, "parallelism": f"{world} latitude band(s) of the target, one per GPU",
+                       "nxgrid": nx_total, "parallelism": f"{world} latitude band(s) of the target, one per GPU", "world_size": world,
                        "exchange": (None if world == 1 else f"all-reduce of the (area, clon, clat) sums of the {int(bidx_t.numel())} source "
                                     f"cells cut by band boundaries ({100.0 * int(bidx_t.numel()) / ncell_in:.1f} % of {ncell_in})")},
             "remapped_points_per_s": remap_pts, "apply_ms_per_call": dta / apply_steps * 1e3, "apply_levels": nz,
@@ -368,7 +527,7 @@ def main():
             "phase_ms": phases, "search_stats": stats,
             "roofline": roof, "roofline_apply": roof_a,
         }
-        if world == 1 and args.gc_steps > 0:
+        if world == 1 and args.gc_steps > 0 and "gc" in legs:
             # BASELINE config 4's clip method on the same grids (create_xgrid_great_circle semantics, first order): unit
             # vectors made on the host with libm as the reference does (not timed), search timed with inputs resident
             th = time.perf_counter()
@@ -397,7 +556,13 @@ def main():
                                     "clip_kernel_ms": gc_ph.get("clip_general"), "search_device_ms": gc_ph.get("search_total"),
                                     "host_latlon2xyz_ms": t_xyz * 1e3, "search_stats": gp.stats()}
             gp.destroy()
-        if world == 1 and args.cpu_rows > 0:
+        if world == 1 and "pcie" in legs:
+            line["pcie_inclusive"] = pcie_leg(fg, ni, nlon, nlat, lon, lat, lo, la, local_rank)
+        if world == 1 and "config4" in legs:
+            line["config4"] = config4_leg(fg, torch, dev, local_rank)
+        if world == 1 and "config5" in legs:
+            line["config5"] = config5_leg(fg, torch, dev, local_rank)
+        if world == 1 and args.cpu_rows > 0 and "cpu" in legs:
             cb, _, _ = cpu_baseline(fg, lon, lat, lo, la, ni, nlon, nlat, args.cpu_rows)
             line["cpu_baseline"] = cb
         print(json.dumps(line))

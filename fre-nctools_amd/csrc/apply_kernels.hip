@@ -167,18 +167,29 @@ __global__ __launch_bounds__(256) void k_src_field_index(int order, const FgTile
   src_idx_f[s] = foff + (j + 1) * (tiles[t].nx + 2) + i + 1;
 }
 
-// Block -> destination-row mapping is the identity.  An XCD-banded remap (each XCD sweeping one
-// contiguous band of rows, cdna_hip_programming.md T1) was measured 14-19 % SLOWER here (C384 -> 0.25 deg,
-// 8/16 levels): HBM traffic already equals the algorithmic bytes (profiles/), so there is no L2 reuse to
-// win, and eight far-apart streams cost DRAM locality.
-__device__ __forceinline__ int d_xcd_block(int b, int nb) { (void)nb; return b; }
+// Block -> destination-row mapping.  The hardware deals blocks round-robin over the 8 XCDs (block b runs on XCD b % 8), each
+// with its own 4 MiB L2.  With the identity mapping the blocks resident on one XCD hold every 8th run of 64 rows, so two
+// destination rows that are neighbours in latitude -- they gather the same source records -- never share an L2.  g_xcd_band:
+// XCD x sweeps ONE contiguous band of rows (tile = start_x + b / 8), so that its ~160 resident blocks cover ~7 adjacent grid
+// rows and the second use of a source record is an L2 hit.  (PMC, round 2: the identity mapping reads 538 MB per launch through
+// the fabric where the algorithm needs 303 MB; TCC hit rate 41 %.)  Measured (scripts/apply_ab.py, same box, 8 levels on records):
+// identity 0.096 ms, banded 0.110 ms -- slower although it re-reads less: the second and third XCD that need a record find it in
+// the Infinity Cache (the fabric counters count those hits, HBM does not see them), and eight bands stream eight separate windows
+// of the CSR.  The identity mapping stays the default; fg_set_apply_xcd(1) selects the banded one.  Non-temporal stores of the
+// output changed nothing.
+__device__ __forceinline__ int d_xcd_block(int b, int nb, int band)
+{
+  if (!band) return b;
+  const int x = b & 7, k = b >> 3, q = nb >> 3, r = nb & 7;
+  return x * q + min(x, r) + k;                       // XCD x owns q + (x < r) consecutive tiles
+}
 
 // Single level, level-major fields (also the has_missing path): one thread per destination cell.
 template <int ORDER, bool MISSING>
 __global__ __launch_bounds__(256) void k_apply1(int ndst, FgCsr csr, const double *f, const double *px, const double *py,
                                                  const int *gmask, double missing, double *out, double *row_sum)
 {
-  int d = d_xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  int d = blockIdx.x * 256 + threadIdx.x;
   if (d >= ndst) return;
   int b = csr.row_ptr[d], e = csr.row_ptr[d + 1];
   double acc = 0.0, asum = 0.0;
@@ -366,7 +377,7 @@ template <> struct __attribute__((aligned(16))) VecD<4> { double v[4]; };
 // to 23 % (NB = 4) faster on MI355X; px, py unused.
 template <int ORDER, int NB, int V, bool MERGED = false>
 __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const double *f, const double *px, const double *py,
-                                                   double missing, double *out, double *row_sum, long out_ld, int nb_valid)
+                                                   double missing, double *out, double *row_sum, long out_ld, int nb_valid, int xcd_band)
 {
   constexpr int LPR = NB / V;                        // lanes per row
   constexpr int ROWS = 256 / LPR;                    // rows per block
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const dou
   typedef typename std::conditional<ORDER == 2, FgCsrEntry2, FgCsrEntry1>::type Entry;
   __shared__ Entry sh_e[APPLY_STAGE];
   const int lev = (threadIdx.x % LPR) * V;
-  const int d0 = d_xcd_block(blockIdx.x, gridDim.x) * ROWS;
+  const int d0 = d_xcd_block(blockIdx.x, gridDim.x, xcd_band) * ROWS;
   const int d = d0 + threadIdx.x / LPR;
   // the block's rows own one contiguous run of CSR records: stage it with coalesced 16-byte loads
   const int dl = min(d0 + ROWS, ndst);
@@ -385,7 +396,10 @@ __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const dou
     constexpr int W = sizeof(Entry) / 16;            // 16-byte words per record
     const uint4 *g = reinterpret_cast<const uint4 *>(src + q0);
     uint4 *l = reinterpret_cast<uint4 *>(sh_e);
-    for (int i = threadIdx.x; i < nstage * W; i += 256) l[i] = g[i];
+    // the CSR records are used once per launch: non-temporal loads keep them from evicting the gathered source records
+    // (measured on MI355X, 8 levels: 0.1071 -> 0.0963 ms on records, 0.1162 -> 0.1049 ms on interleaved arrays)
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    for (int i = threadIdx.x; i < nstage * W; i += 256) ((u4v *)l)[i] = __builtin_nontemporal_load((const u4v *)g + i);
   }
   __syncthreads();
   if (d >= ndst) return;
@@ -613,16 +627,18 @@ void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *g
   }
 }
 
+extern int g_apply_xcd;
 template <int NB, int V>
 static void apply_il_nb(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
                         double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st)
 {
   int grid = nblk(ndst, 256 / (NB / V));
-  if (order == 2) k_apply_il<2, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid);
-  else            k_apply_il<1, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid);
+  if (order == 2) k_apply_il<2, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, g_apply_xcd);
+  else            k_apply_il<1, NB, V><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, g_apply_xcd);
 }
 // nb in {2, 4, 8, 16}: interleaved fields [cell][nb]; out_ld > 0: write out level-major, out[level][cell] with row stride
 // out_ld for the first nb_valid levels (else interleaved [cell][nb])
+int g_apply_xcd = 0;   // 1: each XCD sweeps one contiguous band of destination rows (d_xcd_block)
 int g_apply_vec = 0;   // levels per lane: 0 = auto (4 for nb = 16, else 2; measured best on MI355X), or force 1 / 2 / 4
 void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
                   double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st)
@@ -643,7 +659,7 @@ void fgd_apply_il_merged(int nb, int ndst, FgCsr csr, const double *rec, double 
                          int nb_valid, hipStream_t st)
 {
   if (ndst <= 0) return;
-#define APM(NB_, V_) k_apply_il<2, NB_, V_, true><<<nblk(ndst, 256 / (NB_ / V_)), 256, 0, st>>>(ndst, csr, rec, nullptr, nullptr, missing, out, row_sum, out_ld, nb_valid)
+#define APM(NB_, V_) k_apply_il<2, NB_, V_, true><<<nblk(ndst, 256 / (NB_ / V_)), 256, 0, st>>>(ndst, csr, rec, nullptr, nullptr, missing, out, row_sum, out_ld, nb_valid, g_apply_xcd)
   if (nb == 16) APM(16, 4);
   else if (nb == 8) APM(8, 2);
   else if (nb == 4) APM(4, 2);

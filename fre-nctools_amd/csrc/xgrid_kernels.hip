@@ -425,7 +425,9 @@ __device__ __forceinline__ bool d_box_pass(const FgBinEntry &E, double lat_in_mi
                               // longest scans set the duration of the four-lanes-per-cell path)
 #define CAND_G 4          // lanes per source cell in the candidate scan (one bin row each)
 #define CP_SMALL 32       // pairs per cell up to which the lanes of k_compact rank by comparison; cells with more are "big"
-#define CAND_CHUNK 16    // consecutive waves (of 16 cells) that append to the same region
+#define CAND_CHUNK 1     // consecutive waves (of 16 cells) that append to the same region: 1 = round robin, the best balance
+                          // (16 was tried for the locality of the clip: no faster, and the great-circle search, whose pairs
+                          // pile up around the poles, then overflowed a region and had to be repeated)
 #define HEAVY_BLOCKS 2048 // waves serving the listed cells, appended to the grid of the four-lanes-per-cell blocks
 
 __device__ __forceinline__ bool d_src_active(const FgCells &S, const double *mask, int s)

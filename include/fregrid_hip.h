@@ -294,6 +294,9 @@ void fg_set_search_mode(int exact);
  * the compaction of the previous one.  0 (default) = 1: one stream, in sequence -- at C384 -> 0.25 deg the overlapped kernels
  * slow each other down by more than the overlap wins.  Results do not depend on it.  Also FREGRID_HIP_CHUNKS. */
 void fg_set_search_chunks(int chunks);
+/* Sweep tuning hook: 1 = each XCD sweeps one contiguous band of destination rows (measured slower on MI355X, see
+ * csrc/apply_kernels.hip); 0 (default) = blocks in row order.  Results do not depend on it. */
+void fg_set_apply_xcd(int on);
 
 /* Batched polygon primitives on the device.  Polygons are rows of host arrays [npoly][24];
  * inputs have at most 12 vertices (8 for fix_lon).  fg_clip_2dx2d_batch: n_out[p] = vertex count,

@@ -14,6 +14,28 @@ dev = "cuda:0"
 rng = np.random.default_rng(0)
 h2d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 out = h2d(np.zeros(nz * nlon * nlat))
+if mode == "sweep":
+    # the sweep kernels alone, for the PMC passes that settle their HBM traffic: order-2 level-major call (k_merge3 +
+    # k_apply_il<2,8,2,MERGED>), the same on caller-interleaved arrays (k_apply_il<2,8,2>), and an order-1 level-major call
+    # whose k_interleave3<8> is a pure streaming kernel of known byte count (calibration of the counters)
+    lon_t = [h2d(lon[t]) for t in range(6)]; lat_t = [h2d(lat[t]) for t in range(6)]
+    lo_t, la_t = h2d(lo), h2d(la)
+    p2 = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, nlat, lo_t, la_t, np.pi / nlat, 2 * np.pi / nlon); p2.finalize()
+    p1 = fg.XgridPlan.create_dev(1, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, nlat, lo_t, la_t, np.pi / nlat, 2 * np.pi / nlon); p1.finalize()
+    data = h2d(rng.standard_normal((nz, 6 * (ni + 2) ** 2)))
+    gx = h2d(rng.standard_normal((nz, 6 * ni * ni))); gy = h2d(rng.standard_normal((nz, 6 * ni * ni)))
+    d1 = h2d(rng.standard_normal((nz, 6 * ni * ni)))
+    il = lambda t: t.t().contiguous()
+    data_il, gx_il, gy_il = il(data), il(gx), il(gy)
+    out_il = torch.empty(nlon * nlat, nz, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    for it in range(steps):
+        p2.apply(data, out, nz=nz, grad_x_t=gx, grad_y_t=gy)
+        p2.apply_interleaved(nz, data_il, out_il, gx_il, gy_il)
+        p1.apply(d1, out, nz=nz)
+    p2.sync(); p1.sync()
+    print("nxgrid", p2.nxgrid, p1.nxgrid)
+    sys.exit(0)
 if mode == "gc":
     xin = [tuple(h2d(a) for a in fg.latlon2xyz(lon[t], lat[t])) for t in range(6)]
     xout = tuple(h2d(a) for a in fg.latlon2xyz(lo, la))
