@@ -97,6 +97,29 @@ Pool g_pool;
 
 extern "C" void fg_pool_release(void) { g_pool.release_all(); }
 
+// Device memory for C callers that do not include the HIP headers (the fregrid replacement objects, integration/): blocks come
+// from the plans' caching pool; copies are synchronous.
+extern "C" void *fg_dev_alloc(size_t bytes, int device)
+{
+  if (hipSetDevice(device) != hipSuccess) { fail(FG_ERR_HIP, "fg_dev_alloc: no such HIP device %d", device); return nullptr; }
+  void *p = g_pool.get(device, bytes);
+  if (!p) fail(FG_ERR_HIP, "fg_dev_alloc: out of device memory (%zu bytes)", bytes);
+  return p;
+}
+extern "C" void fg_dev_free(void *p) { g_pool.put(p); }
+extern "C" int fg_dev_upload(void *dst_dev, const void *src_host, size_t bytes)
+{
+  if (bytes && (!dst_dev || !src_host)) return fail(FG_ERR_ARG, "fg_dev_upload: null pointer");
+  if (bytes) HIPCHK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int fg_dev_download(void *dst_host, const void *src_dev, size_t bytes)
+{
+  if (bytes && (!dst_host || !src_dev)) return fail(FG_ERR_ARG, "fg_dev_download: null pointer");
+  if (bytes) HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // ----------------------------------------------------------------------------- phase timing
 // Optional HIP-event timing of the phases of a search / sweep, recorded on the plan's own
 // stream (bench.py reads these for the roofline object; torch.cuda.Event would only see

@@ -143,6 +143,12 @@ void fg_plan_destroy(fg_plan *plan);
 int fg_plan_set_stream(fg_plan *plan, void *stream);
 /* return the cached device blocks of destroyed plans to the HIP runtime */
 void fg_pool_release(void);
+/* Device memory for plain-C callers (no HIP headers needed): blocks from the library's caching pool, synchronous copies.
+ * fg_dev_alloc returns NULL on failure (fg_last_error has the reason). */
+void *fg_dev_alloc(size_t bytes, int device);
+void fg_dev_free(void *p);
+int  fg_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
+int  fg_dev_download(void *dst_host, const void *src_dev, size_t bytes);
 
 long fg_plan_nxgrid(const fg_plan *plan);
 long fg_plan_ncells_in(const fg_plan *plan);      /* sum over source tiles of nx*ny */

@@ -1,0 +1,181 @@
+"""The C side of the boundary: the public header compiled as C, a plain C99 client of the B1 symbols
+written against the reference's prototypes, the fregrid replacement object type-checked against the reference's own struct
+declarations, and the link-order behaviour of libfregrid_hip.so next to the reference's static archive."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "fre-nctools_amd")
+CAPI = os.path.join(ROOT, "tests", "capi")
+REF = "/root/reference/tools"
+C99 = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic"]
+
+
+def _run(cmd, **kw):
+    r = subprocess.run(cmd, capture_output=True, text=True, **kw)
+    assert r.returncode == 0, (cmd, r.stdout[-2000:], r.stderr[-2000:])
+    return r
+
+
+def _build_probe(tmp):
+    exe = os.path.join(tmp, "b1_probe")
+    _run(C99 + ["-o", exe, os.path.join(CAPI, "b1_probe.c"), "-L", PKG, "-lfregrid_hip", f"-Wl,-rpath,{PKG}", "-lm"])
+    return exe
+
+
+def test_header_compiles_as_c99(tmp_path):
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "fregrid_hip.h"\nint main(void) { fg_apply_opts o; o.has_missing = 0; return o.has_missing + (int)sizeof(fg_plan *) * 0; }\n')
+    _run(C99 + ["-Wextra", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+    _run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c++", "-c", str(src), "-o", str(tmp_path / "hdr2.o")])
+
+
+def test_c99_probe_compiles_and_links(tmp_path):
+    """-std=c99 -Wall -Werror -pedantic; the probe's B1 prototypes are the reference's (checked against its headers below)."""
+    exe = _build_probe(str(tmp_path))
+    r = _run([exe, "-v"])                                   # get_maxxgrid: no device needed
+    assert "maxxgrid 5000000" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_probe_prototypes_agree_with_the_reference_headers(tmp_path):
+    """Compile the probe with the reference's create_xgrid.h / interp.h / mosaic_util.h force-included: a prototype that
+    differed from the reference's would be a conflicting-types error."""
+    lib = os.path.join(REF, "libfrencutils")
+    _run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-fsyntax-only", "-I", lib, "-include", os.path.join(lib, "create_xgrid.h"),
+          "-include", os.path.join(lib, "interp.h"), "-include", os.path.join(lib, "mosaic_util.h"), os.path.join(CAPI, "b1_probe.c")])
+    _run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-fsyntax-only", "-I", lib, "-include", os.path.join(lib, "create_xgrid.h"),
+          "-include", os.path.join(lib, "mosaic_util.h"), os.path.join(CAPI, "link_probe.c")])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_fregrid_replacement_object_type_checks_against_the_reference(tmp_path):
+    """integration/conserve_interp_hip.c against the reference's globals.h / conserve_interp.h / mpp.h / mpp_domain.h: every
+    struct member and mpp_* prototype it uses exists with a compatible type.  (globals.h wants <netcdf.h> for the nc_type
+    typedef only; tests/capi/typecheck_shim supplies that one typedef -- syntax check only, nothing is linked or run.)"""
+    _run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(CAPI, "typecheck_shim"),
+          "-I", os.path.join(REF, "fregrid"), "-I", os.path.join(REF, "libfrencutils"), "-I", os.path.join(ROOT, "include"),
+          os.path.join(ROOT, "integration", "conserve_interp_hip.c")])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_link_order_next_to_the_reference_archive(tmp_path):
+    """INTEGRATION.md section 1.  A static archive of the reference's create_xgrid.o + mosaic_util.o (+ mpp.o for mpp_error),
+    the probe linked (A) library first, (B) archive first:
+      (A) create_xgrid.o is NOT pulled in: the create_xgrid_* / get_grid_area calls bind to libfregrid_hip.so.  mosaic_util.o IS
+          pulled in (the program needs maxval_double / error_handler, as fregrid does) and with it the archive's poly_area and
+          fix_lon: the PROGRAM's calls to those two bind to its own copies -- while the library, linked -Bsymbolic-functions,
+          keeps calling its own.
+      (B) everything binds to the archive: the GPU path is silently not used.  That is the order to avoid."""
+    lib = os.path.join(REF, "libfrencutils")
+    objs = []
+    for name in ("create_xgrid", "mosaic_util", "mpp"):
+        o = str(tmp_path / f"{name}.o")
+        _run(["gcc", "-O2", "-w", "-c", "-I", lib, os.path.join(lib, f"{name}.c"), "-o", o])
+        objs.append(o)
+    ar = str(tmp_path / "libfrencutils_ref.a")
+    _run(["ar", "rcs", ar] + objs)
+    po = str(tmp_path / "link_probe.o")
+    _run(["gcc", "-std=c99", "-Wall", "-c", os.path.join(CAPI, "link_probe.c"), "-o", po])
+    a, b = str(tmp_path / "probe_a"), str(tmp_path / "probe_b")
+    _run(["gcc", "-o", a, po, "-L", PKG, "-lfregrid_hip", ar, f"-Wl,-rpath,{PKG}", "-lm"])
+    _run(["gcc", "-o", b, po, ar, "-L", PKG, "-lfregrid_hip", f"-Wl,-rpath,{PKG}", "-lm"])
+
+    def defined(exe):
+        out = _run(["nm", "--defined-only", exe]).stdout
+        return set(re.findall(r" [TtWw] (\w+)$", out, flags=re.M))
+
+    def bindings(exe):
+        env = dict(os.environ, LD_DEBUG="bindings", LD_BIND_NOW="1")
+        r = subprocess.run([exe], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+        out = {}
+        for mm in re.finditer(r"binding file (\S+) \[\d+\] to (\S+) \[\d+\]: normal symbol `(\w+)'", r.stderr):
+            out.setdefault((os.path.basename(mm.group(1)), mm.group(3)), os.path.basename(mm.group(2)))
+        return out
+
+    da, db = defined(a), defined(b)
+    assert "create_xgrid_2dx2d_order1" not in da and "get_grid_area" not in da          # (A) not pulled from the archive
+    assert {"poly_area", "fix_lon", "maxval_double", "error_handler"} <= da              # (A) mosaic_util.o is
+    assert {"create_xgrid_2dx2d_order1", "get_grid_area", "poly_area"} <= db             # (B) all from the archive
+    ba = bindings(a)
+    assert ba[("probe_a", "create_xgrid_2dx2d_order1")] == "libfregrid_hip.so"
+    assert ba[("probe_a", "get_grid_area")] == "libfregrid_hip.so"
+    # the library's own references to exported functions never go through the program's copies
+    leaked = [k for k, v in ba.items() if k[0] == "libfregrid_hip.so" and v == "probe_a" and k[1] in
+              {"poly_area", "fix_lon", "great_circle_area", "get_grid_area", "create_xgrid_2dx2d_order1", "pimod", "clip_2dx2d"}]
+    assert not leaked, leaked
+    # ... because it has no dynamic relocation against them at all (-Wl,-Bsymbolic-functions, csrc/Makefile)
+    rel = _run(["readelf", "-rW", os.path.join(PKG, "libfregrid_hip.so")]).stdout
+    own = [l for l in rel.splitlines() if re.search(r"\b(poly_area|fix_lon|great_circle_area|get_grid_area|create_xgrid_2dx2d_order[12]|clip_2dx2d|pimod)\b", l)]
+    assert not own, own
+
+
+@pytest.mark.gpu
+def test_c99_probe_results_equal_the_oracle(tmp_path, fg, gpu_ok):
+    """Run the C99 program on the device and compare what it wrote with the CPU oracle on the same grids."""
+    import orc
+    exe = _build_probe(str(tmp_path))
+    ni = 12
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(20, 10)
+    nx1, ny1, nx2, ny2 = ni, ni, 20, 10
+    lon1, lat1 = lon[2], lat[2]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        np.array([nx1, ny1, nx2, ny2], dtype=np.int32).tofile(f)
+        for a in (lon1, lat1, lo, la):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+    r = _run([exe, fin, fout])
+    assert "b1_probe ok" in r.stdout
+    buf = open(fout, "rb").read()
+    pos = [0]
+
+    def take(dt, n):
+        a = np.frombuffer(buf, dtype=dt, count=n, offset=pos[0]); pos[0] += a.nbytes
+        return a
+
+    def xg(order):
+        n = int(take(np.int32, 1)[0])
+        d = {"n": n}
+        for k in ("i_in", "j_in", "i_out", "j_out"):
+            d[k] = take(np.int32, n)
+        d["area"] = take(np.float64, n)
+        if order == 2:
+            d["clon"], d["clat"] = take(np.float64, n), take(np.float64, n)
+        return d
+
+    for order in (1, 2):
+        got = xg(order)
+        ref = orc.orc_create_xgrid(order, nx1, ny1, nx2, ny2, lon1, lat1, lo, la)
+        assert got["n"] == ref["n"] > 0
+        for k in ("i_in", "j_in", "i_out", "j_out"):
+            assert np.array_equal(got[k], ref[k])
+        assert np.max(np.abs(got["area"] - ref["area"]) / ref["area"]) < 1e-10
+        if order == 2:
+            for k in ("clon", "clat"):
+                assert np.max(np.abs(got[k] - ref[k])) < 1e-10 * np.max(np.abs(ref[k]))
+    carea = take(np.float64, nx1 * ny1)
+    assert np.max(np.abs(carea - orc.orc_get_grid_area(nx1, ny1, lon1, lat1).ravel()) / carea) < 1e-10
+    got = xg(1)
+    ref = orc.orc_create_xgrid_gc(nx1, ny1, nx2, ny2, lon1, lat1, lo, la)
+    assert got["n"] == ref["n"] and np.array_equal(got["i_out"], ref["i_out"]) and np.array_equal(got["j_out"], ref["j_out"])
+    assert np.max(np.abs(got["area"] - ref["area"]) / ref["area"]) < 1e-10
+    dst = take(np.float64, nx2 * ny2)
+    src = np.array([1.0 + (k % nx1) + 0.5 * (k // nx1) for k in range(nx1 * ny1)])
+    # interp.c:262-305: weights xarea / (sum of xarea over the destination cell), from the oracle's first-order exchange grid
+    x1 = orc.orc_create_xgrid(1, nx1, ny1, nx2, ny2, lon1, lat1, lo, la)
+    d_idx = x1["j_out"].astype(np.int64) * nx2 + x1["i_out"]; s_idx = x1["j_in"].astype(np.int64) * nx1 + x1["i_in"]
+    asum = np.bincount(d_idx, weights=x1["area"], minlength=nx2 * ny2)
+    refd = np.bincount(d_idx, weights=src[s_idx] * x1["area"] / asum[d_idx], minlength=nx2 * ny2)
+    cov = asum > 0
+    assert np.allclose(dst[cov], refd[cov], rtol=1e-10, atol=0) and pos[0] == len(buf)
+    m = re.search(r"poly_area (\S+)", r.stdout)
+    x, y = np.array([0.1, 0.3, 0.3, 0.1]), np.array([0.2, 0.2, 0.5, 0.5])
+    pa = orc.oracle().orc_poly_area(orc._dp(x), orc._dp(y), 4)
+    assert abs(float(m.group(1)) - pa) <= 1e-10 * abs(pa)
