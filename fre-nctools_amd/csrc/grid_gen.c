@@ -15,7 +15,7 @@
  *       follows tools/fregrid/fregrid_util.c:564-603,645-654 (get_output_grid_by_size).
  *
  * Same operation order as the reference so the corners agree to the last bit
- * with glibc libm (checked in tests/test_grid_gen.py against oracle/_ref).
+ * with glibc libm (checked against oracle/_ref in tests/test_oracle_vs_ref.py and tests/test_c2l_cpu.py).
  */
 #include <math.h>
 #include <stdlib.h>

@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """Which libm the bit-identity assertions of the legacy path are judged against (tests/orc.py:host_has_fma): a host whose
+    libm does not evaluate sin/cos the way csrc/sincos_glibc.h does relaxes them to 1e-10 -- make that visible in the log."""
+    import platform
+    try:
+        fma = " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        fma = None
+    libc = " ".join(platform.libc_ver())
+    mode = "bit-identical areas / centroids asserted" if fma else "RELAXED to 1e-10 (host libm without the FMA sin/cos build)"
+    return [f"fregrid-hip parity: host libc {libc}, cpu fma={fma}: {mode}"]
+
+
 def load_package():
     """The package directory is called ``fre-nctools_amd`` (not an identifier): import it as fre_nctools_amd."""
     if "fre_nctools_amd" in sys.modules:

@@ -176,3 +176,26 @@ def test_config4b_c768_legacy_order2_full_size(fg, gpu_ok):
     plan.sync()
     assert float((out - 2.5).abs().max()) < 1e-13
     plan.destroy()
+
+
+def test_mass_gap_equals_the_references(fg, gpu_ok):
+    """north_star asks for mass conserved to 1e-10; by the reference's definition (conserve_interp.c:874-907) the bench reports
+    ~1e-9.  tests/test_mass_gap_reference.py computes that gap with the reference's own compiled code at C96 -> 360x180 and pins
+    it; here the device path must reproduce the SAME number -- the gap belongs to the reference's exchange grid, and the remap
+    itself conserves to rounding (mass_rel_err_xgrid in bench.py)."""
+    import json
+    from test_mass_gap_reference import GOLD, NI, NLON, NLAT, field_on_cells, gap_from
+    lon, lat, lont, latt = fg.gnomonic_ed_grid(NI)
+    lo, la = fg.latlon_corners(NLON, NLAT)
+    plan = fg.XgridPlan.create(2, [fg.GridConfig(NI, NI, lon[t], lat[t]) for t in range(6)], fg.GridConfig(NLON, NLAT, lo, la))
+    x = plan.get_xgrid()
+    assert plan.nxgrid == 256864
+    a_in, _ = plan.get_cell_area(NLON * NLAT)
+    s_idx = x["t_in"].astype(np.int64) * NI * NI + x["j_in"].astype(np.int64) * NI + x["i_in"]
+    gap, closure = gap_from(x["area"], s_idx, a_in, field_on_cells(lont, latt).ravel())
+    gold = json.load(open(GOLD))
+    if orc.host_has_fma():                       # areas are the reference's bits, the sums are the same numpy reductions
+        assert gap == gold["gap"] and closure == gold["closure"], (gap, closure, gold)
+    else:
+        assert abs(gap - gold["gap"]) < 1e-3 * abs(gold["gap"])
+    plan.destroy()
