@@ -220,6 +220,69 @@ def config5_leg(fg, torch, dev, device, nz=50, nt=20, nfields=3):
             "note": "page-locked host buffers (fg_host_alloc); levels cross the link as float and are widened / narrowed on the device"}
 
 
+def banded_search_job(fg, torch, dist, dev, local_rank, world, rank, ni, nlon, nlat, steps, warmup, repeats):
+    """One strong-scaling weight-generation job: C<ni> -> nlon x nlat, order 2, this rank's latitude band of the target (equal
+    rows: measured max/mean <= 1.06 up to 8 ranks, scripts/band_time.py), source cells culled to the band, the per-source-cell sums
+    of the cells cut by a band boundary all-reduced (RCCL).  Returns median seconds per region of `steps` steps, max over ranks."""
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    j0, j1 = fg.band_rows(nlat, world, rank)
+    h2d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lon_t = [h2d(lon[t]) for t in range(6)]; lat_t = [h2d(lat[t]) for t in range(6)]
+    lo_t, la_t = h2d(lo[j0:j1 + 1]), h2d(la[j0:j1 + 1])
+    ncell = 6 * ni * ni
+    stream = torch.cuda.current_stream().cuda_stream
+    mk = lambda: fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, j1 - j0, lo_t, la_t, np.pi / nlat, 2 * np.pi / nlon,
+                                         device=local_rank, stream=stream)
+    bidx_t = None
+    total = torch.empty(3 * ncell, dtype=torch.float64, device=dev)
+    if world > 1:
+        p0 = mk(); cs = p0.get_cell_struct(0, ncell); p0.destroy()
+        bidx_t = h2d(fg.boundary_source_cells(cs["lat_min"], cs["lat_max"], la, nlat, world).astype(np.int64))
+        fg.lib().fg_set_search_cull(1)
+    plan = [None]
+
+    def step():
+        if plan[0] is not None:
+            plan[0].destroy()
+        p = mk()
+        if world > 1:
+            p.copy_cell_sums(total)
+            fg.allreduce_cell_sums_sparse(total, bidx_t, ncell)
+            torch.cuda.current_stream().synchronize()
+            p.finalize(total.data_ptr())
+        else:
+            p.finalize(None)
+        plan[0] = p
+        return p
+    fg.lib().fg_set_profiling(0)
+    for _ in range(warmup):
+        step()
+    reps = []
+    for _ in range(repeats):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            p = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        reps.append(time.perf_counter() - t0)
+    nx = torch.tensor([float(plan[0].nxgrid)], dtype=torch.float64, device=dev)
+    rt = torch.tensor(reps, dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(nx); dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+    plan[0].destroy()
+    fg.lib().fg_set_search_cull(0); fg.lib().fg_set_profiling(1)
+    reps = [float(v) for v in rt.cpu()]
+    med = float(np.median(reps))
+    return {"workload": f"C{ni} (6 tiles) -> {nlon}x{nlat}, conservative_order2, search + centroid pass + CSR build per step",
+            "nxgrid": int(nx.item()), "ms_per_step": med / steps * 1e3, "ms_per_step_min": min(reps) / steps * 1e3,
+            "exchange_cells_per_s": steps * int(nx.item()) / med, "steps": steps, "repeats": repeats, "n_gpus": world,
+            "boundary_cells_exchanged": (int(bidx_t.numel()) if bidx_t is not None else 0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,6 +379,7 @@ def main():
         p0.destroy()
         bidx = fg.boundary_source_cells(cs["lat_min"], cs["lat_max"], la, nlat, world)
         bidx_t = torch.from_numpy(bidx.astype(np.int64)).to(dev)
+        fg.lib().fg_set_search_cull(1)          # each rank builds records only for the source cells that can meet its band
 
     def step():
         if plan[0] is not None:
@@ -362,6 +426,7 @@ def main():
         dist.all_reduce(reps_t, op=dist.ReduceOp.MAX)
     reps = [float(v) for v in reps_t.cpu()]
     dt = float(np.median(reps))
+    fg.lib().fg_set_search_cull(0)
 
     # ---- sweep leg
     apply_steps = args.apply_steps
@@ -527,6 +592,15 @@ def main():
             "phase_ms": phases, "search_stats": stats,
             "roofline": roof, "roofline_apply": roof_a,
         }
+        pass
+    # ---- the larger job of BASELINE config 4 (C768 -> 0.125 deg, 16.7 M exchange cells), same decomposition: where strong scaling
+    # is not bound by launch latency.  Collective: every rank takes part.
+    c768 = None
+    if world > 1 or "c768" in legs:
+        c768 = banded_search_job(fg, torch, dist if world > 1 else None, dev, local_rank, world, rank, 768, 2880, 1440, 5, 2, 3)
+    if rank == 0:
+        if c768 is not None:
+            line["c768_order2"] = c768
         if world == 1 and args.gc_steps > 0 and "gc" in legs:
             # BASELINE config 4's clip method on the same grids (create_xgrid_great_circle semantics, first order): unit
             # vectors made on the host with libm as the reference does (not timed), search timed with inputs resident

@@ -25,12 +25,12 @@ from .c2l import C2lPrep, find_contacts, c2l_grid_info, halo_map  # noqa: F401
 from .remap_file import write_remap_file, read_remap_file  # noqa: F401
 from .field_io import NcFile, Sweep, HostBuffer, read_field_levels  # noqa: F401
 from . import field_io  # noqa: F401
-from .parallel import (band_rows, allreduce_cell_sums, allreduce_scalar_sum, allreduce_minmax,  # noqa: F401
+from .parallel import (band_rows, row_cost, allreduce_cell_sums, allreduce_scalar_sum, allreduce_minmax,  # noqa: F401
                        boundary_source_cells, allreduce_cell_sums_sparse)
 from .conserve_interp import (  # noqa: F401
     CONSERVE_ORDER1, CONSERVE_ORDER2, CHECK_CONSERVE, READ, WRITE, TARGET, MONOTONIC, GREAT_CIRCLE, LEGACY_CLIP, CELL_METHODS_MEAN, CELL_METHODS_SUM,
     GridConfig, InterpConfig, FieldConfig, VarConfig, XgridPlan,
-    setup_conserve_interp, do_scalar_conserve_interp,
+    setup_conserve_interp, do_scalar_conserve_interp, write_remap_gathered,
 )
 
 __all__ = [

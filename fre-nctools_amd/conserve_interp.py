@@ -457,21 +457,52 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
                                                                        x["j_out"], x["area"])
             if order == 2:
                 ic.di_in, ic.dj_in = x["c1"], x["c2"]
-    if opcode & WRITE:                                                 # conserve_interp.c:368-445 (single rank: no gather)
-        from .remap_file import write_remap_file
+    if opcode & WRITE:                                                 # conserve_interp.c:368-445
         for n in range(ntiles_out):
             ic = interp[n]
-            if ic.remap_file and ic.nxgrid > 0:
-                if not fetch:
-                    x = plans[n].get_xgrid()
-                    ic.t_in, ic.i_in, ic.j_in, ic.i_out, ic.j_out, ic.area = (x["t_in"], x["i_in"], x["j_in"], x["i_out"],
-                                                                               x["j_out"], x["area"])
-                    if order == 2:
-                        ic.di_in, ic.dj_in = x["c1"], x["c2"]
-                write_remap_file(ic.remap_file, order, ic.t_in, ic.i_in, ic.j_in, ic.i_out, ic.j_out, ic.area,
-                                 ic.di_in, ic.dj_in, grid_out[n].isc, grid_out[n].jsc)
+            if not ic.remap_file:
+                continue
+            if not fetch and ic.nxgrid > 0:
+                x = plans[n].get_xgrid()
+                ic.t_in, ic.i_in, ic.j_in, ic.i_out, ic.j_out, ic.area = (x["t_in"], x["i_in"], x["j_in"], x["i_out"],
+                                                                           x["j_out"], x["area"])
+                if order == 2:
+                    ic.di_in, ic.dj_in = x["c1"], x["c2"]
+            write_remap_gathered(ic, grid_out[n], order)
     print("NOTE: done calculating index and weight for conservative interpolation")   # :446
     return interp
+
+
+def write_remap_gathered(ic, grid_out_n, order):
+    """The WRITE branch for one output tile (conserve_interp.c:368-445): mpp_sum_int of nxgrid, the exchange cells of every rank
+    gathered on the root in rank order (mpp_gather_field_int / _double; output indices made global with isc / jsc BEFORE the
+    gather, :407,:416), one file written by the root.  Every rank must call it (it is a collective when a process group is
+    initialised); returns the global nxgrid.  Host arrays only: no device work."""
+    from .parallel import world_size
+    from .remap_file import write_remap_file
+    n_loc = int(ic.nxgrid)
+    z_i, z_d = np.zeros(0, dtype=np.int32), np.zeros(0)
+    part = {"t_in": ic.t_in if n_loc else z_i, "i_in": ic.i_in if n_loc else z_i, "j_in": ic.j_in if n_loc else z_i,
+            "i_out": (np.asarray(ic.i_out) + grid_out_n.isc) if n_loc else z_i,
+            "j_out": (np.asarray(ic.j_out) + grid_out_n.jsc) if n_loc else z_i,
+            "area": ic.area if n_loc else z_d}
+    if order == 2:
+        part["di_in"], part["dj_in"] = (ic.di_in if n_loc else z_d), (ic.dj_in if n_loc else z_d)
+    rank = 0
+    if world_size() > 1:
+        import torch.distributed as dist
+        rank = dist.get_rank()
+        parts = [None] * world_size()
+        dist.all_gather_object(parts, {k: np.ascontiguousarray(v) for k, v in part.items()})
+        part = {k: np.concatenate([p[k] for p in parts]) for k in part}
+    n_glob = int(part["area"].size)
+    if rank == 0 and n_glob > 0:
+        write_remap_file(ic.remap_file, order, part["t_in"], part["i_in"], part["j_in"], part["i_out"], part["j_out"], part["area"],
+                         part.get("di_in"), part.get("dj_in"), 0, 0)
+    if world_size() > 1:
+        import torch.distributed as dist
+        dist.barrier()                                                # the file exists when any rank returns
+    return n_glob
 
 
 def pack_field(order, field_in, ntiles_in, nz, key="data"):

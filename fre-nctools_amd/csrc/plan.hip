@@ -377,6 +377,7 @@ static const char *gc_clip_error(int code)
 // Capacities of one attempt: bin-table records and entries per region of the pair list.  The default capacities (bin records
 // 3*ndst, pairs 8*max(nsrc, ndst)) fit every remap between grids of comparable resolution; every kernel clamps its writes
 // AND reads to them, the counters keep counting, and an attempt that outgrew one is repeated with the counted sizes.
+static int g_search_cull = 0;
 struct SearchCaps { unsigned long long entries; int regcap, nreg; };
 // Chunks of source cells per search (1 = everything on one stream, in sequence; fg_set_search_chunks / FREGRID_HIP_CHUNKS).  Measured at C384 -> 0.25 deg with 4 chunks: the
 // kernels slow each other down by more than the overlap wins (clip 4 x 184 us against 482, step 1.48 ms against 1.30), so the
@@ -510,6 +511,10 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     fgd_gc_cell_struct(gct_dev, pl->ntiles, nsrc, pl->S, st);
     fgd_gc_cell_struct(gct_dev + pl->ntiles, 1, ndst, pl->D, st);
     fgd_src_field_index(order, pl->tiles_dev, pl->ntiles, nsrc, pl->src_idx_f, st);
+  } else if (g_search_cull && !boxm) {
+    // destination cells first (their latitude range goes to dc->band_keys), then the source cells that can meet it
+    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, 0, ndst, pl->S, pl->D, bins, bin_cnt, order, nullptr, nullptr, dc->err, st, dc->band_keys, 0);
+    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, 0, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st, dc->band_keys, 1);
   } else
     fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st);
   if (boxm) fgd_box_cell_boxes(boxm->box, pl->S, st);
@@ -644,6 +649,9 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
 // FREGRID_HIP_EXACT_SEARCH=1 starts from empty buffers, i.e. sizes everything by counting (tests; memory-tight callers).
 static int g_search_exact = 0;
 extern "C" void fg_set_search_mode(int exact) { g_search_exact = exact; }
+// 1: source cells whose latitude range cannot meet the destination grid get no record (a rank of a banded multi-GPU job sees
+// a fraction of the source cells); fg_plan_get_cell_area then returns 0 for them.  Results are unchanged.
+extern "C" void fg_set_search_cull(int on) { g_search_cull = on ? 1 : 0; }
 static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
                         double mean_dlat, double mean_dlon, const GcXyz *gc_in = nullptr, const GcXyz *gc_out = nullptr,

@@ -90,6 +90,7 @@ struct FgTileSet { FgTile t[FG_TILESET_MAX]; int n; };
 struct FgCounters {
   unsigned long long total[4];     // [0] bin-table entries  [1] candidate pairs  [2] (unused)  [3] largest region fill
   unsigned long long rows_total;   // total of the destination-row scan (= nxgrid)
+  unsigned long long band_keys[2]; // latitude range of the destination cells as ordered keys (source-cell culling)
   unsigned long long xtot[FG_MAX_CHUNKS];   // running nxgrid after chunk k of the source cells (the last one is nxgrid)
   unsigned err[4];
   int heavy_cnt, pad0;
@@ -108,7 +109,8 @@ void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *st
 // per-cell records of the source tiles and of the destination tile in ONE launch; also counts the destination cells into
 // their bins (slot_cnt), fills src_idx_f, zeroes sums[3][nsrc] (may be null) and stores the tile descriptors at tiles_out
 void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, FgCells D,
-                      FgBins b, int *slot_cnt, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st);
+                      FgBins b, int *slot_cnt, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
+                      unsigned long long *band_keys = nullptr, int cull = 0);
 void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c, unsigned *err, hipStream_t st);
 void fgd_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt, hipStream_t st);
 // bin fill + list of the source cells whose candidate scan gets a whole wave

@@ -179,11 +179,27 @@ void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *st
 // ---------------------------------------------------------------------------------------
 // per-cell records
 // ---------------------------------------------------------------------------------------
+// doubles as unsigned keys with the same order (for atomicMax over latitudes)
+__device__ __forceinline__ unsigned long long d_ord_key(double v)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double d_ord_val(unsigned long long k)
+{
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
 // body shared by the two kernels below: record of cell s0 + threadIdx.x of `ncells` cells described by `tiles`; the 16 vertex
 // doubles are staged so that the block stores its 256 records as one contiguous run (a lane writing its own 128-byte
 // record makes sixteen 8-byte stores at a 128-byte stride).  Returns the vertex count (0: no record) and the box.
+// cull != null: {max key of lat_max, max of ~key of lat_min} over the destination cells (this rank's band): a cell whose
+// latitude range cannot meet the band -- the reference's strict test, create_xgrid.c:1055, would reject every pair -- gets
+// nv = 0 and area 0 and nothing else; a block without a live cell skips its vertex records altogether.
 __device__ __forceinline__ int d_cell_record(const FgTile *tiles, int ntiles, int ncells, const FgCells &c, unsigned *err, int s0,
-                                             double *vtile, double *box /* lat_min, lat_max, lon_min, lon_max */, int *tile_of)
+                                             double *vtile, double *box /* lat_min, lat_max, lon_min, lon_max */, int *tile_of,
+                                             const unsigned long long *cull = nullptr)
 {
   const int s = s0 + threadIdx.x;
   double *row = vtile + threadIdx.x * 17;
@@ -210,8 +226,14 @@ __device__ __forceinline__ int d_cell_record(const FgTile *tiles, int ntiles, in
     c.lat_min[s] = lmin; c.lat_max[s] = lmax;
     box[0] = lmin; box[1] = lmax;
     if (!(lmin >= -G_HPI - 1.e-6) || !(lmax <= G_HPI + 1.e-6)) atomicOr(err, G_ERRBIT_BADLAT);   // also catches NaN
-    int n = d_fix_lon(x, y, 4, G_PI);
-    if (n < 0 || n > G_MAXV) {
+    bool out_of_band = false;
+    if (cull && cull[0]) {
+      const double bmax = d_ord_val(cull[0]), bmin = d_ord_val(~cull[1]);
+      out_of_band = (lmax <= bmin) || (lmin >= bmax);
+    }
+    int n = out_of_band ? 0 : d_fix_lon(x, y, 4, G_PI);
+    if (out_of_band) { c.nv[s] = 0; c.area[s] = 0; }
+    else if (n < 0 || n > G_MAXV) {
       atomicOr(err, G_ERRBIT_MAXV);
       c.nv[s] = 0; c.lon_min[s] = 0; c.lon_max[s] = 0; c.lon_avg[s] = 0; c.area[s] = 0;
     } else {
@@ -230,7 +252,7 @@ __device__ __forceinline__ int d_cell_record(const FgTile *tiles, int ntiles, in
       c.area[s] = d_poly_area<1>(x, y, n);
     }
   }
-  __syncthreads();
+  if (!__syncthreads_or(nvert != 0) && cull) return 0;        // no live cell in this block: no vertex records to store
   const long cnt = (long)min(256, ncells - s0) * 16;
   double *out = c.verts + (size_t)s0 * 16;
 #pragma unroll
@@ -333,7 +355,7 @@ __device__ __forceinline__ void d_bin_insert(bool live, int d, double lat_min, d
 // fregrid_util.c:2137-2145); destination blocks count their cells into the bins; block 0 stores the tile descriptors.
 __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst,
                                                        int nbS, FgCells S, FgCells D, FgBins b, int *slot_cnt, int order, int *src_idx_f,
-                                                       double *sums, unsigned *err)
+                                                       double *sums, unsigned *err, unsigned long long *band_keys, int cull)
 {
   __shared__ double vtile[256 * 17];
   __shared__ FgTile sh_tiles[FG_TILESET_MAX];
@@ -346,7 +368,7 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
   int tl = 0;
   if (!isD) {
     const int s0 = blockIdx.x * 256, s = s0 + threadIdx.x;
-    (void)d_cell_record(tiles, ntiles, nsrc, S, err, s0, vtile, box, &tl);
+    (void)d_cell_record(tiles, ntiles, nsrc, S, err, s0, vtile, box, &tl, cull ? band_keys : nullptr);
     if (s < nsrc && sums) { sums[s] = 0.0; sums[nsrc + s] = 0.0; sums[2 * (size_t)nsrc + s] = 0.0; }   // k_compact visits cells with exchange cells only
     if (s < nsrc && src_idx_f) {
       if (order != 2) src_idx_f[s] = s;
@@ -361,6 +383,12 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
     const int d0 = ((int)blockIdx.x - nbS) * 256, d = d0 + threadIdx.x;
     const int nv = d_cell_record(tiles + ntiles, 1, ndst, D, err, d0, vtile, box, &tl);
     d_bin_insert<false>(d < ndst && nv != 0, d, box[0], box[1], box[2], box[3], box[4], b, slot_cnt, nullptr, nullptr, 0);
+    if (band_keys) {                                    // latitude range of the destination cells, for the culling of a later launch
+      unsigned long long kmax = (d < ndst && nv != 0) ? d_ord_key(box[1]) : 0ull, kmin = (d < ndst && nv != 0) ? ~d_ord_key(box[0]) : 0ull;
+#pragma unroll
+      for (int o = 32; o; o >>= 1) { kmax = max(kmax, __shfl_xor(kmax, o)); kmin = max(kmin, __shfl_xor(kmin, o)); }
+      if ((threadIdx.x & 63) == 0 && kmax) { atomicMax(&band_keys[0], kmax); atomicMax(&band_keys[1], kmin); }
+    }
   }
 }
 
@@ -1162,11 +1190,13 @@ void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c,
 }
 
 void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, FgCells D,
-                      FgBins b, int *slot_cnt, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st)
+                      FgBins b, int *slot_cnt, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
+                      unsigned long long *band_keys, int cull)
 {
   const int nbS = nblk(nsrc, 256), nbD = nblk(ndst, 256);
   if (nbS + nbD > 0)
-    k_cell_struct2<<<nbS + nbD, 256, 0, st>>>(ts, tiles_in, tiles_out, ntiles, nsrc, ndst, nbS, S, D, b, slot_cnt, order, src_idx_f, sums, err);
+    k_cell_struct2<<<nbS + nbD, 256, 0, st>>>(ts, tiles_in, tiles_out, ntiles, nsrc, ndst, nbS, S, D, b, slot_cnt, order, src_idx_f, sums, err,
+                                              band_keys, cull);
 }
 
 void fgd_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt, hipStream_t st)

@@ -300,6 +300,10 @@ void fg_set_search_mode(int exact);
  * the compaction of the previous one.  0 (default) = 1: one stream, in sequence -- at C384 -> 0.25 deg the overlapped kernels
  * slow each other down by more than the overlap wins.  Results do not depend on it.  Also FREGRID_HIP_CHUNKS. */
 void fg_set_search_chunks(int chunks);
+/* 1: source cells whose latitude range cannot meet the destination grid are skipped when the per-cell records are built (a
+ * rank of a banded multi-GPU job meets a fraction of the source cells); fg_plan_get_cell_area / _cell_struct then return 0 /
+ * unspecified values for those cells.  The exchange cells are unchanged.  Default 0. */
+void fg_set_search_cull(int on);
 /* Sweep tuning hook: 1 = each XCD sweeps one contiguous band of destination rows (measured slower on MI355X, see
  * csrc/apply_kernels.hip); 0 (default) = blocks in row order.  Results do not depend on it. */
 void fg_set_apply_xcd(int on);

@@ -17,6 +17,12 @@ def _mono_fields(ncell):
     return rng.standard_normal(ncell) + 5.0, rng.standard_normal(ncell), rng.standard_normal(ncell)
 
 
+def _weights(la, world):
+    """world 2: the reference's equal split; world 4: cost-weighted, unequal bands (parallel.row_cost)"""
+    from conftest import load_package
+    return None if world == 2 else load_package().row_cost(la, 90.0 / 12, pole_rows=3, pole_penalty=4.0)
+
+
 def _worker(rank, world, initfile, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -29,7 +35,8 @@ def _worker(rank, world, initfile, outdir):
     ni, nlon, nlat = 12, 36, 18
     lon, lat = fg.gnomonic_ed_corners(ni)
     lo, la = fg.latlon_corners(nlon, nlat)
-    j0, j1 = fg.band_rows(nlat, world, rank)
+    wts = _weights(la, world)
+    j0, j1 = fg.band_rows(nlat, world, rank, wts)
     blo, bla = lo[j0:j1 + 1], la[j0:j1 + 1]
     ncell = 6 * ni * ni
     sums = np.zeros((3, ncell))
@@ -47,7 +54,7 @@ def _worker(rank, world, initfile, outdir):
     # cell the rank can see exchange cells of (its band), the result must equal the full all-reduce
     lat_rng = [orc.orc_cell_struct(ni, ni, lon[t], lat[t]) for t in range(6)]
     lat_min = np.concatenate([c["lat_min"] for c in lat_rng]); lat_max = np.concatenate([c["lat_max"] for c in lat_rng])
-    bidx = fg.boundary_source_cells(lat_min, lat_max, la, nlat, world)
+    bidx = fg.boundary_source_cells(lat_min, lat_max, la, nlat, world, wts)
     sparse = torch.from_numpy(sums.reshape(-1).copy())
     fg.allreduce_cell_sums_sparse(sparse, torch.from_numpy(bidx.astype(np.int64)), ncell)
     sparse = sparse.numpy().reshape(3, ncell)
@@ -78,18 +85,36 @@ def _worker(rank, world, initfile, outdir):
     dist.destroy_process_group()
 
 
-def test_two_rank_band_decomposition_matches_single_rank(fg):
-    import torch.multiprocessing as mp
-    import orc
+def test_band_rows_equal_and_weighted(fg):
     assert [fg.band_rows(720, 8, r) for r in (0, 7)] == [(0, 90), (630, 720)]
     assert [fg.band_rows(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]      # mpp_compute_extent style
-    world = 2
+    w = np.array([8.0, 1, 1, 1, 1, 1, 1, 1, 1, 8])
+    cuts = [fg.band_rows(10, 3, r, w) for r in range(3)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    assert cuts == [(0, 1), (1, 9), (9, 10)]                                             # the heavy end rows stand alone
+    assert [fg.band_rows(5, 5, r, np.ones(5)) for r in range(5)] == [(k, k + 1) for k in range(5)]
+    lo, la = fg.latlon_corners(36, 18)
+    rc = fg.row_cost(la, 7.5)
+    assert rc.shape == (18,) and rc[0] < rc[4] < rc[8]          # equatorial rows produce the most exchange cells
+    assert fg.row_cost(la, 7.5, pole_rows=2, pole_penalty=4.0)[0] > rc[0]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_band_decomposition_matches_single_rank(fg, world):
+    import torch.multiprocessing as mp
+    import orc
     with tempfile.TemporaryDirectory() as td:
         initfile = os.path.join(td, "init")
         mp.spawn(_worker, args=(world, initfile, td), nprocs=world, join=True)
         parts = [np.load(os.path.join(td, f"rank{r}.npz")) for r in range(world)]
-    assert list(parts[0]["band"]) == [0, 9] and list(parts[1]["band"]) == [9, 18]
     ni, nlon, nlat = 12, 36, 18
+    la_full = fg.latlon_corners(nlon, nlat)[1]
+    bands = [fg.band_rows(nlat, world, r, _weights(la_full, world)) for r in range(world)]
+    assert [tuple(p["band"]) for p in parts] == bands
+    if world == 2:
+        assert bands == [(0, 9), (9, 18)]
+    else:
+        assert len({b[1] - b[0] for b in bands}) > 1                                     # unequal bands
     lon, lat = fg.gnomonic_ed_corners(ni)
     lo, la = fg.latlon_corners(nlon, nlat)
     o = orc.orc_setup(2, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
@@ -104,7 +129,7 @@ def test_two_rank_band_decomposition_matches_single_rank(fg):
         v = np.concatenate([p[k] for p in parts])[order]
         assert np.max(np.abs(v - o[k])) < 1e-12 * max(1.0, np.max(np.abs(o[k])))
     assert abs(float(parts[0]["gsum"]) - float(np.sum(o["area"]))) < 1e-6 * np.sum(o["area"]) * 1e-6
-    assert float(parts[0]["gsum"]) == float(parts[1]["gsum"])
+    assert all(float(p["gsum"]) == float(parts[0]["gsum"]) for p in parts)
     # monotone extremes: both ranks hold the global per-source-cell min / max
     f, gxv, gyv = _mono_fields(6 * ni * ni)
     sref = o["t_in"].astype(np.int64) * ni * ni + o["j_in"] * ni + o["i_in"]
@@ -113,4 +138,53 @@ def test_two_rank_band_decomposition_matches_single_rank(fg):
     np.minimum.at(fmin, sref, xd); np.maximum.at(fmax, sref, xd)
     for p in parts:
         assert np.allclose(p["fmin"], fmin, rtol=1e-12, atol=1e-12) and np.allclose(p["fmax"], fmax, rtol=1e-12, atol=1e-12)
-    assert np.array_equal(parts[0]["fmin"], parts[1]["fmin"]) and np.array_equal(parts[0]["fmax"], parts[1]["fmax"])
+    assert all(np.array_equal(parts[0]["fmin"], p["fmin"]) and np.array_equal(parts[0]["fmax"], p["fmax"]) for p in parts)
+
+
+def _write_worker(rank, world, initfile, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from conftest import load_package
+    import orc
+    fg = load_package()
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    ni, nlon, nlat = 12, 36, 18
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    j0, j1 = fg.band_rows(nlat, world, rank)
+    o = orc.orc_setup(2, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, j1 - j0, lo[j0:j1 + 1], la[j0:j1 + 1])])
+    ic = fg.InterpConfig(nxgrid=o["n"], i_in=o["i_in"], j_in=o["j_in"], i_out=o["i_out"], j_out=o["j_out"], t_in=o["t_in"],
+                         di_in=o["di"], dj_in=o["dj"], area=o["area"], remap_file=os.path.join(outdir, "remap_parallel.nc"))
+    g = fg.GridConfig(nlon, j1 - j0, lo[j0:j1 + 1], la[j0:j1 + 1]); g.isc, g.jsc = 0, j0
+    n = fg.write_remap_gathered(ic, g, 2)
+    open(os.path.join(outdir, f"n{rank}.txt"), "w").write(str(n))
+    dist.destroy_process_group()
+
+
+def test_write_branch_gathers_to_one_file(fg, tmp_path):
+    """with several ranks the WRITE branch must gather every band's exchange cells on the root and write ONE file
+    (conserve_interp.c:368-445), not let each rank clobber it with its own band.  Two ranks (bands of the target) against the
+    single-rank file: same cells in band order, global output indices, and a READ of it gives the single-rank plan back."""
+    import torch.multiprocessing as mp
+    import orc
+    world = 2
+    td = str(tmp_path)
+    mp.spawn(_write_worker, args=(world, os.path.join(td, "init"), td), nprocs=world, join=True)
+    ni, nlon, nlat = 12, 36, 18
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    o = orc.orc_setup(2, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
+    assert [int(open(os.path.join(td, f"n{r}.txt")).read()) for r in range(world)] == [o["n"], o["n"]]
+    ic = fg.InterpConfig(nxgrid=o["n"], i_in=o["i_in"], j_in=o["j_in"], i_out=o["i_out"], j_out=o["j_out"], t_in=o["t_in"],
+                         di_in=o["di"], dj_in=o["dj"], area=o["area"], remap_file=os.path.join(td, "remap_single.nc"))
+    g = fg.GridConfig(nlon, nlat, lo, la); g.isc, g.jsc = 0, 0
+    assert fg.write_remap_gathered(ic, g, 2) == o["n"]
+    par, one = fg.read_remap_file(os.path.join(td, "remap_parallel.nc"), 2), fg.read_remap_file(os.path.join(td, "remap_single.nc"), 2)
+    key = lambda x: (x["t_in"].astype(np.int64) * ni * ni + x["j_in"] * ni + x["i_in"]) * nlon * nlat + x["j_out"] * nlon + x["i_out"]
+    kp, k1 = key(par), key(one)
+    assert kp.size == k1.size == o["n"] and np.array_equal(np.sort(kp), np.sort(k1))
+    assert np.all(np.diff(par["j_out"] >= 9) >= 0)                    # rank order: band 0's cells, then band 1's
+    op, o1 = np.argsort(kp, kind="stable"), np.argsort(k1, kind="stable")
+    for k in ("area", "di_in", "dj_in"):
+        assert np.allclose(par[k][op], one[k][o1], rtol=1e-12, atol=1e-300)

@@ -389,6 +389,39 @@ def test_chunked_search_gives_the_same_plan(fg, gpu_ok):
     assert res[0][1]["pairs"] == res[1][1]["pairs"] == res[2][1]["pairs"]
 
 
+def test_source_cell_culling_keeps_the_plan(fg, gpu_ok):
+    """fg_set_search_cull(1): a rank that owns one latitude band builds records only for the source cells that can meet it.
+    Same exchange cells, order-2 integrals and cell sums as without culling, on a polar and on a mid-latitude band."""
+    ni, nlon, nlat = 24, 72, 36
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    gin = [(ni, ni, lon[t], lat[t]) for t in range(6)]
+    for (j0, j1) in ((0, 5), (14, 23), (30, 36)):
+        band = (nlon, j1 - j0, lo[j0:j1 + 1], la[j0:j1 + 1])
+        res = []
+        try:
+            for cull in (0, 1):
+                fg.lib().fg_set_search_cull(cull)
+                plan = fg.XgridPlan.create(2, [fg.GridConfig(*g) for g in gin], fg.GridConfig(*band))
+                a_in, _ = plan.get_cell_area(band[0] * band[1])
+                plan.finalize()
+                x = plan.get_xgrid()
+                res.append((plan.nxgrid, x, a_in))
+                plan.destroy()
+        finally:
+            fg.lib().fg_set_search_cull(0)
+        (n0, x0, a0), (n1, x1, a1) = res
+        assert n0 == n1 > 0
+        for k in ("t_in", "i_in", "j_in", "i_out", "j_out"):
+            assert np.array_equal(x0[k], x1[k])
+        for k in ("area", "c1", "c2"):
+            assert np.array_equal(x0[k].view(np.uint64), x1[k].view(np.uint64))
+        live = a1 != 0
+        assert 0 < live.sum() < live.size and np.array_equal(a0[live], a1[live])      # culled cells report area 0
+        s = x0["t_in"].astype(np.int64) * ni * ni + x0["j_in"].astype(np.int64) * ni + x0["i_in"]
+        assert live[s].all()                                                            # every cell with exchange cells was kept
+
+
 def test_bin_record_overflow_falls_back_to_exact_mode(fg, gpu_ok):
     """Bins no larger than the target cells (the caller's mean cell size is an input): every target cell then spans four bin
     rows, lands in the per-row wide lists four times and the single-sync search's record buffer (3 per target cell) is too
