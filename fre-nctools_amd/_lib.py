@@ -40,7 +40,7 @@ EXPORTS = [
     "fg_c2l_create", "fg_c2l_destroy", "fg_c2l_ncells", "fg_c2l_halo_size", "fg_c2l_set_stream", "fg_c2l_sync",
     "fg_c2l_get_centres", "fg_c2l_fill_halo", "fg_c2l_gradient", "fg_c2l_gradient_records", "fg_c2l_records", "fg_c2l_grid_info", "fg_find_contacts", "fg_halo_map",
     "fg_gnomonic_ed_grid", "fg_tripolar_corners", "fg_remap_write", "fg_remap_write_interp", "fg_remap_read_size", "fg_remap_read", "fg_remap_last_error",
-    "fg_plan_ncells_out", "fg_plan_order", "fg_plan_device", "fg_dev_alloc", "fg_dev_free", "fg_dev_upload", "fg_dev_download",
+    "fg_plan_trim", "fg_plan_ncells_out", "fg_plan_order", "fg_plan_device", "fg_dev_alloc", "fg_dev_free", "fg_dev_upload", "fg_dev_download",
     "fg_nc_open", "fg_nc_create", "fg_nc_def_dim", "fg_nc_def_var", "fg_nc_put_att_text", "fg_nc_put_att_double", "fg_nc_enddef",
     "fg_nc_inq_ndims", "fg_nc_inq_nvars", "fg_nc_inq_numrecs", "fg_nc_inq_dimid", "fg_nc_inq_dim", "fg_nc_inq_varid", "fg_nc_inq_var",
     "fg_nc_get_att_double", "fg_nc_get_att_text", "fg_nc_get_vara", "fg_nc_get_vara_double", "fg_nc_put_vara", "fg_nc_put_vara_double",

@@ -384,10 +384,20 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
     const int nv = d_cell_record(tiles + ntiles, 1, ndst, D, err, d0, vtile, box, &tl);
     d_bin_insert<false>(d < ndst && nv != 0, d, box[0], box[1], box[2], box[3], box[4], b, slot_cnt, nullptr, nullptr, 0);
     if (band_keys) {                                    // latitude range of the destination cells, for the culling of a later launch
+      // one pair of atomics per BLOCK, and only when it would change the value: thousands of same-address atomics serialise
+      // at ~12 ns each (a wave-level version of this cost the kernel 0.37 ms)
+      __shared__ unsigned long long sh_k[2][4];
       unsigned long long kmax = (d < ndst && nv != 0) ? d_ord_key(box[1]) : 0ull, kmin = (d < ndst && nv != 0) ? ~d_ord_key(box[0]) : 0ull;
 #pragma unroll
       for (int o = 32; o; o >>= 1) { kmax = max(kmax, __shfl_xor(kmax, o)); kmin = max(kmin, __shfl_xor(kmin, o)); }
-      if ((threadIdx.x & 63) == 0 && kmax) { atomicMax(&band_keys[0], kmax); atomicMax(&band_keys[1], kmin); }
+      if ((threadIdx.x & 63) == 0) { sh_k[0][threadIdx.x >> 6] = kmax; sh_k[1][threadIdx.x >> 6] = kmin; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        kmax = max(max(sh_k[0][0], sh_k[0][1]), max(sh_k[0][2], sh_k[0][3]));
+        kmin = max(max(sh_k[1][0], sh_k[1][1]), max(sh_k[1][2], sh_k[1][3]));
+        if (kmax > __hip_atomic_load(&band_keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&band_keys[0], kmax);
+        if (kmin > __hip_atomic_load(&band_keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&band_keys[1], kmin);
+      }
     }
   }
 }

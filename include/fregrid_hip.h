@@ -150,6 +150,9 @@ void fg_dev_free(void *p);
 int  fg_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
 int  fg_dev_download(void *dst_host, const void *src_dev, size_t bytes);
 
+/* Give back the surplus of the capacity-sized exchange-cell arrays (8*max(nsrc, ndst) entries -> nxgrid entries; device-to-device
+ * copies).  For callers that keep many plans resident.  Any state after the search. */
+int  fg_plan_trim(fg_plan *plan);
 long fg_plan_nxgrid(const fg_plan *plan);
 long fg_plan_ncells_in(const fg_plan *plan);      /* sum over source tiles of nx*ny */
 long fg_plan_ncells_out(const fg_plan *plan);     /* nx_out*ny_out */

@@ -6,6 +6,7 @@ sys.path.insert(0, root)
 import numpy as np, torch
 import __graft_entry__ as ge
 fg = ge.load_package()
+fg.lib().fg_set_search_cull(int(os.environ.get("FG_CULL", "0")))
 ni, nlon, nlat = 384, 1440, 720
 lon, lat = fg.gnomonic_ed_corners(ni); lo, la = fg.latlon_corners(nlon, nlat)
 dev = "cuda:0"

@@ -422,6 +422,33 @@ def test_source_cell_culling_keeps_the_plan(fg, gpu_ok):
         assert live[s].all()                                                            # every cell with exchange cells was kept
 
 
+def test_plan_trim_keeps_the_plan(fg, gpu_ok):
+    """fg_plan_trim re-allocates the capacity-sized exchange-cell arrays at nxgrid entries: before or after
+    fg_plan_finalize, the exchange cells and the sweep are unchanged."""
+    import torch
+    ni, nlon, nlat = 16, 48, 24
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    src = torch.from_numpy(np.random.default_rng(5).standard_normal((3, 6 * ni * ni))).to("cuda:0")
+    outs, xs = [], []
+    for when in ("never", "before", "after"):
+        p = fg.XgridPlan.create(1, grids, fg.GridConfig(nlon, nlat, lo, la))
+        if when == "before":
+            assert fg.lib().fg_plan_trim(p._h) == 0
+        p.finalize()
+        if when == "after":
+            assert fg.lib().fg_plan_trim(p._h) == 0
+        out = torch.empty(3, nlon * nlat, dtype=torch.float64, device="cuda:0")
+        p.apply(src, out, nz=3); p.sync()
+        outs.append(out.cpu().numpy()); xs.append(p.get_xgrid())
+        p.destroy()
+    for o, x in zip(outs[1:], xs[1:]):
+        assert np.array_equal(o, outs[0])
+        for k in ("t_in", "i_in", "j_in", "i_out", "j_out", "area"):
+            assert np.array_equal(x[k], xs[0][k])
+
+
 def test_bin_record_overflow_falls_back_to_exact_mode(fg, gpu_ok):
     """Bins no larger than the target cells (the caller's mean cell size is an input): every target cell then spans four bin
     rows, lands in the per-row wide lists four times and the single-sync search's record buffer (3 per target cell) is too
