@@ -16,7 +16,7 @@
 //
 // Bit-faithfulness: every double operation has the reference's expression tree (-ffp-contract=off); the extended
 // precision solve runs on the software x87 of fp80.h; acosl is fp80.h's fg_acosl.  Compaction into the canonical
-// order (source cell, destination index) is the legacy path's k_scatter_xcells.
+// order (source cell, destination index) is the legacy path's k_compact (xgrid_kernels.hip).
 #include "xgrid_device.h"
 #include "fp80.h"
 

@@ -609,7 +609,9 @@ __global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCel
       const SrcQuery q = d_src_query(lat_in_min, lat_in_max, lon_in_min, lon_in_max, b);
       const int cnt = d_heavy_scan<false>(q, b, slot_start, entries, ecap, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg,
                                           s, nullptr, nullptr, 0, 0);
-      const int r = s % ps.nreg;                          // by cell, not by list position: the list order varies from run to run
+      // region by a hash of the cell number -- not by list position (the list order varies from run to run), and not s % nreg
+      // (the cells around a pole share a few residues when the tile width is a multiple of nreg: 20 regions took all their pairs)
+      const int r = (int)(((unsigned)s * 2654435761u >> 12) % (unsigned)ps.nreg);
       unsigned base = 0;
       if (lane == 0 && cnt) base = atomicAdd(&ps.fill[r * FG_FILL_STRIDE], (unsigned)cnt);
       base = __shfl(base, 0);
@@ -647,7 +649,9 @@ __global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCel
   const unsigned incl = wave_incl_scan((unsigned)cnt, lane);
   const unsigned total = __shfl(incl, 63);
   const unsigned excl = incl - (unsigned)cnt;
-  const int r = (bR / CAND_CHUNK) % ps.nreg;           // 256 consecutive cells share a region: neighbouring pairs stay neighbours for the clip
+  // region by a hash of the wave's number: plain round robin leaves whole residue classes to the dense cells around a pole when
+  // the tile width is a multiple of the region count (the great-circle search then overflowed a region and was repeated)
+  const int r = (int)((((unsigned)(bR / CAND_CHUNK)) * 2654435761u >> 12) % (unsigned)ps.nreg);
   unsigned base = 0;
   if (lane == 0 && total) base = atomicAdd(&ps.fill[r * FG_FILL_STRIDE], total);
   base = __shfl(base, 0);

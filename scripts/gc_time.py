@@ -23,11 +23,11 @@ torch.cuda.synchronize()
 fg.lib().fg_set_profiling(1)
 for rep in range(3):
     t2 = time.time()
-    plan = fg.XgridPlan.create_great_circle_dev([ni] * 6, [ni] * 6, xin, nlon, nlat, xout)
+    plan = fg.XgridPlan.create_great_circle_dev([ni] * 6, [ni] * 6, xin, nlon, nlat, xout, np.pi / nlat, 2 * np.pi / nlon)
     plan.finalize()
     plan.sync()
     t3 = time.time()
-    print(f"rep {rep}: search+finalize {1e3 * (t3 - t2):.2f} ms, nxgrid {plan.nxgrid}, phases {plan.phase_ms()}", flush=True)
+    print(f"rep {rep}: search+finalize {1e3 * (t3 - t2):.2f} ms, nxgrid {plan.nxgrid}, exact_mode {plan.stats()['exact_mode']}, phases {plan.phase_ms()}", flush=True)
     if rep < 2:
         plan.destroy()
 st = plan.stats()
