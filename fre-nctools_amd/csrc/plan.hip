@@ -1181,7 +1181,7 @@ extern "C" int fg_plan_set_xgrid(fg_plan *pl, long nxgrid, const int *t_in, cons
 extern int g_apply_vec;
 
 extern int g_apply_xcd;
-extern "C" void fg_set_apply_xcd(int on) { g_apply_xcd = on ? 1 : 0; }       // tuning hook: XCD-banded row mapping of the sweep
+extern "C" void fg_set_apply_xcd(int on) { g_apply_xcd = on < 0 ? 0 : on; }       // tuning hook: tile -> XCD mapping of the sweep (0 identity, 1 banded, C >= 2 chunked)
 extern "C" void fg_set_apply_vec(int v) { g_apply_vec = (v >= 4) ? 4 : (v >= 2 ? 2 : (v == 1 ? 1 : 0)); }   // tuning hook (scripts/)
 
 static int ensure_il_scratch(fg_plan *pl, bool want_rs)

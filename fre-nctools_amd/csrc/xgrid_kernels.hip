@@ -360,10 +360,33 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
   __shared__ double vtile[256 * 17];
   __shared__ FgTile sh_tiles[FG_TILESET_MAX];
   if (ts.n && (int)threadIdx.x < ts.n) sh_tiles[threadIdx.x] = ts.t[threadIdx.x];
+  const bool isD = (int)blockIdx.x >= nbS;
+  if (cull && !isD && band_keys[0]) {
+    // a rank of a banded job: most source blocks lie wholly outside the band -- find that out from the corner latitudes alone
+    // and leave before the trig table is loaded (nv = 0 is all the later kernels look at)
+    __syncthreads();
+    const FgTile *tl0 = ts.n ? sh_tiles : tiles_in;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (s < nsrc) {
+      int t = 0;
+      while (t + 1 < ntiles && s >= tl0[t + 1].cell_off) t++;
+      const int loc = s - tl0[t].cell_off, i = loc % tl0[t].nx, j = loc / tl0[t].nx, nxp = tl0[t].nx + 1;
+      const int n0 = j * nxp + i;
+      const double y0 = tl0[t].lat[n0], y1 = tl0[t].lat[n0 + 1], y2 = tl0[t].lat[n0 + nxp + 1], y3 = tl0[t].lat[n0 + nxp];
+      const double lmin = fmin(fmin(y0, y1), fmin(y2, y3)), lmax = fmax(fmax(y0, y1), fmax(y2, y3));
+      const double bmax = d_ord_val(band_keys[0]), bmin = d_ord_val(~band_keys[1]);
+      keep = !((lmax <= bmin) || (lmin >= bmax)) || !(lmin == lmin);        // NaN goes on to the full path (it reports the error)
+    }
+    if (!__syncthreads_or(keep)) {
+      if (s < nsrc) { S.nv[s] = 0; S.area[s] = 0; if (sums) { sums[s] = 0.0; sums[nsrc + s] = 0.0; sums[2 * (size_t)nsrc + s] = 0.0; } }
+      if (ts.n && blockIdx.x == 0 && (int)threadIdx.x < ts.n) tiles_out[threadIdx.x] = sh_tiles[threadIdx.x];
+      return;
+    }
+  }
   d_load_trig_table();                                   // (barrier inside)
   const FgTile *tiles = ts.n ? sh_tiles : tiles_in;
   if (ts.n && blockIdx.x == 0 && (int)threadIdx.x < ts.n) tiles_out[threadIdx.x] = sh_tiles[threadIdx.x];
-  const bool isD = (int)blockIdx.x >= nbS;
   double box[5] = {0, 0, 0, 0, 0};
   int tl = 0;
   if (!isD) {
@@ -827,6 +850,10 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCe
                                                             unsigned long long *stats, unsigned *err)
 {
   __shared__ double2 sh_poly[8][CLIP_THREADS];
+  {                                                   // the launch covers the regions' CAPACITY: blocks beyond a region's fill leave at once
+    const unsigned first = blockIdx.x * CLIP_THREADS, r = first / (unsigned)ps.regcap;
+    if (first - r * (unsigned)ps.regcap >= ps.fill[r * FG_FILL_STRIDE]) return;
+  }
   d_load_trig_table();
   const int tid = threadIdx.x, lane = tid & 63;
   const int p = blockIdx.x * CLIP_THREADS + tid;

@@ -307,8 +307,9 @@ void fg_set_search_chunks(int chunks);
  * rank of a banded multi-GPU job meets a fraction of the source cells); fg_plan_get_cell_area / _cell_struct then return 0 /
  * unspecified values for those cells.  The exchange cells are unchanged.  Default 0. */
 void fg_set_search_cull(int on);
-/* Sweep tuning hook: 1 = each XCD sweeps one contiguous band of destination rows (measured slower on MI355X, see
- * csrc/apply_kernels.hip); 0 (default) = blocks in row order.  Results do not depend on it. */
+/* Sweep tuning hook, the tile -> XCD mapping: 0 = blocks in row order; 1 = each XCD sweeps one contiguous band of
+ * destination rows (measured slower); C >= 2 = chunks of C consecutive tiles per XCD, chunks dealt round-robin (default 64,
+ * see csrc/apply_kernels.hip).  Results do not depend on it. */
 void fg_set_apply_xcd(int on);
 
 /* Batched polygon primitives on the device.  Polygons are rows of host arrays [npoly][24];

@@ -21,7 +21,7 @@ for nb in (8, 16):
     data = h2d(rng.standard_normal((6 * (ni + 2) ** 2, nb))); gx = h2d(rng.standard_normal((ncell, nb))); gy = h2d(rng.standard_normal((ncell, nb)))
     out = torch.empty(nlon * nlat, nb, dtype=torch.float64, device=dev)
     rec = h2d(rng.standard_normal((ncell, 3, 8))); outl = torch.empty(8, nlon * nlat, dtype=torch.float64, device=dev)
-    for xcd in (0, 1, 0, 1):
+    for xcd in (0, 1, 32, 64, 128, 256, 0, 128):
         L.fg_set_apply_xcd(xcd)
         for name, fn in (("il", lambda: p.apply_interleaved(nb, data, out, gx, gy)), ("rec", lambda: p.apply_records(8, rec, outl))):
             if name == "rec" and nb != 8: continue
@@ -34,6 +34,7 @@ for nb in (8, 16):
 for k, v in sorted(res.items()): print(k, ["%.4f" % x for x in v])
 # same bits either way
 L.fg_set_apply_xcd(0); p.apply_records(8, rec, outl); p.sync(); a = outl.clone()
-L.fg_set_apply_xcd(1); p.apply_records(8, rec, outl); p.sync()
+L.fg_set_apply_xcd(1); p.apply_records(8, rec, outl); p.sync(); b1 = outl.clone()
+L.fg_set_apply_xcd(64); p.apply_records(8, rec, outl); p.sync()
 print("bitwise equal:", bool(torch.equal(a, outl)))
-L.fg_set_apply_xcd(0)
+L.fg_set_apply_xcd(64)

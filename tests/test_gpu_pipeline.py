@@ -449,6 +449,32 @@ def test_plan_trim_keeps_the_plan(fg, gpu_ok):
             assert np.array_equal(x[k], xs[0][k])
 
 
+def test_sweep_tile_mapping_keeps_the_bits(fg, gpu_ok):
+    """fg_set_apply_xcd: identity, one band per XCD, and chunked tile -> XCD mappings (chunk sizes that divide the grid and
+    that leave a tail) are permutations of the tiles: the sweep's output is bitwise the same for each."""
+    import torch
+    ni, nlon, nlat = 48, 360, 180
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    p = fg.XgridPlan.create(1, grids, fg.GridConfig(nlon, nlat, lo, la))
+    p.finalize()
+    src = torch.from_numpy(np.random.default_rng(11).standard_normal((8, 6 * ni * ni))).to("cuda:0")
+    outs = []
+    try:
+        for mode in (0, 1, 2, 3, 7, 64, 1000):
+            fg.lib().fg_set_apply_xcd(mode)
+            out = torch.full((8, nlon * nlat), np.nan, dtype=torch.float64, device="cuda:0")
+            p.apply(src, out, nz=8); p.sync()
+            outs.append(out.cpu().numpy())
+    finally:
+        fg.lib().fg_set_apply_xcd(64)
+        p.destroy()
+    assert np.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
 def test_bin_record_overflow_falls_back_to_exact_mode(fg, gpu_ok):
     """Bins no larger than the target cells (the caller's mean cell size is an input): every target cell then spans four bin
     rows, lands in the per-row wide lists four times and the single-sync search's record buffer (3 per target cell) is too
