@@ -19,6 +19,7 @@
 // order (source cell, destination index) is the legacy path's k_compact (xgrid_kernels.hip).
 #include "xgrid_device.h"
 #include "fp80.h"
+#include <algorithm>
 
 #define GC_EPSLN8 (1.e-8)
 #define GC_EPSLN10 (1.e-10)
@@ -831,6 +832,400 @@ __global__ __launch_bounds__(64) void k_gc_clip_slow(const int *defer_list, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------ split clip
+// k_gc_clip spends its time in three places (C384 -> 0.25 deg, 9.1 ms: 2.3 ms in the 32 angle sums of the inside tests, 3.8 ms
+// in a per-lane loop over the extended-precision solves -- a wave runs max-over-lanes = 5.7 of them for 3.0 on average --
+// and 2.3 ms in the walk and the area, all of it behind ~1 KB per lane of dynamically indexed tables in scratch).  The
+// ordinary pair -- two plainly convex quads with four distinct corners each and no intersection on or next to a corner --
+// goes through three passes instead:
+//   k_gc_screen   lane per pair.  Eight edge normals and 32 point-against-plane dot products decide (a) the isInside flag of
+//                 each corner whenever the corner is clear of every edge plane of the other cell by sin > 1e-6 (the angle sum
+//                 of insidePolygon is then 2 pi to ~1e-10, or short of it by > 2e-6; the 1e-8 test cannot go the other way);
+//                 a corner closer than that gets the reference's angle sum; (b) the edge pairs that certainly do not
+//                 cross (the screen of gc_clip_fast on the same dot products).  One task per remaining edge pair.
+//   k_gc_solve    lane per task: line_intersect_2D_3D on the software x87, nothing else; no divergence between pairs.
+//   k_gc_walk     lane per pair: the reference's list insertions and walk as index logic on packed lists (no corner is ever
+//                 rewritten, so "find by coordinate value" is "find by identity"), output polygon in LDS, area.
+// Everything else -- a cell with coincident corners (pole cells), very large or very small cells, an intersection that snaps
+// onto a corner (u = 0 or 1: the reference rewrites the corner and later solves see the new coordinates) or lies within 1e-6
+// of one, more than 8 intersections, any of the walk's fatal checks -- is put on a list and redone from scratch by the
+// one-kernel version above (k_gc_clip_list), which also reports the errors.
+#define GC_SIN2_CLEAR 1.e-12
+#define GC_WALK_PTS 8      // output polygon of k_gc_walk (convex x convex); a ninth point sends the pair to the list
+
+__device__ __forceinline__ double gc_dot(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// insidePolygon (mosaic_util.c:1546-1589) of the corner pnt0 against the four corners q, both read from the cell records in
+// memory; the arithmetic of gcf_inside.  -1: too close to the 1e-8 threshold for the fast acos (the one-kernel clip redoes the pair)
+__device__ int gc_inside4(const double *pnt0g, const double *q)
+{
+  const double pnt0[3] = {pnt0g[0], pnt0g[1], pnt0g[2]};
+  double anglesum = 0;
+  for (int k = 0; k < 4; k++) {
+    const int kn = (k + 1) & 3;
+    const double q1[3] = {q[k * 3], q[k * 3 + 1], q[k * 3 + 2]}, q2[3] = {q[kn * 3], q[kn * 3 + 1], q[kn * 3 + 2]};
+    if (gc_same_point(pnt0[0], pnt0[1], pnt0[2], q1[0], q1[1], q1[2])) return 1;
+    anglesum += gc_spherical_angle<false>(pnt0, q2, q1);
+  }
+  const double dev = fabs(anglesum - 2 * GC_PI);
+  if (fabs(dev - GC_EPSLN8) < 1.e-12) return -1;
+  return dev < GC_EPSLN8;
+}
+
+// The four corners p against the four edge planes of q.  false: q is not a plainly convex quad.
+//   in_bits / out_bits  per corner of p: inside every / outside some half-space of q by more than the clearance
+//   miss                bit (edge of the source cell * 4 + edge of the destination cell): edge i of p meets the plane of edge e of
+//                       q at a parameter outside [-1e-5, 1 + 1e-5] (gc_screen_out: t = n.l1 / (n.l1 - n.l2), n = q_e x q_e+1)
+// The dot products carry an absolute error of ~1e-15, so a parameter is only trusted when |det| > 1e-8 as well.
+template <bool SWAP>
+__device__ __forceinline__ bool gc_half_screen(const double *p, const double *q, const double *plen2, const double *qlen2,
+                                               unsigned &in_bits, unsigned &out_bits, unsigned &miss)
+{
+  in_bits = 15u; out_bits = 0; miss = 0;
+  double sigma = 1.0;
+  bool convex = true;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    double n[3];
+    gc_cross(q + e * 3, q + ((e + 1) & 3) * 3, n);
+    const double nn = gc_dot(n, n);
+    const double c2 = gc_dot(n, q + ((e + 2) & 3) * 3), c3 = gc_dot(n, q + ((e + 3) & 3) * 3);
+    if (e == 0) sigma = (c2 > 0) ? 1.0 : -1.0;
+    if (!(c2 * sigma > 1.e-14 && c3 * sigma > 1.e-14)) convex = false;
+    double raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) raw[k] = gc_dot(n, p + k * 3);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool clear = raw[k] * raw[k] > GC_SIN2_CLEAR * nn;
+      const double sd = raw[k] * sigma;
+      if (!(clear && sd > 0)) in_bits &= ~(1u << k);
+      if (clear && sd < 0) out_bits |= 1u << k;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double det = raw[i] - raw[(i + 1) & 3];
+      const double n1 = plen2[i], n2 = qlen2[e];
+      if (n1 > 1.e-8 && n2 > 1.e-8 && det * det > 1.e-6 * n1 * n2 && fabs(det) > 1.e-8) {
+        const double r = (det > 0) ? raw[i] : -raw[i], ad = fabs(det);                 // td = r / ad outside [-1e-5, 1 + 1e-5]
+        if (r < -1.e-5 * ad || r > (1.0 + 1.e-5) * ad) miss |= 1u << (SWAP ? e * 4 + i : i * 4 + e);
+      }
+    }
+  }
+  return convex;
+}
+
+// four distinct corners, edges longer than 3e-5 rad; len2[e] = |v_e - v_e+1|^2
+__device__ __forceinline__ bool gc_plain_quad(const double *v, double *len2)
+{
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int kn = (k + 1) & 3;
+    const double ex = v[k * 3] - v[kn * 3], ey = v[k * 3 + 1] - v[kn * 3 + 1], ez = v[k * 3 + 2] - v[kn * 3 + 2];
+    len2[k] = ex * ex + ey * ey + ez * ez;
+    if (!(len2[k] > 1.e-9)) ok = false;
+  }
+  if (gc_same_point(v[0], v[1], v[2], v[6], v[7], v[8]) || gc_same_point(v[3], v[4], v[5], v[9], v[10], v[11])) ok = false;   // the diagonals
+  return ok;
+}
+
+__global__ __launch_bounds__(64) void k_gc_screen(FgPairSpace ps, FgCells S, FgCells D, GcSplit g, unsigned *err)
+{
+  const unsigned first = blockIdx.x * 64u, reg = first / (unsigned)ps.regcap;
+  if (first - reg * (unsigned)ps.regcap >= ps.fill[reg * FG_FILL_STRIDE]) return;          // block beyond its region's fill
+  const int lane = threadIdx.x, p = (int)first + lane;
+  const bool live = d_pair_live(ps, p);
+  unsigned meta = 0;
+  bool defer = false, valid = false;
+  if (live) {
+    const int s = ps.src[p], d = ps.dst[p];
+    double a[16], b[16];
+    {
+      const double *ga = S.verts + (size_t)s * 16, *gb = D.verts + (size_t)d * 16;
+#pragma unroll
+      for (int k = 0; k < 16; k++) { a[k] = ga[k]; b[k] = gb[k]; }
+    }
+    if (!gc_prefilter(a, b, S.area[s], D.area[d], err)) ps.dst[p] = -1;
+    else {
+      double la[4], lb[4];
+      bool plain = gc_plain_quad(a, la);
+      plain = gc_plain_quad(b, lb) && plain;
+      plain = plain && a[15] >= 0.97 && b[15] >= 0.97;                      // cap radii <= 0.245: every distance in the pair < 1 rad
+      unsigned in_a, out_a, miss_a, in_b, out_b, miss_b;
+      const bool cvx_b = gc_half_screen<false>(a, b, la, lb, in_a, out_a, miss_a);      // corners of a, edges of b
+      const bool cvx_a = gc_half_screen<true>(b, a, lb, la, in_b, out_b, miss_b);
+      if (!(plain && cvx_a && cvx_b)) defer = true;
+      else {
+        // corners near an edge plane: k_gc_walk takes their angle sums
+        meta = (~(miss_a | miss_b) & 0xffffu) | (in_a << 16) | (in_b << 20) | ((~(in_a | out_a) & 15u) << 24) | ((~(in_b | out_b) & 15u) << 28);
+        valid = true;
+      }
+    }
+  }
+  // tasks: one atomic per wave
+  int cnt = __popc(meta & 0xffffu), incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+  const int total = __shfl(incl, 63);
+  // (a single counter would serialise 100 000 same-address atomics, ~12 ns each: the task space is cut into regions like the pair list)
+  const unsigned treg = (blockIdx.x * 2654435761u >> 12) % FG_NREG;
+  unsigned wbase = 0;
+  if (lane == 0 && total) wbase = atomicAdd(&g.ntask[treg * FG_FILL_STRIDE], (unsigned)total);
+  wbase = __shfl(wbase, 0);
+  const unsigned local = wbase + (unsigned)(incl - cnt), base = treg * g.tcap + local;
+  if (!live) return;
+  // every slot below min(ntask[r], tcap) of a region holds a well-formed task, also those of a pair that did not fit and goes to the list
+  unsigned need = meta & 0xffffu, t = local;
+  while (need) { const int bit = __ffs((int)need) - 1; need &= need - 1; if (t < g.tcap) g.task[treg * g.tcap + t] = ((unsigned)p << 4) | (unsigned)bit; t++; }
+  if (cnt && local + (unsigned)cnt > g.tcap) { defer = true; valid = false; }
+  if (defer) g.list[atomicAdd(g.list_cnt, 1)] = p;
+  g.meta[p] = meta;
+  g.tbase[p] = valid ? (int)base : -1;                     // -1: rejected, or on the list
+}
+
+__global__ __launch_bounds__(256) void k_gc_solve(FgPairSpace ps, FgCells S, FgCells D, GcSplit g)
+{
+  const unsigned n = min(g.ntask[blockIdx.y * FG_FILL_STRIDE], g.tcap);      // blockIdx.y = region of the task space
+  for (unsigned tl = blockIdx.x * 256u + threadIdx.x; tl < n; tl += gridDim.x * 256u) {
+    const unsigned t = blockIdx.y * g.tcap + tl;
+    const unsigned w = g.task[t];
+    const int p = (int)(w >> 4), i1 = (int)(w >> 2) & 3, i2 = (int)w & 3;
+    const double *A = S.verts + (size_t)ps.src[p] * 16, *B = D.verts + (size_t)ps.dst[p] * 16;
+    double a1[3], a2[3], q1[3], q2[3], q3[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      a1[c] = A[i1 * 3 + c]; a2[c] = A[((i1 + 1) & 3) * 3 + c];
+      q1[c] = B[i2 * 3 + c]; q2[c] = B[((i2 + 1) & 3) * 3 + c]; q3[c] = B[((i2 + 2) & 3) * 3 + c];
+    }
+    double I[3], u1, u2;
+    int inbound;
+    double2 r;
+    if (!gc_line_intersect(a1, a2, q1, q2, q3, I, &u1, &u2, &inbound)) { r.x = -1.0; r.y = 0.0; }
+    else if (u1 == 0 || u1 == 1 || u2 == 0 || u2 == 1) {                 // snapped onto a corner: the pair leaves the three passes
+      r.x = 2.0; r.y = 0.0;
+      if (atomicExch(&g.tbase[p], -1) >= 0) g.list[atomicAdd(g.list_cnt, 1)] = p;
+    }
+    else { r.x = u1; r.y = (inbound == 2) ? -u2 : u2; }
+    ((double2 *)g.res)[t] = r;
+  }
+}
+
+__device__ __forceinline__ double gcw_sel8(const double *a, int k)
+{
+  double v = a[0];
+#pragma unroll
+  for (int m = 1; m < 8; m++) v = (k == m) ? a[m] : v;
+  return v;
+}
+// insertIntersect (mosaic_util.c:1313-1397) for an intersection strictly inside the edge that starts at corner `vtx`;
+// iu[] = the parameters of the intersections along this list's edges
+__device__ __forceinline__ int gcw_insert(GcPacked &l, int vtx, double u_cur, int inbound, const double *iu, int iref)
+{
+  int k1 = -1;
+  for (int k = 0; k < l.n; k++) { const unsigned c = gcp_get(l, k); if (GCN_INTER(c) == 0 && (int)GCN_REF(c) == vtx) { k1 = k; break; } }
+  if (k1 < 0) return -7;
+  if (inbound == 1) {
+    int k2 = (k1 + 1 < l.n) ? k1 + 1 : 0, guard = 0;
+    while (GCN_INTER(gcp_get(l, k2))) { k2 = (k2 + 1 < l.n) ? k2 + 1 : 0; if (++guard > 32) return -7; }
+    gcp_set(l, k2, gcp_get(l, k2) & ~(1u << 6));
+  } else if (inbound == 2)
+    gcp_set(l, k1, gcp_get(l, k1) & ~(1u << 6));
+  int k2 = k1 + 1;
+  while (k2 < l.n) {
+    const unsigned c = gcp_get(l, k2);
+    if (GCN_INTER(c) == 1) { if (gcw_sel8(iu, (int)GCN_REF(c) - 4) > u_cur) break; }
+    else break;
+    k2++;
+  }
+  if (l.n >= 12) return -9;
+  gcp_insert(l, k2, (unsigned)(4 + iref) | (1u << 4) | (1u << 6));
+  return 0;
+}
+
+#define GCW_P(k, c) lds[((k) * 3 + (c)) * 64 + lane]
+// addNode of the output polygon: coordinates of the node `code` of list L, dropped if within 1e-10 of a point already there
+__device__ __forceinline__ int gcw_poly_add(double *lds, int lane, int &n, bool dedup, int L, unsigned code, const double *A, const double *B,
+                                            const double *iu0, unsigned long long imeta)
+{
+  double q[3];
+  const int r = (int)GCN_REF(code);
+  if (r < 4) {
+    const double *v = (L ? B : A) + r * 3;
+    q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+  } else {
+    const int i1 = (int)(imeta >> (6 * (r - 4))) & 3;
+    const double u = gcw_sel8(iu0, r - 4);
+    const double *a1 = A + i1 * 3, *a2 = A + ((i1 + 1) & 3) * 3;
+    q[0] = a1[0] + u * (a2[0] - a1[0]);                       // line_intersect_2D_3D, create_xgrid.c:2050-2056
+    q[1] = a1[1] + u * (a2[1] - a1[1]);
+    q[2] = a1[2] + u * (a2[2] - a1[2]);
+    const double norm = gc_metric(q);
+    q[0] /= norm; q[1] /= norm; q[2] /= norm;
+  }
+  if (dedup)
+    for (int k = 0; k < n; k++) if (gc_same_point(GCW_P(k, 0), GCW_P(k, 1), GCW_P(k, 2), q[0], q[1], q[2])) return 0;
+  if (n >= GC_WALK_PTS) return -9;
+  GCW_P(n, 0) = q[0]; GCW_P(n, 1) = q[1]; GCW_P(n, 2) = q[2];
+  n++;
+  return 0;
+}
+
+__global__ __launch_bounds__(64) void k_gc_walk(FgPairSpace ps, FgCells S, const double *mask, FgCells D, GcSplit g,
+                                                double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err)
+{
+  __shared__ double lds[GC_WALK_PTS * 3 * 64];
+  const unsigned first = blockIdx.x * 64u, reg = first / (unsigned)ps.regcap;
+  if (first - reg * (unsigned)ps.regcap >= ps.fill[reg * FG_FILL_STRIDE]) return;
+  const int lane = threadIdx.x, p = (int)first + lane;
+  if (!d_pair_live(ps, p)) return;
+  const int d = ps.dst[p];
+  if (d < 0) return;
+  const int t0 = g.tbase[p];
+  if (t0 < 0) return;                                      // on the list
+  unsigned meta = g.meta[p];
+  const int s = ps.src[p];
+  const double *A = S.verts + (size_t)s * 16, *B = D.verts + (size_t)d * 16;
+  bool bad = false;
+  for (unsigned edge = meta >> 24; edge; edge &= edge - 1) {             // corners near an edge plane of the other cell
+    const int bit = __ffs((int)edge) - 1;
+    const int in = (bit < 4) ? gc_inside4(A + bit * 3, B) : gc_inside4(B + (bit - 4) * 3, A);
+    if (in < 0) bad = true;
+    if (in > 0) meta |= 1u << (16 + bit);
+  }
+
+  GcPacked gl0, gl1;                                       // (two named values: a list indexed by L would live in scratch)
+  gl0.bits = 0; gl0.n = 4; gl1.bits = 0; gl1.n = 4;
+  for (int k = 0; k < 4; k++) {
+    gl0.bits |= (gc_u128)((unsigned)k | (((meta >> (16 + k)) & 1u) << 6)) << (8 * k);
+    gl1.bits |= (gc_u128)((unsigned)k | (((meta >> (20 + k)) & 1u) << 6)) << (8 * k);
+  }
+  double iu0[8], iu1[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { iu0[k] = -1.0; iu1[k] = -1.0; }
+  unsigned long long imeta = 0;                            // per intersection: i1 | i2 << 2 | inbound << 4
+  int nil = 0;
+  {
+    unsigned need = meta & 0xffffu;
+    int t = t0;
+    while (need && !bad) {
+      const int bit = __ffs((int)need) - 1;
+      need &= need - 1;
+      const double2 r = ((const double2 *)g.res)[t++];
+      if (r.x < 0) continue;
+      const double u1 = r.x, u2 = fabs(r.y);
+      if (u1 > 1.5 || u1 < 1.e-6 || u1 > 1.0 - 1.e-6 || u2 < 1.e-6 || u2 > 1.0 - 1.e-6) { bad = true; break; }
+      const int inbound = (r.y < 0) ? 2 : 1, i1 = bit >> 2, i2 = bit & 3;
+      bool dup = false;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int m = (int)(imeta >> (6 * k));
+        if (k < nil && ((iu0[k] == u1 && (m & 3) == i1) || (iu1[k] == u2 && ((m >> 2) & 3) == i2))) dup = true;
+      }
+      if (dup) continue;
+      if (nil >= 8) { bad = true; break; }
+      const int iref = nil++;
+#pragma unroll
+      for (int k = 0; k < 8; k++) { if (k == iref) { iu0[k] = u1; iu1[k] = u2; } }
+      imeta |= (unsigned long long)(i1 | (i2 << 2) | (inbound << 4)) << (6 * iref);
+      if (gcw_insert(gl0, i1, u1, inbound, iu0, iref) || gcw_insert(gl1, i2, u2, 0, iu1, iref)) bad = true;
+    }
+  }
+
+  int n_out = 0;
+  if (!bad) {
+    int nintersect = nil, firstx = -1;
+    if (nintersect > 1) for (int k = 0; k < nil; k++) if (((imeta >> (6 * k + 4)) & 3u) == 2u) { firstx = k; break; }
+    if (firstx >= 0) {
+      const int maxiter1 = nintersect;
+      int np = 0;
+      gcw_poly_add(lds, lane, np, false, 0, (unsigned)(4 + firstx) | (1u << 4), A, B, iu0, imeta);
+      nintersect--;
+      int L = 0, iter1 = 0, found1 = 0, found2 = 0, cur = firstx;
+      unsigned ccode = 0;
+      while (iter1 < maxiter1 && !bad) {
+        const GcPacked lw = L ? gl1 : gl0;                 // the walk only reads the lists
+        int k1 = -1;
+        for (int k = 0; k < lw.n; k++) { const unsigned c = gcp_get(lw, k); if (GCN_INTER(c) == 1 && (int)GCN_REF(c) - 4 == cur) { k1 = k; break; } }
+        if (k1 < 0) { bad = true; break; }
+        int k2 = (k1 + 1 < lw.n) ? k1 + 1 : 0;
+        const int maxiter2 = lw.n;
+        int iter2 = 0;
+        found2 = 0;
+        while (iter2 < maxiter2) {
+          int t2_is_inter = 0;
+          const unsigned c2 = gcp_get(lw, k2);
+          if (GCN_INTER(c2)) {
+            if ((int)GCN_REF(c2) - 4 == firstx) { found1 = 1; break; }
+            const unsigned c3 = gcp_get(lw, (k2 + 1 < lw.n) ? k2 + 1 : 0);
+            found2 = 1;
+            t2_is_inter = 1;
+            if (GCN_INTER(c3) || GCN_INSIDE(c3) == 1) found2 = 0;
+          }
+          if (found2) { cur = (int)GCN_REF(c2) - 4; ccode = c2; break; }
+          if (gcw_poly_add(lds, lane, np, true, L, c2, A, B, iu0, imeta)) { bad = true; break; }
+          if (t2_is_inter) nintersect--;
+          k2 = (k2 + 1 < lw.n) ? k2 + 1 : 0;
+          iter2++;
+        }
+        if (bad || found1) break;
+        if (!found2) { bad = true; break; }
+        if (gcw_poly_add(lds, lane, np, true, L, ccode, A, B, iu0, imeta)) { bad = true; break; }
+        nintersect--;
+        L = 1 - L;
+        iter1++;
+      }
+      if (!found1 || nintersect > 0) bad = true;
+      n_out = (np < 3) ? 0 : np;
+    }
+    if (!bad && n_out == 0) {
+#pragma unroll
+      for (int L = 0; L < 2; L++) {                        // grid1 inside grid2 (:1839-1870), then grid2 inside grid1 (:1873-1904)
+        const GcPacked lw = L ? gl1 : gl0;
+        int nin = 0;
+        for (int k = 0; k < lw.n; k++) { const unsigned c = gcp_get(lw, k); if (GCN_INTER(c) != 1 && GCN_INSIDE(c) == 1) nin++; }
+        if (n_out == 0 && nin == 4) {
+          int np = 0;
+          for (int k = 0; k < 4; k++) gcw_poly_add(lds, lane, np, false, L, gcp_get(lw, k), A, B, iu0, imeta);
+          n_out = 4;
+        }
+      }
+    }
+  }
+  if (bad) { g.list[g.list_cap - 1 - atomicAdd(g.list2_cnt, 1)] = p; return; }
+  if (n_out == 0) { ps.dst[p] = -1; return; }
+  double sum = 0.0;                                        // great_circle_area, mosaic_util.c:763-787
+  for (int i = 0; i < n_out; i++) {
+    const int i1 = (i + 1 < n_out) ? i + 1 : 0, i2 = (i1 + 1 < n_out) ? i1 + 1 : 0;
+    const double p0[3] = {GCW_P(i, 0), GCW_P(i, 1), GCW_P(i, 2)}, p1[3] = {GCW_P(i1, 0), GCW_P(i1, 1), GCW_P(i1, 2)},
+                 p2[3] = {GCW_P(i2, 0), GCW_P(i2, 1), GCW_P(i2, 2)};
+    sum += gc_spherical_angle<true>(p1, p2, p0);
+  }
+  const double area1 = S.area[s], area2 = D.area[d];
+  const double xarea = (sum - (n_out - 2.) * GC_PI) * GC_RADIUS * GC_RADIUS * (mask ? mask[s] : 1.0);
+  const double min_area = (area1 < area2) ? area1 : area2;
+  const double ratio = xarea / min_area;
+  if (fabs(ratio - 1.e-6) < 1.e-12) atomicAdd(&stats[FG_STAT_BORDERLINE], 1ull);
+  if (ratio > 1.e-6) { tmp_area[p] = xarea; atomicAdd(&nacc[s], 1); }
+  else { ps.dst[p] = -1; atomicAdd(&stats[FG_STAT_BELOW], 1ull); }
+}
+
+// the listed pairs: the one-kernel version (prefilter passed in k_gc_screen), entries list[q * stride]
+__global__ __launch_bounds__(64) void k_gc_clip_list(const int *list, int stride, const int *list_cnt, FgPairSpace ps, FgCells S, const double *mask,
+                                                     FgCells D, double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err)
+{
+  const int nl = *list_cnt;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nl; q += gridDim.x * blockDim.x) {
+    const int p = list[(long)q * stride];
+    const int s = ps.src[p], d = ps.dst[p];
+    const double *a = S.verts + (size_t)s * 16, *b = D.verts + (size_t)d * 16;
+    GcPoly out;
+    int n_out = gc_clip_fast(a, b, &out.p[0][0]);
+    if (n_out == GC_FALLBACK) n_out = gc_clip(a, b, out);
+    gc_finish(p, s, n_out, &out.p[0][0], mask ? mask[s] : 1.0, S.area[s], D.area[d], ps.dst, tmp_area, nacc, stats, err);
+  }
+}
+
 static inline int gc_nblk(long n, int t) { return (int)((n + t - 1) / t); }
 
 void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st)
@@ -845,6 +1240,30 @@ void fgd_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
   if (np <= 0) return;
   k_gc_clip<<<gc_nblk(np, 64), 64, 0, st>>>(ps, S, mask, D, tmp_area, nacc, defer_list, defer_cnt, stats, err);
   k_gc_clip_slow<<<64, 64, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, nacc, stats, err);
+}
+
+// the three-pass version; g.list doubles as the defer list of the one-kernel version when the split cannot be used.
+// st2 / e1 / e2 (may be null): the listed pairs -- a few latency-bound waves, 0.55 ms at C384 -> 0.25 deg -- run on st2 beside
+// k_gc_walk; st has waited for them when this returns.
+void fgd_gc_clip_split(FgPairSpace ps, FgCells S, const double *mask, FgCells D, double *tmp_area, int *nacc, GcSplit g,
+                       unsigned long long *stats, unsigned *err, hipStream_t st, hipStream_t st2, hipEvent_t e1, hipEvent_t e2)
+{
+  const long np = fgd_pairs_total(ps);
+  if (np <= 0) return;
+  if (np >= (1L << 28) || !g.task) {                      // a task word holds a 28-bit pair index
+    fgd_gc_clip(ps, S, mask, D, tmp_area, nacc, g.list, g.list_cnt, stats, err, st);
+    return;
+  }
+  const bool two = st2 && e1 && e2;
+  k_gc_screen<<<gc_nblk(np, 64), 64, 0, st>>>(ps, S, D, g, err);
+  k_gc_solve<<<dim3((unsigned)std::min<long>(gc_nblk(g.tcap, 256), 256), FG_NREG), 256, 0, st>>>(ps, S, D, g);
+  hipStream_t sl = st;
+  if (two) { (void)hipEventRecord(e1, st); (void)hipStreamWaitEvent(st2, e1, 0); sl = st2; }
+  k_gc_clip_list<<<2048, 64, 0, sl>>>(g.list, 1, g.list_cnt, ps, S, mask, D, tmp_area, nacc, stats, err);
+  if (two) (void)hipEventRecord(e2, st2);
+  k_gc_walk<<<gc_nblk(np, 64), 64, 0, st>>>(ps, S, mask, D, g, tmp_area, nacc, stats, err);
+  k_gc_clip_list<<<256, 64, 0, st>>>(g.list + g.list_cap - 1, -1, g.list2_cnt, ps, S, mask, D, tmp_area, nacc, stats, err);
+  if (two) (void)hipStreamWaitEvent(st, e2, 0);
 }
 
 // ------------------------------------------------------------------------------------------------ batch primitives

@@ -379,6 +379,10 @@ static const char *gc_clip_error(int code)
 // 3*ndst, pairs 8*max(nsrc, ndst)) fit every remap between grids of comparable resolution; every kernel clamps its writes
 // AND reads to them, the counters keep counting, and an attempt that outgrew one is repeated with the counted sizes.
 static int g_search_cull = 0;
+// great-circle clip: 1 = three passes (k_gc_screen / k_gc_solve / k_gc_walk) with the one-kernel clip for the unusual pairs,
+// 0 = the one-kernel clip for every pair (fg_set_gc_split; the tests compare the two)
+static int g_gc_split = 1;
+extern "C" void fg_set_gc_split(int on) { g_gc_split = on ? 1 : 0; }
 struct SearchCaps { unsigned long long entries; int regcap, nreg; };
 // Chunks of source cells per search (1 = everything on one stream, in sequence; fg_set_search_chunks / FREGRID_HIP_CHUNKS).  Measured at C384 -> 0.25 deg with 4 chunks: the
 // kernels slow each other down by more than the overlap wins (clip 4 x 184 us against 482, step 1.48 ms against 1.30), so the
@@ -471,7 +475,8 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   const size_t ztick = 128;
   const size_t zlb = (size_t)(t_bins + t_rows + t_comp) * sizeof(unsigned long long);
   const size_t zints = ((size_t)(2 * (nslots + 1) + ndst + 1 + nsrc + 1) * sizeof(int) + 15) / 16 * 16;
-  const size_t zbytes = zc + zfill + ztick + zlb + zints;
+  const size_t zgc = gc ? (size_t)K * FG_NREG * FG_FILL_STRIDE * sizeof(unsigned) : 0;        // task counters of the great-circle clip
+  const size_t zbytes = zc + zfill + ztick + zlb + zints + zgc;
   char *zero_blk = pl->alloc<char>(zbytes);
   int *bin_start = pl->alloc<int>(nslots + 1);
   int *heavy_list = pl->alloc<int>(nsrc + 1);
@@ -483,6 +488,16 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   double *tmp_clon = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
   double *tmp_clat = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
   int *defer_list = pl->alloc<int>(npairs + 1);
+  // great-circle path, three-pass clip: per-pair words, and 3 tasks (edge pairs to solve) per pair of capacity -- 3.0 per LIVE
+  // pair were counted at C384 -> 0.25 deg; pairs whose tasks do not fit go through the one-kernel clip instead
+  const bool gc_split = gc && g_gc_split && npairs < (1L << 28);
+  const long tcap_reg = gc_split ? std::min<long>((3 * npairs / K / FG_NREG + 255) / 256 * 256, 0x7ffffff0L / (K * FG_NREG)) : 0;   // tasks per region
+  const long tcap_all = tcap_reg * K * FG_NREG;
+  unsigned *gc_meta = gc_split ? pl->alloc<unsigned>(npairs + 1) : nullptr;
+  int *gc_tbase = gc_split ? pl->alloc<int>(npairs + 1) : nullptr;
+  unsigned *gc_task = gc_split ? pl->alloc<unsigned>(tcap_all + 1) : nullptr;
+  double *gc_res = gc_split ? pl->alloc<double>(2 * (size_t)tcap_all + 2) : nullptr;
+  if (gc_split && (!gc_meta || !gc_tbase || !gc_task || !gc_res)) return fail(FG_ERR_HIP, "out of device memory");
   pl->xoff = pl->alloc<int>(nsrc + 1);
   pl->x_src = pl->alloc<int>(nx_alloc + 1); pl->x_dst = pl->alloc<int>(nx_alloc + 1);
   pl->x_area = pl->alloc<double>(nx_alloc + 1);
@@ -538,6 +553,11 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     sb = pl->stream_b;
   }
   std::vector<hipEvent_t> ev_c(K, nullptr), ev_q(K, nullptr);
+  hipEvent_t gc_e1 = nullptr, gc_e2 = nullptr;        // great-circle clip: the listed pairs run on stream B beside k_gc_walk
+  if (gc_split && K == 1) {
+    if (!pl->stream_b) pl->stream_b = g_handles.get_stream(pl->device);
+    gc_e1 = g_handles.get_sync_event(); gc_e2 = g_handles.get_sync_event();
+  }
   PhaseTimer ptb; ptb.start(g_profiling != 0, sb);
   int cb[FG_MAX_CHUNKS + 1];
   for (int k = 0; k <= K; k++) cb[k] = (k == K) ? nsrc : (int)(((long)nsrc * k / K) / 256 * 256);
@@ -564,7 +584,14 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
       ptb.end();
     } else if (gc) {
       ptb.begin(PH_CLIP_GENERAL);
-      fgd_gc_clip(q, pl->S, pl->mask_dev, pl->D, ta, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb);
+      if (gc_split) {
+        const long tcap_k = tcap_reg * FG_NREG;
+        unsigned *ntask = (unsigned *)(zero_blk + zbytes - zgc) + (size_t)k * FG_NREG * FG_FILL_STRIDE;
+        GcSplit g{gc_meta + k * pcap_k, gc_tbase + k * pcap_k, gc_task + k * tcap_k, gc_res + 2 * k * tcap_k, (unsigned)tcap_reg,
+                  ntask, dl, &dc->defer_cnt[k], &dc->gc_list2_cnt[k], pcap_k};
+        fgd_gc_clip_split(q, pl->S, pl->mask_dev, pl->D, ta, nacc, g, dc->stats, dc->err, sb, K == 1 ? pl->stream_b : nullptr, gc_e1, gc_e2);
+      } else
+        fgd_gc_clip(q, pl->S, pl->mask_dev, pl->D, ta, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb);
       ptb.end();
     } else {
       ptb.begin(PH_CLIP_QUAD);
@@ -605,6 +632,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms); ptb.collect(pl->phase_ms);   // (also hands the timing events back on every exit below)
   for (hipEvent_t e : ev_c) g_handles.put_sync_event(e);
   for (hipEvent_t e : ev_q) g_handles.put_sync_event(e);
+  g_handles.put_sync_event(gc_e1); g_handles.put_sync_event(gc_e2);
   HIPCHK(hipGetLastError());
   if (hc->total[0] > nentries) { caps->entries = hc->total[0]; return FG_RETRY; }
   if (hc->total[0] > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
@@ -630,13 +658,13 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pl->stats[FG_STAT_BINS] = nbins;
   pl->stats[FG_STAT_BIN_ENTRIES] = (long)hc->total[0];
   pl->stats[FG_STAT_DEFERRED] = 0;
-  for (int k = 0; k < K; k++) pl->stats[FG_STAT_DEFERRED] += hc->defer_cnt[k];
+  for (int k = 0; k < K; k++) pl->stats[FG_STAT_DEFERRED] += hc->defer_cnt[k] + hc->gc_list2_cnt[k];
   pl->stats[FG_STAT_HEAVY] = hc->heavy_cnt;
   pl->stats[FG_STAT_BELOW] = (long)hc->stats[FG_STAT_BELOW];
 
   // scratch no longer needed
   void *scratch[] = {zero_blk, bin_start, bin_entries, heavy_list, big_list, pair_beg, pair_cnt, ps.src, ps.dst,
-                     tmp_area, tmp_clon, tmp_clat, defer_list};
+                     tmp_area, tmp_clon, tmp_clat, defer_list, gc_meta, gc_tbase, gc_task, gc_res};
   for (void *p : scratch) pl->release(p);
   pl->release(pl->x_rowpos); pl->x_rowpos = nullptr;
   pl->rows_built = true;

@@ -95,6 +95,7 @@ struct FgCounters {
   unsigned err[4];
   int heavy_cnt, pad0;
   int defer_cnt[FG_MAX_CHUNKS], big_cnt[FG_MAX_CHUNKS];
+  int gc_list2_cnt[FG_MAX_CHUNKS];           // great-circle path: pairs k_gc_walk handed to the one-kernel clip
   unsigned long long stats[FG_NSTATS];
 };
 #define G_ERRBIT_LOOKBACK 128u     // a single-pass scan waited too long for its predecessor tile (never observed)
@@ -227,6 +228,21 @@ void fgd_grid_area_no_adjust(int nx, int ny, const double *lon, const double *la
 void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st);
 void fgd_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
                  double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st);
+// buffers of the three-pass clip (k_gc_screen / k_gc_solve / k_gc_walk, gc_kernels.hip)
+struct GcSplit {
+  unsigned *meta;          // [pairs] need mask (16) | isInside of the source / destination corners (4 + 4) | corners whose isInside
+                           //         k_gc_walk has to take from the angle sum (4 + 4)
+  int *tbase;              // [pairs] first task of the pair, -1: not a pair of the three passes (rejected, or on the list)
+  unsigned *task;          // [FG_NREG][tcap]  pair << 4 | i1 << 2 | i2; a block of k_gc_screen appends to one region
+  double *res;             // [FG_NREG][tcap][2]  (u1, +-u2): sign of the second = inbound 2;  (-1, 0) no intersection;  (2, 0) snapped onto a corner
+  unsigned tcap;           // tasks per region
+  unsigned *ntask;         // ntask[r * FG_FILL_STRIDE]: tasks handed out in region r (may exceed tcap: the pairs beyond it are on the list)
+  int *list, *list_cnt;    // pairs for the one-kernel version (k_gc_clip_list): from k_gc_screen and k_gc_solve, upwards from list[0]
+  int *list2_cnt;          // ... from k_gc_walk, downwards from list[list_cap - 1]
+  long list_cap;
+};
+void fgd_gc_clip_split(FgPairSpace ps, FgCells S, const double *mask, FgCells D, double *tmp_area, int *nacc, GcSplit g,
+                       unsigned long long *stats, unsigned *err, hipStream_t st, hipStream_t st2, hipEvent_t e1, hipEvent_t e2);
 #define FG_GC_POLY_CAP 16
 void fgd_gc_clip_batch(int n, const double *a, const double *b, double *out, int *n_out, double *area, hipStream_t st);
 void fgd_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *n, double *area, hipStream_t st);

@@ -307,6 +307,9 @@ void fg_set_search_chunks(int chunks);
  * rank of a banded multi-GPU job meets a fraction of the source cells); fg_plan_get_cell_area / _cell_struct then return 0 /
  * unspecified values for those cells.  The exchange cells are unchanged.  Default 0. */
 void fg_set_search_cull(int on);
+/* Great-circle search: 1 (default) = the clip runs as three passes (screen / extended-precision solves / walk) with the
+ * one-kernel clip for the unusual pairs; 0 = the one-kernel clip for every pair.  Results do not depend on it. */
+void fg_set_gc_split(int on);
 /* Sweep tuning hook, the tile -> XCD mapping: 0 = blocks in row order; 1 = each XCD sweeps one contiguous band of
  * destination rows (measured slower); C >= 2 = chunks of C consecutive tiles per XCD, chunks dealt round-robin (default 64,
  * see csrc/apply_kernels.hip).  Results do not depend on it. */

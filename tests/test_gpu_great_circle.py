@@ -169,3 +169,30 @@ def test_great_circle_degenerate_cases(fg, gpu_ok):
     # fully masked source
     r = fg.create_xgrid_great_circle(6, 6, 6, 6, lo1, la1, lo1, la1, mask_in=np.zeros(36))
     assert r[0] == 0
+
+
+@pytest.mark.parametrize("ni,nlon,nlat", [(24, 144, 90), (96, 360, 180), (48, 1440, 720)])
+def test_three_pass_clip_equals_the_one_kernel_clip(fg, gpu_ok, ni, nlon, nlat):
+    """The great-circle clip runs as three passes (k_gc_screen / k_gc_solve / k_gc_walk) for ordinary pairs and as the
+    one-kernel clip (the version pinned to the oracle above) for the rest.  Here every pair goes through each of the two
+    and the plans must be bit-identical; only a small fraction of the pairs may be handed back by the three passes."""
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    res = []
+    try:
+        for split in (0, 1):
+            fg.lib().fg_set_gc_split(split)
+            plan = fg.XgridPlan.create_great_circle(grids, fg.GridConfig(nlon, nlat, lo, la))
+            plan.finalize()
+            res.append((plan.get_xgrid(), plan.stats()))
+            plan.destroy()
+    finally:
+        fg.lib().fg_set_gc_split(1)
+    (a, sa), (b, sb) = res
+    assert len(a["area"]) == len(b["area"]) > 0
+    for k in ("t_in", "i_in", "j_in", "i_out", "j_out"):
+        assert np.array_equal(a[k], b[k])
+    assert np.array_equal(_bits(a["area"]), _bits(b["area"]))
+    assert sa["below"] == sb["below"] and sa["borderline"] == sb["borderline"]
+    assert sb["deferred"] < 0.1 * sb["pairs"] + 4000        # pole cells, tile-edge cells on lat-lon lines, snapped intersections
