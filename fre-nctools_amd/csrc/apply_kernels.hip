@@ -378,12 +378,13 @@ template <int V> struct VecD;
 template <> struct VecD<1> { double v[1]; };
 template <> struct __attribute__((aligned(16))) VecD<2> { double v[2]; };
 template <> struct __attribute__((aligned(16))) VecD<4> { double v[4]; };
+template <> struct __attribute__((aligned(16))) VecD<8> { double v[8]; };
 
 
 // MERGED (order 2): f points at records [source cell][3][NB] = {field, grad_x, grad_y} of the interior cell idx_g
 // (k_merge3): one contiguous 3*NB*8-byte segment per entry instead of three NB*8-byte ones in three arrays -- 13 % (NB = 8)
 // to 23 % (NB = 4) faster on MI355X; px, py unused.
-template <int ORDER, int NB, int V, bool MERGED = false>
+template <int ORDER, int NB, int V, bool MERGED = false, int UNR = 1>
 __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const double *f, const double *px, const double *py,
                                                    double missing, double *out, double *row_sum, long out_ld, int nb_valid, int xcd_band)
 {
@@ -415,6 +416,37 @@ __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const dou
   double acc[V], asum = 0.0;
 #pragma unroll
   for (int k = 0; k < V; k++) acc[k] = 0.0;
+  if (MERGED && UNR > 1) {
+    // UNR entries of the row in flight per lane: all their gathers are issued before the first is consumed (a row has ~4
+    // entries; the sums keep the CSR order).  Entries past the row's end repeat its last one (same lines, no new traffic).
+    for (int q = b; q < e; q += UNR) {
+      FgCsrEntry2 E[UNR];
+      VecD<V> fv[UNR], gxv[UNR], gyv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const int qq = min(q + u, e - 1), ql = qq - q0;
+        E[u] = (ql < APPLY_STAGE) ? ((const FgCsrEntry2 *)sh_e)[ql] : csr.e2[qq];
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const double *pf = f + (size_t)E[u].idx_g * (3 * NB) + lev;
+        fv[u] = *reinterpret_cast<const VecD<V> *>(pf);
+        gxv[u] = *reinterpret_cast<const VecD<V> *>(pf + NB);
+        gyv[u] = *reinterpret_cast<const VecD<V> *>(pf + 2 * NB);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        if (q + u < e) {
+#pragma unroll
+          for (int k = 0; k < V; k++) {
+            double v = (fv[u].v[k] + gxv[u].v[k] * E[u].di + gyv[u].v[k] * E[u].dj);
+            acc[k] += v * E[u].area;
+          }
+          asum += E[u].area;
+        }
+      }
+    }
+  } else
   for (int q = b; q < e; q++) {
     const int ql = q - q0;
     if (ORDER == 2) {
@@ -648,12 +680,13 @@ static void apply_il_nb(int order, int ndst, FgCsr csr, const double *f, const d
 // out_ld for the first nb_valid levels (else interleaved [cell][nb])
 int g_apply_xcd = 64;  // d_xcd_block: 0 identity, 1 one band per XCD, C >= 2 chunks of C tiles per XCD (measured on the 1440x720 sweep,
                        // 8 levels merged records: 0.0936 ms with C = 32..256, 0.0966 identity, 0.1105 banded)
-int g_apply_vec = 0;   // levels per lane: 0 = auto (4 for nb = 16, else 2; measured best on MI355X), or force 1 / 2 / 4
+int g_apply_vec = 0;   // levels per lane: 0 = auto (4 for nb >= 8, else 2: with chunked tiles 0.0986 against 0.1010 ms on interleaved arrays,
+                       // 0.0875 against 0.0937 on records, 1440x720 x 8 levels), or force 1 / 2 / 4
 void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
                   double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st)
 {
   if (ndst <= 0) return;
-  const int v = g_apply_vec ? g_apply_vec : (nb >= 16 ? 4 : 2);
+  const int v = g_apply_vec ? g_apply_vec : (nb >= 8 ? 4 : 2);
 #define AP(NB_) do { if (v >= 4 && NB_ >= 4) apply_il_nb<NB_, (NB_ >= 4 ? 4 : 2)>(order, ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, st); \
                      else if (v >= 2) apply_il_nb<NB_, 2>(order, ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, st); \
                      else apply_il_nb<NB_, 1>(order, ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, st); } while (0)
@@ -670,7 +703,7 @@ void fgd_apply_il_merged(int nb, int ndst, FgCsr csr, const double *rec, double 
   if (ndst <= 0) return;
 #define APM(NB_, V_) k_apply_il<2, NB_, V_, true><<<nblk(ndst, 256 / (NB_ / V_)), 256, 0, st>>>(ndst, csr, rec, nullptr, nullptr, missing, out, row_sum, out_ld, nb_valid, g_apply_xcd)
   if (nb == 16) APM(16, 4);
-  else if (nb == 8) APM(8, 2);
+  else if (nb == 8) { if (g_apply_vec == 2) APM(8, 2); else APM(8, 4); }   // 4 levels per lane: 0.0875 ms against 0.0936 with 2 (1440x720, 8 levels, chunked tiles)
   else if (nb == 4) APM(4, 2);
   else APM(2, 2);
 #undef APM

@@ -307,6 +307,8 @@ void fg_set_search_chunks(int chunks);
  * rank of a banded multi-GPU job meets a fraction of the source cells); fg_plan_get_cell_area / _cell_struct then return 0 /
  * unspecified values for those cells.  The exchange cells are unchanged.  Default 0. */
 void fg_set_search_cull(int on);
+/* Sweep tuning hook: levels per lane (1, 2 or 4; 0 = automatic).  Results do not depend on it. */
+void fg_set_apply_vec(int v);
 /* Great-circle search: 1 (default) = the clip runs as three passes (screen / extended-precision solves / walk) with the
  * one-kernel clip for the unusual pairs; 0 = the one-kernel clip for every pair.  Results do not depend on it. */
 void fg_set_gc_split(int on);

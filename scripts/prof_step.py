@@ -14,6 +14,7 @@ dev = "cuda:0"
 rng = np.random.default_rng(0)
 h2d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 out = h2d(np.zeros(nz * nlon * nlat))
+if os.environ.get("FG_XCD"): fg.lib().fg_set_apply_xcd(int(os.environ["FG_XCD"]))
 if mode == "sweep":
     # the sweep kernels alone, for the PMC passes that settle their HBM traffic: order-2 level-major call (k_merge3 +
     # k_apply_il<2,8,2,MERGED>), the same on caller-interleaved arrays (k_apply_il<2,8,2>), and an order-1 level-major call

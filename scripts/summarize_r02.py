@@ -70,7 +70,7 @@ for k in keys:
     wr = 64 * c.get("TCC_EA0_WRREQ_64B_sum", 0) / 1e6
     hit = c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))
     lines.append(f"| `{k}` | {rd:.1f} | {c['TCC_EA0_RDREQ_sum'] * 64 / 1e6:.1f} | {wr:.1f} | {hit:.2f} |")
-    if k == "k_apply_il<2, 8, 2, true>":
+    if k in ("k_apply_il<2, 8, 4, true>", "k_apply_il<2, 8, 2, true>"):
         traffic["k_apply"] = (rd + wr) * 1e6
 md += ["Bytes from the by-size request counters (exact on the calibration kernel: 56.6 MB read, 56.6 MB written):", "", "\n".join(lines), "",
        "Reading: nearly every fabric read is a 128-byte request, FETCH_SIZE books it as 64 bytes -- the guide's 2x correction holds for the "
