@@ -399,6 +399,8 @@ __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const dou
   // the block's rows own one contiguous run of CSR records: stage it with coalesced 16-byte loads
   const int dl = min(d0 + ROWS, ndst);
   const int q0 = csr.row_ptr[d0], q1 = csr.row_ptr[dl];
+  const int dc = min(d, ndst - 1);
+  const int b = csr.row_ptr[dc], e = csr.row_ptr[dc + 1];   // (issued with q0, q1: one memory round trip less per wave)
   {
     const Entry *src = (ORDER == 2) ? (const Entry *)csr.e2 : (const Entry *)csr.e1;
     const int nstage = min(q1 - q0, APPLY_STAGE);
@@ -412,7 +414,6 @@ __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const dou
   }
   __syncthreads();
   if (d >= ndst) return;
-  const int b = csr.row_ptr[d], e = csr.row_ptr[d + 1];
   double acc[V], asum = 0.0;
 #pragma unroll
   for (int k = 0; k < V; k++) acc[k] = 0.0;

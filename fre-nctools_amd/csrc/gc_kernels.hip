@@ -111,6 +111,14 @@ __device__ int gc_inside_polygon(const GcNode &node, const GcList &l)
 // range [-1e-8, 1+1e-8] (create_xgrid.c:1993-2001): line_intersect_2D_3D returns 0 for that edge pair.
 __device__ bool gc_screen_out(const double *pnt0, const double *pnt1, const double *l1, const double *l2)
 {
+  {                                                              // both ends clear of the plane on one side (see gc_half_screen)
+    double n[3];
+    n[0] = pnt0[1] * pnt1[2] - pnt0[2] * pnt1[1]; n[1] = pnt0[2] * pnt1[0] - pnt0[0] * pnt1[2]; n[2] = pnt0[0] * pnt1[1] - pnt0[1] * pnt1[0];
+    const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    const double r1 = n[0] * l1[0] + n[1] * l1[1] + n[2] * l1[2], r2 = n[0] * l2[0] + n[1] * l2[1] + n[2] * l2[2];
+    const double m1 = fabs(r1), m2 = fabs(r2);
+    if ((r1 > 0) == (r2 > 0) && r1 * r1 > 1.e-12 * nn && r2 * r2 > 1.e-12 * nn && fmin(m1, m2) >= 1.e-5 * fmax(m1, m2)) return true;
+  }
   const double d0 = l1[0] - l2[0], d1 = pnt1[0] - pnt0[0], d2 = 0.0 - pnt0[0];
   const double d3 = l1[1] - l2[1], d4 = pnt1[1] - pnt0[1], d5 = 0.0 - pnt0[1];
   const double d6 = l1[2] - l2[2], d7 = pnt1[2] - pnt0[2], d8 = 0.0 - pnt0[2];
@@ -875,8 +883,7 @@ __device__ int gc_inside4(const double *pnt0g, const double *q)
 // The four corners p against the four edge planes of q.  false: q is not a plainly convex quad.
 //   in_bits / out_bits  per corner of p: inside every / outside some half-space of q by more than the clearance
 //   miss                bit (edge of the source cell * 4 + edge of the destination cell): edge i of p meets the plane of edge e of
-//                       q at a parameter outside [-1e-5, 1 + 1e-5] (gc_screen_out: t = n.l1 / (n.l1 - n.l2), n = q_e x q_e+1)
-// The dot products carry an absolute error of ~1e-15, so a parameter is only trusted when |det| > 1e-8 as well.
+//                       q at a parameter outside [-1e-5, 1 + 1e-5] (t = n.l1 / (n.l1 - n.l2), n = q_e x q_e+1)
 template <bool SWAP>
 __device__ __forceinline__ bool gc_half_screen(const double *p, const double *q, const double *plen2, const double *qlen2,
                                                unsigned &in_bits, unsigned &out_bits, unsigned &miss)
@@ -895,21 +902,26 @@ __device__ __forceinline__ bool gc_half_screen(const double *p, const double *q,
     double raw[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) raw[k] = gc_dot(n, p + k * 3);
+    unsigned clr = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const bool clear = raw[k] * raw[k] > GC_SIN2_CLEAR * nn;
       const double sd = raw[k] * sigma;
+      if (clear) clr |= 1u << k;
       if (!(clear && sd > 0)) in_bits &= ~(1u << k);
       if (clear && sd < 0) out_bits |= 1u << k;
     }
+    // edge i of p against this plane: the parameter of line_intersect_2D_3D is t = r_i / (r_i - r_i+1), outside [0, 1] exactly
+    // when both ends lie on one side.  With both ends clear of the plane (sin > 1e-6, far above the 1e-10 a later snap can move
+    // an end and the ~1e-15 of the dot products) and |r| ratio >= 1e-5, t is outside [-1e-5, 1 + 1e-5]: certainly no
+    // intersection, however parallel the two edges are (meridian edges of a cubed-sphere face against meridians: 4 of the 16
+    // edge pairs of most pairs at C384 -> lat-lon, which the determinant-based screen of gc_screen_out let through).
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const double det = raw[i] - raw[(i + 1) & 3];
-      const double n1 = plen2[i], n2 = qlen2[e];
-      if (n1 > 1.e-8 && n2 > 1.e-8 && det * det > 1.e-6 * n1 * n2 && fabs(det) > 1.e-8) {
-        const double r = (det > 0) ? raw[i] : -raw[i], ad = fabs(det);                 // td = r / ad outside [-1e-5, 1 + 1e-5]
-        if (r < -1.e-5 * ad || r > (1.0 + 1.e-5) * ad) miss |= 1u << (SWAP ? e * 4 + i : i * 4 + e);
-      }
+      const double r1 = raw[i], r2 = raw[(i + 1) & 3], m1 = fabs(r1), m2 = fabs(r2);
+      const bool same = (r1 > 0) == (r2 > 0);
+      if (same && ((clr >> i) & 1u) && ((clr >> ((i + 1) & 3)) & 1u) && fmin(m1, m2) >= 1.e-5 * fmax(m1, m2))
+        miss |= 1u << (SWAP ? e * 4 + i : i * 4 + e);
     }
   }
   return convex;
@@ -1018,28 +1030,44 @@ __device__ __forceinline__ double gcw_sel8(const double *a, int k)
   for (int m = 1; m < 8; m++) v = (k == m) ? a[m] : v;
   return v;
 }
+// node lists of k_gc_walk: 4-bit refs in one 64-bit word, the intersect (0 / 1) and isInside flags as bit masks -- the 128-bit
+// byte codes of GcPacked cost three times the instructions per access; gl_get returns the same code (ref | intersect << 4 | inside << 6)
+struct GcL64 { unsigned long long refs; unsigned inter, inside; int n; };
+__device__ __forceinline__ unsigned gl_get(const GcL64 &l, int k)
+{
+  return ((unsigned)(l.refs >> (4 * k)) & 15u) | (((l.inter >> k) & 1u) << 4) | (((l.inside >> k) & 1u) << 6);
+}
+__device__ __forceinline__ void gl_insert(GcL64 &l, int k, unsigned ref)       // an intersection node: intersect = 1, isInside = 1
+{
+  const unsigned long long low = l.refs & ((1ull << (4 * k)) - 1ull);
+  l.refs = low | ((unsigned long long)ref << (4 * k)) | ((l.refs >> (4 * k)) << (4 * (k + 1)));
+  const unsigned lm = (1u << k) - 1u;
+  l.inter = (l.inter & lm) | (1u << k) | ((l.inter >> k) << (k + 1));
+  l.inside = (l.inside & lm) | (1u << k) | ((l.inside >> k) << (k + 1));
+  l.n++;
+}
 // insertIntersect (mosaic_util.c:1313-1397) for an intersection strictly inside the edge that starts at corner `vtx`;
 // iu[] = the parameters of the intersections along this list's edges
-__device__ __forceinline__ int gcw_insert(GcPacked &l, int vtx, double u_cur, int inbound, const double *iu, int iref)
+__device__ __forceinline__ int gcw_insert(GcL64 &l, int vtx, double u_cur, int inbound, const double *iu, int iref)
 {
   int k1 = -1;
-  for (int k = 0; k < l.n; k++) { const unsigned c = gcp_get(l, k); if (GCN_INTER(c) == 0 && (int)GCN_REF(c) == vtx) { k1 = k; break; } }
+  for (int k = 0; k < l.n; k++) { const unsigned c = gl_get(l, k); if (GCN_INTER(c) == 0 && (int)GCN_REF(c) == vtx) { k1 = k; break; } }
   if (k1 < 0) return -7;
   if (inbound == 1) {
     int k2 = (k1 + 1 < l.n) ? k1 + 1 : 0, guard = 0;
-    while (GCN_INTER(gcp_get(l, k2))) { k2 = (k2 + 1 < l.n) ? k2 + 1 : 0; if (++guard > 32) return -7; }
-    gcp_set(l, k2, gcp_get(l, k2) & ~(1u << 6));
+    while ((l.inter >> k2) & 1u) { k2 = (k2 + 1 < l.n) ? k2 + 1 : 0; if (++guard > 32) return -7; }
+    l.inside &= ~(1u << k2);
   } else if (inbound == 2)
-    gcp_set(l, k1, gcp_get(l, k1) & ~(1u << 6));
+    l.inside &= ~(1u << k1);
   int k2 = k1 + 1;
   while (k2 < l.n) {
-    const unsigned c = gcp_get(l, k2);
+    const unsigned c = gl_get(l, k2);
     if (GCN_INTER(c) == 1) { if (gcw_sel8(iu, (int)GCN_REF(c) - 4) > u_cur) break; }
     else break;
     k2++;
   }
   if (l.n >= 12) return -9;
-  gcp_insert(l, k2, (unsigned)(4 + iref) | (1u << 4) | (1u << 6));
+  gl_insert(l, k2, (unsigned)(4 + iref));
   return 0;
 }
 
@@ -1094,12 +1122,9 @@ __global__ __launch_bounds__(64) void k_gc_walk(FgPairSpace ps, FgCells S, const
     if (in > 0) meta |= 1u << (16 + bit);
   }
 
-  GcPacked gl0, gl1;                                       // (two named values: a list indexed by L would live in scratch)
-  gl0.bits = 0; gl0.n = 4; gl1.bits = 0; gl1.n = 4;
-  for (int k = 0; k < 4; k++) {
-    gl0.bits |= (gc_u128)((unsigned)k | (((meta >> (16 + k)) & 1u) << 6)) << (8 * k);
-    gl1.bits |= (gc_u128)((unsigned)k | (((meta >> (20 + k)) & 1u) << 6)) << (8 * k);
-  }
+  GcL64 gl0, gl1;                                          // (two named values: a list indexed by L would live in scratch)
+  gl0.refs = gl1.refs = 0x3210ull; gl0.inter = gl1.inter = 0; gl0.n = gl1.n = 4;
+  gl0.inside = (meta >> 16) & 15u; gl1.inside = (meta >> 20) & 15u;
   double iu0[8], iu1[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) { iu0[k] = -1.0; iu1[k] = -1.0; }
@@ -1107,11 +1132,20 @@ __global__ __launch_bounds__(64) void k_gc_walk(FgPairSpace ps, FgCells S, const
   int nil = 0;
   {
     unsigned need = meta & 0xffffu;
-    int t = t0;
+    // the first four results (a pair has 3.0 on average) in one round trip; the rest one by one
+    const int ntask = __popc(need);
+    double2 rpre[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) rpre[i] = ((const double2 *)g.res)[t0 + min(i, max(ntask - 1, 0))];
+    int ti = 0;
     while (need && !bad) {
       const int bit = __ffs((int)need) - 1;
       need &= need - 1;
-      const double2 r = ((const double2 *)g.res)[t++];
+      double2 r = rpre[0];
+#pragma unroll
+      for (int i = 1; i < 4; i++) r = (ti == i) ? rpre[i] : r;
+      if (ti >= 4) r = ((const double2 *)g.res)[t0 + ti];
+      ti++;
       if (r.x < 0) continue;
       const double u1 = r.x, u2 = fabs(r.y);
       if (u1 > 1.5 || u1 < 1.e-6 || u1 > 1.0 - 1.e-6 || u2 < 1.e-6 || u2 > 1.0 - 1.e-6) { bad = true; break; }
@@ -1144,9 +1178,9 @@ __global__ __launch_bounds__(64) void k_gc_walk(FgPairSpace ps, FgCells S, const
       int L = 0, iter1 = 0, found1 = 0, found2 = 0, cur = firstx;
       unsigned ccode = 0;
       while (iter1 < maxiter1 && !bad) {
-        const GcPacked lw = L ? gl1 : gl0;                 // the walk only reads the lists
+        const GcL64 lw = L ? gl1 : gl0;                 // the walk only reads the lists
         int k1 = -1;
-        for (int k = 0; k < lw.n; k++) { const unsigned c = gcp_get(lw, k); if (GCN_INTER(c) == 1 && (int)GCN_REF(c) - 4 == cur) { k1 = k; break; } }
+        for (int k = 0; k < lw.n; k++) { const unsigned c = gl_get(lw, k); if (GCN_INTER(c) == 1 && (int)GCN_REF(c) - 4 == cur) { k1 = k; break; } }
         if (k1 < 0) { bad = true; break; }
         int k2 = (k1 + 1 < lw.n) ? k1 + 1 : 0;
         const int maxiter2 = lw.n;
@@ -1154,10 +1188,10 @@ __global__ __launch_bounds__(64) void k_gc_walk(FgPairSpace ps, FgCells S, const
         found2 = 0;
         while (iter2 < maxiter2) {
           int t2_is_inter = 0;
-          const unsigned c2 = gcp_get(lw, k2);
+          const unsigned c2 = gl_get(lw, k2);
           if (GCN_INTER(c2)) {
             if ((int)GCN_REF(c2) - 4 == firstx) { found1 = 1; break; }
-            const unsigned c3 = gcp_get(lw, (k2 + 1 < lw.n) ? k2 + 1 : 0);
+            const unsigned c3 = gl_get(lw, (k2 + 1 < lw.n) ? k2 + 1 : 0);
             found2 = 1;
             t2_is_inter = 1;
             if (GCN_INTER(c3) || GCN_INSIDE(c3) == 1) found2 = 0;
@@ -1181,12 +1215,12 @@ __global__ __launch_bounds__(64) void k_gc_walk(FgPairSpace ps, FgCells S, const
     if (!bad && n_out == 0) {
 #pragma unroll
       for (int L = 0; L < 2; L++) {                        // grid1 inside grid2 (:1839-1870), then grid2 inside grid1 (:1873-1904)
-        const GcPacked lw = L ? gl1 : gl0;
+        const GcL64 lw = L ? gl1 : gl0;
         int nin = 0;
-        for (int k = 0; k < lw.n; k++) { const unsigned c = gcp_get(lw, k); if (GCN_INTER(c) != 1 && GCN_INSIDE(c) == 1) nin++; }
+        for (int k = 0; k < lw.n; k++) { const unsigned c = gl_get(lw, k); if (GCN_INTER(c) != 1 && GCN_INSIDE(c) == 1) nin++; }
         if (n_out == 0 && nin == 4) {
           int np = 0;
-          for (int k = 0; k < 4; k++) gcw_poly_add(lds, lane, np, false, L, gcp_get(lw, k), A, B, iu0, imeta);
+          for (int k = 0; k < 4; k++) gcw_poly_add(lds, lane, np, false, L, gl_get(lw, k), A, B, iu0, imeta);
           n_out = 4;
         }
       }

@@ -70,6 +70,33 @@ extern "C" long fp80_check_acosl(long n, long *ulp1)
   }
   return bad;
 }
+// fg_acosl (short series + rounding check) against fg_acosl_long (the 13-term series): must agree on every argument; also
+// dd_from_x80_pos against dd_from_x80
+extern "C" long fp80_check_acosl_fast(long n)
+{
+  srand48(4711);
+  long bad = 0;
+  for (long i = 0; i < n; i++) {
+    double x;
+    switch (i % 6) {
+      case 0: x = drand48() * 2 - 1; break;
+      case 1: x = 1 - ldexp(drand48(), -(int)(drand48() * 52)); break;
+      case 2: x = -1 + ldexp(drand48(), -(int)(drand48() * 52)); break;
+      case 3: x = ldexp(drand48() * 2 - 1, -(int)(drand48() * 60)); break;
+      case 4: x = cos((i / 6 % 129) * (3.14159265358979323846 / 128) + (drand48() - 0.5) * 1e-9); break;   // next to the table angles
+      default: x = cos(ldexp(1.0, -(int)(i / 6 % 40)) * (1 + drand48())); break;                            // results near powers of two
+    }
+    if (x > 1) x = 1;
+    if (x < -1) x = -1;
+    if (fg_acosl(x) != fg_acosl_long(x)) bad++;
+    x80 y; y.s = 0; y.e = (int)(lrand48() % 80) - 60;
+    y.m = (((uint64_t)lrand48() << 33) ^ ((uint64_t)lrand48() << 11) ^ (uint64_t)lrand48()) | 0x8000000000000000ULL;
+    if (i % 5 == 0) y.m |= 0x7ff; if (i % 7 == 0) y.m = (y.m & ~0x7ffULL) | 0x400; if (i % 11 == 0) y.m = 0xffffffffffffffffULL - (i % 3);
+    const dd2 a = dd_from_x80(y), b = dd_from_x80_pos(y);
+    if (a.hi != b.hi || a.lo != b.lo) bad++;
+  }
+  return bad;
+}
 // crafted significands for the estimate-and-correct divide and square root: extreme, exact and just-off-exact cases
 static long double to_ld(x80 a)
 {

@@ -23,6 +23,8 @@ def chk():
     L.fp80_check_ops.restype = C.c_long
     L.fp80_check_acosl.argtypes = [C.c_long, C.POINTER(C.c_long)]
     L.fp80_check_acosl.restype = C.c_long
+    L.fp80_check_acosl_fast.argtypes = [C.c_long]
+    L.fp80_check_acosl_fast.restype = C.c_long
     L.fp80_check_edges.argtypes = [C.c_long, C.POINTER(C.c_long)]
     L.fp80_check_edges.restype = C.c_long
     return L
@@ -49,3 +51,10 @@ def test_acosl_matches_glibc_up_to_rare_final_rounding(chk):
     bad = chk.fp80_check_acosl(n, C.byref(ulp1))
     assert bad == ulp1.value          # any difference is a last-place double rounding
     assert bad <= n * 2e-3, bad
+
+
+def test_short_series_acosl_equals_the_long_series(chk):
+    """fg_acosl takes a 7-term series with a double tail and keeps its result only when it is provably the nearest double;
+    fg_acosl_long (13 double-double terms) is what it falls back to.  They must agree everywhere (random arguments, next to
+    +-1, next to the table angles, results next to powers of two); dd_from_x80_pos must equal dd_from_x80."""
+    assert chk.fp80_check_acosl_fast(6000000) == 0
