@@ -382,7 +382,7 @@ static int g_search_cull = 0;
 // great-circle clip: 1 = three passes (k_gc_screen / k_gc_solve / k_gc_walk) with the one-kernel clip for the unusual pairs,
 // 0 = the one-kernel clip for every pair (fg_set_gc_split; the tests compare the two)
 static int g_gc_split = 1;
-extern "C" void fg_set_gc_split(int on) { g_gc_split = on ? 1 : 0; }
+extern "C" void fg_set_gc_split(int on) { g_gc_split = on < 0 ? 0 : on; }      // 2: a task space 64 times too small (tests of the overflow path)
 struct SearchCaps { unsigned long long entries; int regcap, nreg; };
 // Chunks of source cells per search (1 = everything on one stream, in sequence; fg_set_search_chunks / FREGRID_HIP_CHUNKS).  Measured at C384 -> 0.25 deg with 4 chunks: the
 // kernels slow each other down by more than the overlap wins (clip 4 x 184 us against 482, step 1.48 ms against 1.30), so the
@@ -491,7 +491,8 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   // great-circle path, three-pass clip: per-pair words, and 3 tasks (edge pairs to solve) per pair of capacity -- 3.0 per LIVE
   // pair were counted at C384 -> 0.25 deg; pairs whose tasks do not fit go through the one-kernel clip instead
   const bool gc_split = gc && g_gc_split && npairs < (1L << 28);
-  const long tcap_reg = gc_split ? std::min<long>((3 * npairs / K / FG_NREG + 255) / 256 * 256, 0x7ffffff0L / (K * FG_NREG)) : 0;   // tasks per region
+  const long tcap_want = (g_gc_split == 2) ? npairs / 64 : 3 * npairs;
+  const long tcap_reg = gc_split ? std::min<long>((tcap_want / K / FG_NREG + 255) / 256 * 256, 0x7ffffff0L / (K * FG_NREG)) : 0;   // tasks per region
   const long tcap_all = tcap_reg * K * FG_NREG;
   unsigned *gc_meta = gc_split ? pl->alloc<unsigned>(npairs + 1) : nullptr;
   int *gc_tbase = gc_split ? pl->alloc<int>(npairs + 1) : nullptr;

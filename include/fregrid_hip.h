@@ -310,7 +310,8 @@ void fg_set_search_cull(int on);
 /* Sweep tuning hook: levels per lane (1, 2 or 4; 0 = automatic).  Results do not depend on it. */
 void fg_set_apply_vec(int v);
 /* Great-circle search: 1 (default) = the clip runs as three passes (screen / extended-precision solves / walk) with the
- * one-kernel clip for the unusual pairs; 0 = the one-kernel clip for every pair.  Results do not depend on it. */
+ * one-kernel clip for the unusual pairs; 0 = the one-kernel clip for every pair; 2 = three passes with a task buffer 64 times
+ * too small (test hook for the overflow path).  Results do not depend on it. */
 void fg_set_gc_split(int on);
 /* Sweep tuning hook, the tile -> XCD mapping: 0 = blocks in row order; 1 = each XCD sweeps one contiguous band of
  * destination rows (measured slower); C >= 2 = chunks of C consecutive tiles per XCD, chunks dealt round-robin (default 64,

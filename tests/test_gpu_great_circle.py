@@ -181,18 +181,24 @@ def test_three_pass_clip_equals_the_one_kernel_clip(fg, gpu_ok, ni, nlon, nlat):
     grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
     res = []
     try:
-        for split in (0, 1):
+        # one kernel | three passes | three passes in 3 chunks of source cells | three passes with a task buffer 64 times too small
+        for split, chunks in ((0, 1), (1, 1), (1, 3), (2, 1)):
             fg.lib().fg_set_gc_split(split)
+            fg.lib().fg_set_search_chunks(chunks)
             plan = fg.XgridPlan.create_great_circle(grids, fg.GridConfig(nlon, nlat, lo, la))
             plan.finalize()
             res.append((plan.get_xgrid(), plan.stats()))
             plan.destroy()
     finally:
         fg.lib().fg_set_gc_split(1)
-    (a, sa), (b, sb) = res
-    assert len(a["area"]) == len(b["area"]) > 0
-    for k in ("t_in", "i_in", "j_in", "i_out", "j_out"):
-        assert np.array_equal(a[k], b[k])
-    assert np.array_equal(_bits(a["area"]), _bits(b["area"]))
-    assert sa["below"] == sb["below"] and sa["borderline"] == sb["borderline"]
-    assert sb["deferred"] < 0.1 * sb["pairs"] + 4000        # pole cells, tile-edge cells on lat-lon lines, snapped intersections
+        fg.lib().fg_set_search_chunks(0)
+    a, sa = res[0]
+    assert len(a["area"]) > 0 and sa["deferred"] == 0
+    for b, sb in res[1:]:
+        assert len(a["area"]) == len(b["area"])
+        for k in ("t_in", "i_in", "j_in", "i_out", "j_out"):
+            assert np.array_equal(a[k], b[k])
+        assert np.array_equal(_bits(a["area"]), _bits(b["area"]))
+        assert sa["below"] == sb["below"] and sa["borderline"] == sb["borderline"]
+    assert res[1][1]["deferred"] < 0.1 * sa["pairs"] + 4000   # pole cells, tile-edge cells on lat-lon lines, snapped intersections
+    assert res[3][1]["deferred"] > 0.1 * sa["pairs"]          # the overflow path really ran
