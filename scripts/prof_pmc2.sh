@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-2 rocprofv3 passes (each counter group in its own run with --kernel-trace only; TCC has 4 slots per pass).
 #   search (prof_step.py legacy): stats, FETCH_SIZE, WRITE_SIZE, SQ group
+#   gc     (prof_step.py gc):     stats, SQ group, FETCH/WRITE
+#   bench.py: stats of the default run and of the headline-only run (--legs none)
 #   sweep  (prof_step.py sweep):  stats, FETCH_SIZE, WRITE_SIZE, the raw TCC request counters by size, L2 hit / miss
 # Run on the GPU box from the repo root; outputs under gpurun_out/r02_*.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -12,6 +14,12 @@ run() { # tag mode counters...
 }
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/r02_stats_search -o s -- python3 scripts/prof_step.py 10 legacy > $R/r02_stats_search.log 2>&1 || exit 2
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/r02_stats_sweep -o s -- python3 scripts/prof_step.py 10 sweep > $R/r02_stats_sweep.log 2>&1 || exit 3
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/r02_stats_gc -o s -- python3 scripts/prof_step.py 10 gc > $R/r02_stats_gc.log 2>&1 || exit 4
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/r02_stats_bench_headline -o s -- python3 bench.py --legs none --cpu-rows 0 --gc-steps 0 > $R/r02_stats_bench_headline.log 2>&1 || exit 5
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/r02_stats_bench -o s -- python3 bench.py > $R/r02_stats_bench.log 2>&1 || exit 6
+run gc_sq gc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
+run gc_fetch gc FETCH_SIZE
+run gc_write gc WRITE_SIZE
 run search_fetch legacy FETCH_SIZE
 run search_write legacy WRITE_SIZE
 run search_sq legacy SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU

@@ -68,7 +68,7 @@ if mg:
     md += ["## PMC passes, great-circle search (`prof_step.py 3 gc`)", "", pmc_table(mg, cs[:5]), ""]
 open(os.path.join(P, f"{tag}_summary.md"), "w").write("\n".join(md))
 traffic = {}
-for key, kname in (("k_clip_quad", "k_clip_quad<2>"), ("k_apply", "k_apply_il<2, 8, 4, true>")):
+for key, kname in (("k_clip_quad", "k_clip_quad<2>"), ("k_apply", "k_apply_il<2, 8, 4, true, 1>")):
     if kname in m and "FETCH_SIZE" in m[kname] and "WRITE_SIZE" in m[kname]:
         traffic[key] = (2 * m[kname]["FETCH_SIZE"] + m[kname]["WRITE_SIZE"]) * 1024.0
 if "k_clip_quad<2>" in m and "SQ_INSTS_VALU" in m["k_clip_quad<2>"]:

@@ -42,7 +42,15 @@ if os.path.exists(b):
     t, _ = stats(b, 30)
     md += ["## `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py`  (default run: C384 -> 1440x720 order 2 + all legs)", "",
            "Full CSV: `r02_bench_kernel_stats.csv`.  Top kernels:", "", t, ""]
+b = os.path.join(G, "r02_stats_bench_headline", "s_kernel_stats.csv")
+if os.path.exists(b):
+    shutil.copy(b, os.path.join(P, "r02_bench_headline_kernel_stats.csv"))
+    t, _ = stats(b, 16)
+    md += ["## `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --legs none --cpu-rows 0 --gc-steps 0`  (the headline job only: "
+           "every `k_clip_quad<2>` / `k_apply_il` launch here is a C384 -> 1440x720 one, so the averages are the ones the bench line's `roofline` quotes)", "",
+           "Full CSV: `r02_bench_headline_kernel_stats.csv`.", "", t, ""]
 for tag, title in (("search", "python3 scripts/prof_step.py 10 legacy  (search + finalize + order-2 sweep)"),
+                   ("gc", "python3 scripts/prof_step.py 10 gc  (great-circle search + finalize + order-1 sweep, C384 -> 1440x720)"),
                    ("sweep", "python3 scripts/prof_step.py 10 sweep  (order-2 level-major, order-2 interleaved, order-1 level-major sweeps)")):
     f = os.path.join(G, f"r02_stats_{tag}", "s_kernel_stats.csv")
     if os.path.exists(f):
@@ -54,6 +62,11 @@ md += ["## PMC passes, search (`scripts/prof_pmc2.sh`: one counter group per run
        "FETCH_SIZE / WRITE_SIZE in KB per dispatch (mean).  FETCH_SIZE counts a 128-byte fabric request as 64 bytes on gfx950 (see the sweep "
        "section: the by-size counters prove it), so read bytes = 2 x FETCH_SIZE for these kernels.", "",
        table(ms, ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"]), ""]
+mg = pmc(["gc_fetch", "gc_write", "gc_sq"])
+if mg:
+    md += ["## PMC passes, great-circle search (`prof_step.py 3 gc`)", "",
+           table(mg, ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"],
+                 keys=[k for k in sorted(mg, key=lambda k: -mg[k].get("SQ_WAVE_CYCLES", 0)) if k.startswith("k_gc")]), ""]
 mw = pmc(["sweep_fetch", "sweep_write", "sweep_rd", "sweep_l2", "sweep_wr", "sweep_sq"])
 keys = [k for k in mw if k.startswith(("k_apply_il", "k_interleave3", "k_merge3"))]
 md += ["## PMC passes, sweep: what the fabric counters really count", "",
@@ -70,24 +83,30 @@ for k in keys:
     wr = 64 * c.get("TCC_EA0_WRREQ_64B_sum", 0) / 1e6
     hit = c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))
     lines.append(f"| `{k}` | {rd:.1f} | {c['TCC_EA0_RDREQ_sum'] * 64 / 1e6:.1f} | {wr:.1f} | {hit:.2f} |")
-    if k in ("k_apply_il<2, 8, 4, true>", "k_apply_il<2, 8, 2, true>"):
+    if k.startswith("k_apply_il<2, 8, 4, true"):
         traffic["k_apply"] = (rd + wr) * 1e6
 md += ["Bytes from the by-size request counters (exact on the calibration kernel: 56.6 MB read, 56.6 MB written):", "", "\n".join(lines), "",
        "Reading: nearly every fabric read is a 128-byte request, FETCH_SIZE books it as 64 bytes -- the guide's 2x correction holds for the "
-       "sweep too.  `k_apply_il<2,8,2,MERGED>` moves 538 MB in + 66 MB out per launch against 369 MB algorithmic (1.64x): the gathered source "
-       "records are fetched by more than one XCD (L2 hit rate 0.41).  Those re-fetches are served by the Infinity Cache (the 170 MB record array "
-       "fits), which the fabric counters include; an XCD-banded row mapping that removes them is SLOWER (scripts/apply_ab.py: 0.110 vs 0.096 ms).", ""]
+       "sweep too.  The order-2 sweep on records (`k_apply_il<2,8,4,MERGED>`) has 369 MB of algorithmic traffic per launch (133 MB CSR records, "
+       "170 MB source records, 66 MB output); what it really moves depends on the tile -> XCD mapping, because neighbouring destination rows "
+       "share source records and each XCD has its own L2 (separate PMC passes, `scripts/prof_xcd.sh`, two levels per lane): tiles in row order 532 MB "
+       "read, L2 hit rate 0.42, 0.0966 ms; chunks of 64 tiles per XCD (the default) 384 MB, 0.56, 0.0936 ms; one band per XCD 314 MB, 0.63, "
+       "0.1105 ms.  Less traffic is NOT faster in proportion: the kernel is bound by the latency of its dependent gathers at the occupancy it "
+       "has (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.68; ~12 us per wave, 8 waves per SIMD), not by HBM or fabric bytes.  The table above is the "
+       "shipped configuration (four levels per lane, chunked tiles): 355 MB read + 66 MB written = 1.14x the algorithmic bytes, L2 hit rate 0.61, "
+       "0.0875 ms back to back (`scripts/apply_ab.py`), 0.090 ms per launch by HIP events in `bench.py`, 0.099 ms per dispatch under rocprofv3 "
+       "(which serialises dispatches with a cache write-back inside its timestamps).", ""]
 k = "k_clip_quad<2>"
 if k in ms and "FETCH_SIZE" in ms[k] and "WRITE_SIZE" in ms[k]:
     traffic["k_clip_quad"] = (2 * ms[k]["FETCH_SIZE"] + ms[k]["WRITE_SIZE"]) * 1024.0
 if k in ms and "SQ_INSTS_VALU" in ms[k]:
     traffic["k_clip_quad_valu_insts"] = ms[k]["SQ_INSTS_VALU"]
-old = json.load(open(os.path.join(P, "pmc_traffic.json")))
-if "k_gc_clip" in old:
-    traffic["k_gc_clip"] = old["k_gc_clip"]
+for kk in ("k_gc_walk", "k_gc_solve", "k_gc_screen"):
+    if kk in mg and "FETCH_SIZE" in mg[kk] and "WRITE_SIZE" in mg[kk]:
+        traffic[kk] = (2 * mg[kk]["FETCH_SIZE"] + mg[kk]["WRITE_SIZE"]) * 1024.0
 traffic["round"] = "round 2"
 traffic["_note"] = ("HBM-side bytes per launch from rocprofv3 PMC, C384 -> 1440x720: k_apply from the by-size fabric request counters "
-                    "(TCC_EA0_RDREQ_{32,64,128}B, TCC_EA0_WRREQ_64B); k_clip_quad = 2*FETCH_SIZE + WRITE_SIZE; k_gc_clip from round 1; "
+                    "(TCC_EA0_RDREQ_{32,64,128}B, TCC_EA0_WRREQ_64B); k_clip_quad and the k_gc_* kernels = 2*FETCH_SIZE + WRITE_SIZE; "
                     "see profiles/r02_summary.md")
 json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 bt = os.path.join(G, "r02_band_time.txt")
