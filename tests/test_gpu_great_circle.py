@@ -202,3 +202,72 @@ def test_three_pass_clip_equals_the_one_kernel_clip(fg, gpu_ok, ni, nlon, nlat):
         assert sa["below"] == sb["below"] and sa["borderline"] == sb["borderline"]
     assert res[1][1]["deferred"] < 0.1 * sa["pairs"] + 4000   # pole cells, tile-edge cells on lat-lon lines, snapped intersections
     assert res[3][1]["deferred"] > 0.1 * sa["pairs"]          # the overflow path really ran
+
+
+def _rotated(lon, lat, ax, ang):
+    """corner arrays rotated about the unit axis `ax` by `ang` (a curvilinear grid whose edges cross everything at odd angles)"""
+    x, y, z = np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)
+    v = np.stack([x, y, z], -1)
+    ax = np.asarray(ax, float) / np.linalg.norm(ax)
+    c, s = np.cos(ang), np.sin(ang)
+    r = v * c + np.cross(ax, v) * s + ax * (v @ ax)[..., None] * (1 - c)
+    lo = np.arctan2(r[..., 1], r[..., 0])
+    lo[lo < 0] += 2 * np.pi
+    return np.ascontiguousarray(lo), np.ascontiguousarray(np.arcsin(np.clip(r[..., 2], -1, 1)))
+
+
+def test_three_pass_clip_on_awkward_grid_pairs(fg, gpu_ok):
+    """Pairs of grids chosen to sit on the branches of the three-pass clip: edges and corners that almost coincide (shifts of
+    1e-9 .. 1e-5 rad: snapped, nearly snapped and borderline-inside cases), generic crossings at odd angles (rotated grids),
+    coarse against fine, tripolar folds, regional windows.  Three passes == one-kernel clip bit for bit; the small cases also
+    against the oracle."""
+    lo72, la72 = fg.latlon_corners(72, 36)
+    reg = fg.latlon_corners(40, 30, 20.0, 100.0, -35.0, 40.0)
+    c16 = fg.gnomonic_ed_corners(16)
+    tri = fg.tripolar_corners(60, 40)
+    cases = []
+    for sh in (1e-9, 3e-8, 1e-6, 1e-5):
+        cases.append((72, 36, 72, 36, lo72, la72, np.ascontiguousarray(lo72 + sh), la72))
+    cases.append((40, 30, 40, 30) + reg + _rotated(*reg, (0.3, -0.5, 0.8), 0.37))
+    cases.append((72, 36, 40, 30, lo72, la72) + _rotated(*reg, (1.0, 0.2, 0.1), 1.1))
+    cases.append((16, 16, 40, 30, c16[0][1], c16[1][1]) + reg)
+    cases.append((16, 16, 16, 16, c16[0][0], c16[1][0]) + _rotated(c16[0][0], c16[1][0], (0.1, 0.9, 0.4), 0.05))
+    cases.append((60, 40, 72, 36) + tri + (lo72, la72))
+    def run(args):
+        """plan API (errors come back as exceptions instead of the reference's exit): (xgrid dict | None, message)"""
+        nxi, nyi, nxo, nyo, loi, lai, loo, lao = args
+        try:
+            plan = fg.XgridPlan.create_great_circle([fg.GridConfig(nxi, nyi, loi, lai)], fg.GridConfig(nxo, nyo, loo, lao))
+        except Exception as e:                       # the reference's own fatal checks (mpp_error) on this input
+            return None, str(e)
+        x = plan.get_xgrid() if plan.nxgrid else {"area": np.zeros(0)}
+        plan.destroy()
+        return x, ""
+
+    nok = 0
+    for ci, args in enumerate(cases):
+        outs = []
+        try:
+            for split in (0, 1):
+                fg.lib().fg_set_gc_split(split)
+                outs.append(run(args))
+        finally:
+            fg.lib().fg_set_gc_split(1)
+        (a, ea), (b, eb) = outs
+        assert ea == eb, (ci, ea, eb)                # same fatal check, same message -- or none
+        if a is None:
+            continue
+        nok += 1
+        assert len(a["area"]) == len(b["area"]), ci
+        if len(a["area"]) == 0:
+            continue
+        for k in ("i_in", "j_in", "i_out", "j_out"):
+            assert np.array_equal(a[k], b[k]), (ci, k)
+        assert np.array_equal(_bits(a["area"]), _bits(b["area"])), ci
+        if args[0] * args[1] * args[2] * args[3] <= 40 * 30 * 40 * 30:
+            o = orc.orc_create_xgrid_gc(*args)
+            assert len(b["area"]) == o["n"], ci
+            assert np.array_equal(b["i_in"], o["i_in"]) and np.array_equal(b["j_in"], o["j_in"]), ci
+            assert np.array_equal(b["i_out"], o["i_out"]) and np.array_equal(b["j_out"], o["j_out"]), ci
+            assert np.max(np.abs(b["area"] - o["area"]) / o["area"]) < RTOL, ci
+    assert nok >= 5
