@@ -538,7 +538,7 @@ def main():
         # sweep: weights streamed once per launch of nz levels + per level the source fields and the output
         alg_apply = 32.0 * nx_rank0 + nb * (24.0 * ncell_in + 8.0 * nlon * ny_band)
         sweep_ms = rec_kernel_ms if rec_kernel_ms > 0 else apply_kernel_ms
-        roof_a = {"kernel": f"k_apply_il<2,{nb},4,MERGED>" if rec_kernel_ms > 0 else f"k_apply_il<2,{nb}>", "bound": "hbm",
+        roof_a = {"kernel": ("k_apply_ep8<256,256>" if nb == 8 else f"k_apply_il<2,{nb},4,MERGED>") if rec_kernel_ms > 0 else f"k_apply_il<2,{nb}>", "bound": "hbm",
                   "achieved": (alg_apply / 1e9) / (sweep_ms / 1e3) if sweep_ms > 0 else None,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                   "algorithmic_bytes_per_launch": alg_apply, "kernel_ms": sweep_ms, "levels_per_launch": nb,

@@ -490,6 +490,112 @@ __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const dou
     *reinterpret_cast<VecD<V> *>(out + (size_t)d * NB + lev) = r;
 }
 
+// Entry-parallel order-2 sweep on merged records, 8 levels: the gathers of ALL of a tile's exchange cells are issued in one go
+// (a lane pair per exchange cell, up to three per lane pair), the products area * (f + gx di + gy dj) go to LDS, and a lane group
+// per destination row adds them in CSR order -- the same operations in the same order as k_apply_il, so the same bits, but a
+// wave's dependent chain is row pointers -> CSR staging -> ONE round of gathers -> LDS sums instead of ~7 gather rounds.
+// A tile whose rows hold more than EP_CAP exchange cells (fine -> coarse remaps) takes the row-serial loop.
+#define EP_ROWS 32
+template <int TPB, int CAP>
+__global__ __launch_bounds__(TPB) void k_apply_ep8(int ndst, FgCsr csr, const double *rec, double missing, double *out, double *row_sum,
+                                                    long out_ld, int nb_valid, int xcd_band)
+{
+  constexpr int NB = 8;
+  constexpr int LPR = TPB / EP_ROWS, LV = NB / LPR;      // sum phase: LPR lanes per row, LV levels each
+  constexpr int EPP = TPB / 2, PASS = CAP / EPP;          // gather phase: a lane pair per exchange cell, EPP cells per pass
+  // one buffer: the staged CSR records first, then (once every lane holds its records in registers) the products and areas
+  __shared__ __attribute__((aligned(16))) double sh_raw[CAP * (NB + 1)];
+  FgCsrEntry2 *sh_e = reinterpret_cast<FgCsrEntry2 *>(sh_raw);
+  double *sh_p = sh_raw, *sh_a = sh_raw + CAP * NB;
+  const int t = threadIdx.x;
+  const int d0 = d_xcd_block(blockIdx.x, gridDim.x, xcd_band) * EP_ROWS;
+  const int dl = min(d0 + EP_ROWS, ndst);
+  const int q0 = csr.row_ptr[d0], q1 = csr.row_ptr[dl];
+  const int d = d0 + t / LPR, lev = (t % LPR) * LV;
+  const int dc = min(d, ndst - 1);
+  const int b = csr.row_ptr[dc], e = csr.row_ptr[dc + 1];
+  const int n = q1 - q0, nst = min(n, CAP);
+  {
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v *g = reinterpret_cast<const u4v *>(csr.e2 + q0);
+    u4v *l = reinterpret_cast<u4v *>(sh_e);
+    for (int i = t; i < nst * 2; i += TPB) l[i] = __builtin_nontemporal_load(g + i);
+  }
+  __syncthreads();
+  double acc[LV], asum = 0.0;
+#pragma unroll
+  for (int k = 0; k < LV; k++) acc[k] = 0.0;
+  if (n <= CAP) {
+    const int h = (t & 1) * 4;                             // four levels per lane of the pair
+    VecD<4> fv[PASS], gxv[PASS], gyv[PASS];
+    FgCsrEntry2 E[PASS];
+#pragma unroll
+    for (int j = 0; j < PASS; j++) {
+      if (EPP * j < n) {                                   // (block-uniform)
+        const int i = min(t / 2 + EPP * j, n - 1);
+        E[j] = sh_e[i];
+        const double *pf = rec + (size_t)E[j].idx_g * (3 * NB) + h;
+        fv[j] = *reinterpret_cast<const VecD<4> *>(pf);
+        gxv[j] = *reinterpret_cast<const VecD<4> *>(pf + NB);
+        gyv[j] = *reinterpret_cast<const VecD<4> *>(pf + 2 * NB);
+      }
+    }
+    __syncthreads();                                       // the records are in registers: the buffer becomes the product table
+#pragma unroll
+    for (int j = 0; j < PASS; j++) {
+      const int i = t / 2 + EPP * j;
+      if (EPP * j < n && i < n) {
+        VecD<4> pv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          double v = (fv[j].v[k] + gxv[j].v[k] * E[j].di + gyv[j].v[k] * E[j].dj);
+          pv.v[k] = v * E[j].area;
+        }
+        *reinterpret_cast<VecD<4> *>(sh_p + i * NB + h) = pv;
+        if (h == 0) sh_a[i] = E[j].area;
+      }
+    }
+    __syncthreads();
+    if (d >= ndst) return;
+    for (int q = b - q0; q < e - q0; q++) {
+      const VecD<LV> pv = *reinterpret_cast<const VecD<LV> *>(sh_p + q * NB + lev);
+#pragma unroll
+      for (int k = 0; k < LV; k++) acc[k] += pv.v[k];
+      asum += sh_a[q];
+    }
+  } else {
+    if (d >= ndst) return;
+    for (int q = b; q < e; q++) {
+      const int ql = q - q0;
+      const FgCsrEntry2 E = (ql < CAP) ? sh_e[ql] : csr.e2[q];
+      const double *pf = rec + (size_t)E.idx_g * (3 * NB) + lev;
+      const VecD<LV> fv = *reinterpret_cast<const VecD<LV> *>(pf);
+      const VecD<LV> gxv = *reinterpret_cast<const VecD<LV> *>(pf + NB);
+      const VecD<LV> gyv = *reinterpret_cast<const VecD<LV> *>(pf + 2 * NB);
+#pragma unroll
+      for (int k = 0; k < LV; k++) {
+        double v = (fv.v[k] + gxv.v[k] * E.di + gyv.v[k] * E.dj);
+        acc[k] += v * E.area;
+      }
+      asum += E.area;
+    }
+  }
+  VecD<LV> r, rs;
+#pragma unroll
+  for (int k = 0; k < LV; k++) {
+    rs.v[k] = (asum > 0) ? acc[k] : 0.0;
+    if (asum > 0) r.v[k] = acc[k] / asum;
+    else if (e > b) r.v[k] = 0.0;
+    else r.v[k] = missing;
+  }
+  if (row_sum) *reinterpret_cast<VecD<LV> *>(row_sum + (size_t)d * NB + lev) = rs;
+  if (out_ld > 0) {
+#pragma unroll
+    for (int k = 0; k < LV; k++) if (lev + k < nb_valid) out[(size_t)(lev + k) * out_ld + d] = r.v[k];
+  } else
+    *reinterpret_cast<VecD<LV> *>(out + (size_t)d * NB + lev) = r;
+}
+
 // [nb][n] (level-major, row stride ld) <-> [n][NB] interleaved
 template <int NB>
 __global__ __launch_bounds__(256) void k_interleave(long n, const double *in, long ld, int nb, double *out)
@@ -681,6 +787,7 @@ static void apply_il_nb(int order, int ndst, FgCsr csr, const double *f, const d
 // out_ld for the first nb_valid levels (else interleaved [cell][nb])
 int g_apply_xcd = 64;  // d_xcd_block: 0 identity, 1 one band per XCD, C >= 2 chunks of C tiles per XCD (measured on the 1440x720 sweep,
                        // 8 levels merged records: 0.0936 ms with C = 32..256, 0.0966 identity, 0.1105 banded)
+int g_apply_ep = 1;    // entry-parallel kernel for 8-level sweeps on records (k_apply_ep8): 0.0832 against 0.0872 ms (1440x720 x 8 levels)
 int g_apply_vec = 0;   // levels per lane: 0 = auto (4 for nb >= 8, else 2: with chunked tiles 0.0986 against 0.1010 ms on interleaved arrays,
                        // 0.0875 against 0.0937 on records, 1440x720 x 8 levels), or force 1 / 2 / 4
 void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
@@ -698,12 +805,14 @@ void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const
 #undef AP
 }
 // order-2 sweep on merged records (k_merge3); same arguments otherwise
-void fgd_apply_il_merged(int nb, int ndst, FgCsr csr, const double *rec, double missing, double *out, double *row_sum, long out_ld,
+void fgd_apply_il_merged(int nb, int ndst, long nx, FgCsr csr, const double *rec, double missing, double *out, double *row_sum, long out_ld,
                          int nb_valid, hipStream_t st)
 {
   if (ndst <= 0) return;
 #define APM(NB_, V_) k_apply_il<2, NB_, V_, true><<<nblk(ndst, 256 / (NB_ / V_)), 256, 0, st>>>(ndst, csr, rec, nullptr, nullptr, missing, out, row_sum, out_ld, nb_valid, g_apply_xcd)
   if (nb == 16) APM(16, 4);
+  else if (nb == 8 && g_apply_ep && nx <= 6L * ndst)       // rows of ~4 exchange cells: a tile's cells fit the product table
+    k_apply_ep8<256, 256><<<nblk(ndst, EP_ROWS), 256, 0, st>>>(ndst, csr, rec, missing, out, row_sum, out_ld, nb_valid, g_apply_xcd >= 2 ? 2 * g_apply_xcd : g_apply_xcd);
   else if (nb == 8) { if (g_apply_vec == 2) APM(8, 2); else APM(8, 4); }   // 4 levels per lane: 0.0875 ms against 0.0936 with 2 (1440x720, 8 levels, chunked tiles)
   else if (nb == 4) APM(4, 2);
   else APM(2, 2);

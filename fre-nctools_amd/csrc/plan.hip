@@ -1207,7 +1207,8 @@ extern "C" int fg_plan_set_xgrid(fg_plan *pl, long nxgrid, const int *t_in, cons
   return 0;
 }
 
-extern int g_apply_vec;
+extern int g_apply_vec, g_apply_ep;
+extern "C" void fg_set_apply_ep(int on) { g_apply_ep = on ? 1 : 0; }     // tuning hook: entry-parallel 8-level sweep on records
 
 extern int g_apply_xcd;
 extern "C" void fg_set_apply_xcd(int on) { g_apply_xcd = on < 0 ? 0 : on; }       // tuning hook: tile -> XCD mapping of the sweep (0 identity, 1 banded, C >= 2 chunked)
@@ -1269,7 +1270,7 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
       if (pl->order == 2) {
         // field + gradients of the chunk -> one record per source cell, then the sweep writes level-major directly
         fgd_merge3(nbp, pl->nsrc, pl->src_idx_f, f, pl->f_stride, gx, gy, pl->nsrc, nbv, pl->il_m, st);
-        fgd_apply_il_merged(nbp, ndst, pl->csr, pl->il_m, miss, o, rs, (long)ndst, nbv, st);
+        fgd_apply_il_merged(nbp, ndst, pl->nx, pl->csr, pl->il_m, miss, o, rs, (long)ndst, nbv, st);
       } else {
         const double *ins[3] = {f, nullptr, nullptr};
         double *outs[3] = {pl->il_f, nullptr, nullptr};
@@ -1310,7 +1311,7 @@ extern "C" int fg_plan_apply_records(fg_plan *pl, int nz, const double *rec, dou
   }
   pl->apply_pt.start(g_profiling != 0 && pl->apply_spans < 256, st);     // (a long sweep loop must not pile up timing events)
   pl->apply_pt.begin(PH_APPLY);
-  fgd_apply_il_merged(nbp, ndst, pl->csr, rec, -1.e20, out, gsum_out ? pl->il_rs : nullptr, (long)ndst, nz, st);
+  fgd_apply_il_merged(nbp, ndst, pl->nx, pl->csr, rec, -1.e20, out, gsum_out ? pl->il_rs : nullptr, (long)ndst, nz, st);
   if (gsum_out) fgd_reduce_sum(pl->il_rs, (long)ndst * nbp, pl->red_partial, pl->red_result, st);
   pl->apply_pt.end();
   if (pl->apply_pt.on) pl->apply_spans++;

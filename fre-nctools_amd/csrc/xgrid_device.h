@@ -175,7 +175,7 @@ void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *g
 void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
                   double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st);
 void fgd_interleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st);
-void fgd_apply_il_merged(int nb, int ndst, FgCsr csr, const double *rec, double missing, double *out, double *row_sum, long out_ld,
+void fgd_apply_il_merged(int nb, int ndst, long nx, FgCsr csr, const double *rec, double missing, double *out, double *row_sum, long out_ld,
                          int nb_valid, hipStream_t st);
 void fgd_merge3(int nb_pad, long n, const int *src_idx_f, const double *f, long ld_f, const double *gx, const double *gy, long ld_g,
                 int nb_valid, double *out, hipStream_t st);

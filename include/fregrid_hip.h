@@ -307,6 +307,9 @@ void fg_set_search_chunks(int chunks);
  * rank of a banded multi-GPU job meets a fraction of the source cells); fg_plan_get_cell_area / _cell_struct then return 0 /
  * unspecified values for those cells.  The exchange cells are unchanged.  Default 0. */
 void fg_set_search_cull(int on);
+/* Sweep tuning hook: 1 (default) = 8-level order-2 sweeps on merged records use the entry-parallel kernel when rows are short
+ * (nxgrid <= 6 x destination cells), 0 = always the row-serial kernel.  Results do not depend on it. */
+void fg_set_apply_ep(int on);
 /* Sweep tuning hook: levels per lane (1, 2 or 4; 0 = automatic).  Results do not depend on it. */
 void fg_set_apply_vec(int v);
 /* Great-circle search: 1 (default) = the clip runs as three passes (screen / extended-precision solves / walk) with the

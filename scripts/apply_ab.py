@@ -21,8 +21,8 @@ for nb in (8, 16):
     data = h2d(rng.standard_normal((6 * (ni + 2) ** 2, nb))); gx = h2d(rng.standard_normal((ncell, nb))); gy = h2d(rng.standard_normal((ncell, nb)))
     out = torch.empty(nlon * nlat, nb, dtype=torch.float64, device=dev)
     rec = h2d(rng.standard_normal((ncell, 3, 8))); outl = torch.empty(8, nlon * nlat, dtype=torch.float64, device=dev)
-    for xcd in (64, 642, 644):
-        L.fg_set_apply_xcd(64); L.fg_set_apply_vec({64: 0, 642: 2, 644: 4}[xcd])
+    for xcd in (64, 991, 64, 991):
+        L.fg_set_apply_xcd(64); L.fg_set_apply_ep(1 if xcd > 990 else 0)
         for name, fn in (("il", lambda: p.apply_interleaved(nb, data, out, gx, gy)), ("rec", lambda: p.apply_records(8, rec, outl))):
             if name == "rec" and nb != 8: continue
             for _ in range(5): fn()
@@ -33,8 +33,9 @@ for nb in (8, 16):
     ref = out.clone()
 for k, v in sorted(res.items()): print(k, ["%.4f" % x for x in v])
 # same bits either way
-L.fg_set_apply_xcd(0); p.apply_records(8, rec, outl); p.sync(); a = outl.clone()
+L.fg_set_apply_ep(0); L.fg_set_apply_xcd(0); p.apply_records(8, rec, outl); p.sync(); a = outl.clone()
+L.fg_set_apply_ep(1); p.apply_records(8, rec, outl); p.sync(); print('ep bitwise equal:', bool(torch.equal(a, outl)))
 L.fg_set_apply_xcd(1); p.apply_records(8, rec, outl); p.sync(); b1 = outl.clone()
 L.fg_set_apply_xcd(64); p.apply_records(8, rec, outl); p.sync()
 print("bitwise equal:", bool(torch.equal(a, outl)))
-L.fg_set_apply_xcd(64); L.fg_set_apply_vec(0)
+L.fg_set_apply_xcd(64); L.fg_set_apply_vec(0); L.fg_set_apply_ep(1)

@@ -475,6 +475,46 @@ def test_sweep_tile_mapping_keeps_the_bits(fg, gpu_ok):
         assert np.array_equal(o, outs[0])
 
 
+@pytest.mark.parametrize("ni,nlon,nlat", [(48, 360, 180), (96, 90, 45), (24, 1440, 720), (96, 360, -1)])
+def test_entry_parallel_sweep_keeps_the_bits(fg, gpu_ok, ni, nlon, nlat):
+    """fg_set_apply_ep: the entry-parallel 8-level order-2 sweep (products through LDS, row sums in CSR order) against the
+    row-serial kernel, on similar cells, on fine -> coarse (rows of ~20 exchange cells: the host keeps the row-serial kernel,
+    or a tile overflows the product table and takes the row-serial loop inside the kernel) and on coarse -> fine."""
+    import torch
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    if nlat > 0:
+        lo, la = fg.latlon_corners(nlon, nlat)
+    else:
+        # tall cells in the south (12 exchange cells per row), short ones in the north (3): 4.3 on average, so the entry-parallel
+        # kernel is chosen and its southern tiles overflow the product table
+        edges = np.deg2rad(np.concatenate([np.linspace(-90.0, 0.0, 20), np.linspace(0.0, 90.0, 161)[1:]]))
+        nlat = edges.size - 1
+        lo, la = np.meshgrid(np.linspace(0.0, 2 * np.pi, nlon + 1), edges)
+        lo, la = np.ascontiguousarray(lo), np.ascontiguousarray(la)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    p = fg.XgridPlan.create(2, grids, fg.GridConfig(nlon, nlat, lo, la))
+    p.finalize()
+    if nlon == 360 and ni == 96:
+        assert p.nxgrid <= 6 * nlon * nlat and p.nxgrid > 3.5 * nlon * nlat
+    rng = np.random.default_rng(12)
+    nc = 6 * ni * ni
+    src = torch.from_numpy(rng.standard_normal((8, 6 * (ni + 2) ** 2))).to("cuda:0")
+    gx = torch.from_numpy(rng.standard_normal((8, nc))).to("cuda:0")
+    gy = torch.from_numpy(rng.standard_normal((8, nc))).to("cuda:0")
+    outs = []
+    try:
+        for ep in (0, 1):
+            fg.lib().fg_set_apply_ep(ep)
+            out = torch.full((8, nlon * nlat), np.nan, dtype=torch.float64, device="cuda:0")
+            p.apply(src, out, nz=8, grad_x_t=gx, grad_y_t=gy); p.sync()
+            outs.append(out.cpu().numpy())
+    finally:
+        fg.lib().fg_set_apply_ep(1)
+        p.destroy()
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_bin_record_overflow_falls_back_to_exact_mode(fg, gpu_ok):
     """Bins no larger than the target cells (the caller's mean cell size is an input): every target cell then spans four bin
     rows, lands in the per-row wide lists four times and the single-sync search's record buffer (3 per target cell) is too
