@@ -572,7 +572,8 @@ def main():
                                    "exchange-grid search + centroid pass + CSR build per step",
                        "nxgrid": nx_total, "parallelism": f"{world} latitude band(s) of the target, one per GPU", "world_size": world,
                        "exchange": (None if world == 1 else f"all-reduce of the (area, clon, clat) sums of the {int(bidx_t.numel())} source "
-                                    f"cells cut by band boundaries ({100.0 * int(bidx_t.numel()) / ncell_in:.1f} % of {ncell_in})")},
+                                    f"cells cut by band boundaries ({100.0 * int(bidx_t.numel()) / ncell_in:.1f} % of {ncell_in}): partial sums, one collective; "
+                                    f"setup_conserve_interp's default hands running sums from rank to rank instead (bit-reproducible, parallel.ordered_cell_sums)")},
             "remapped_points_per_s": remap_pts, "apply_ms_per_call": dta / apply_steps * 1e3, "apply_levels": nz,
             "apply_device_ms_per_call": apply_call_ms,
             "remapped_points_per_s_interleaved": apply_steps * ndst * nb / dtb,

@@ -239,6 +239,13 @@ class XgridPlan:
     def copy_cell_sums(self, dst_t):
         check(lib().fg_plan_copy_cell_sums(self._h, C.c_void_p(dst_t.data_ptr())))
 
+    def accumulate_cell_sums(self, total_t, cells_t=None):
+        """total_t[3, ncells_in] += this plan's exchange cells, one by one in exchange-cell order, continuing from the values
+        already there (conserve_interp.c:203-221); cells_t: int32 device tensor restricting the update to those source cells."""
+        check(lib().fg_plan_accumulate_cell_sums(self._h, C.c_void_p(total_t.data_ptr()),
+                                                 C.c_void_p(cells_t.data_ptr()) if cells_t is not None else None,
+                                                 int(cells_t.numel()) if cells_t is not None else 0))
+
     def stats(self):
         s = (C.c_long * 10)()
         check(lib().fg_plan_stats(self._h, s, 10))
@@ -432,16 +439,8 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
                 g.cell_area = a_in[off:off + g.nx * g.ny].copy()
                 off += g.nx * g.ny
     if order == 2:
-        ncell = plans[0].ncells_in
-        total = torch.zeros(3 * ncell, dtype=torch.float64, device=f"cuda:{device}")
-        for p in plans:
-            part = torch.empty_like(total)
-            p.copy_cell_sums(part)
-            total += part
-        from .parallel import allreduce_cell_sums
-        allreduce_cell_sums(total)              # the one exchange step of the path; bench.py restricts it to the
-                                                # source cells cut by band boundaries (parallel.boundary_source_cells)
-        torch.cuda.synchronize(device)
+        from .parallel import ordered_cell_sums
+        total = ordered_cell_sums(plans, device)   # the one exchange step of the path, in the reference's order
         for p in plans:
             p.finalize(total.data_ptr())
     else:

@@ -120,6 +120,25 @@ extern "C" int fg_dev_download(void *dst_host, const void *src_dev, size_t bytes
   if (bytes) HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
   return 0;
 }
+// dst_dev[i] = src_dev[idx_dev[i]] / dst_dev[idx_dev[i]] = src_dev[i], i < n: moving a short list of source cells in and out of the
+// [3][ncells] sum arrays (integration/conserve_interp_hip.c hands the shared cells' running sums from rank to rank with them)
+__global__ __launch_bounds__(256) void k_gather_f64(long n, double *dst, const double *src, const int *idx, int scatter)
+{
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (scatter) dst[idx[i]] = src[i]; else dst[i] = src[idx[i]];
+}
+static int dev_gather(double *dst_dev, const double *src_dev, const int *idx_dev, long n, int scatter)
+{
+  if (n < 0 || (n > 0 && (!dst_dev || !src_dev || !idx_dev))) return fail(FG_ERR_ARG, "fg_dev_gather_f64 / fg_dev_scatter_f64: bad argument");
+  if (n == 0) return 0;
+  k_gather_f64<<<(unsigned)((n + 255) / 256), 256>>>(n, dst_dev, src_dev, idx_dev, scatter);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+extern "C" int fg_dev_gather_f64(double *dst_dev, const double *src_dev, const int *idx_dev, long n) { return dev_gather(dst_dev, src_dev, idx_dev, n, 0); }
+extern "C" int fg_dev_scatter_f64(double *dst_dev, const double *src_dev, const int *idx_dev, long n) { return dev_gather(dst_dev, src_dev, idx_dev, n, 1); }
 
 // ----------------------------------------------------------------------------- phase timing
 // Optional HIP-event timing of the phases of a search / sweep, recorded on the plan's own
@@ -990,6 +1009,20 @@ extern "C" int fg_plan_copy_cell_sums(fg_plan *pl, double *dst_dev)
   if (pl->order != 2 || !pl->sums) return fail(FG_ERR_STATE, "plan holds no order-2 cell sums");
   HIPCHK(hipSetDevice(pl->device));
   HIPCHK(hipMemcpyAsync(dst_dev, pl->sums, 3 * (size_t)pl->nsrc * sizeof(double), hipMemcpyDeviceToDevice, pl->stream));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  return 0;
+}
+// total_dev[3][ncells_in] (sum of area, of the clon integral, of the clat integral per source cell) += this plan's exchange cells,
+// added one by one in exchange-cell order onto what total_dev already holds; cells_dev (may be null = all) restricts it to a list
+// of source cells.  Before fg_plan_finalize only.
+extern "C" int fg_plan_accumulate_cell_sums(fg_plan *pl, double *total_dev, const int *cells_dev, int ncells)
+{
+  if (!pl || !total_dev) return fail(FG_ERR_ARG, "null argument");
+  if (pl->order != 2 || !pl->searched || pl->finalized || !pl->xoff)
+    return fail(FG_ERR_STATE, "fg_plan_accumulate_cell_sums: needs a searched, not yet finalized order-2 plan");
+  HIPCHK(hipSetDevice(pl->device));
+  if (pl->nx > 0)
+    fgd_accumulate_cell_sums(cells_dev ? ncells : pl->nsrc, cells_dev, pl->nsrc, pl->xoff, pl->x_area, pl->x_c1, pl->x_c2, total_dev, pl->stream);
   HIPCHK(hipStreamSynchronize(pl->stream));
   return 0;
 }

@@ -224,6 +224,9 @@ void fgd_clip_single(const double *lon_in, const double *lat_in, int n_in, doubl
 void fgd_box_ctr(double ll_lon, double ll_lat, double ur_lon, double ur_lat, double clon, double *out, hipStream_t st);
 void fgd_grid_area_no_adjust(int nx, int ny, const double *lon, const double *lat, double *area, hipStream_t st);
 
+void fgd_accumulate_cell_sums(int n, const int *cells, int nsrc, const int *xoff, const double *xa, const double *c1, const double *c2,
+                              double *total, hipStream_t st);
+
 // ---- great-circle path (gc_kernels.hip)
 void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st);
 void fgd_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D,

@@ -1308,3 +1308,26 @@ void fgd_distances(long nx, int nsrc, const int *x_src, const double *x_area, co
 {
   if (nx > 0) k_distances<<<nblk(nx, 256), 256, 0, st>>>(nx, nsrc, x_src, x_area, cen, x_c1, x_c2);
 }
+
+// total[3][nsrc] += this plan's exchange cells, cell by cell in exchange-cell order, CONTINUING from the value already there:
+// conserve_interp.c:203-221 adds the gathered exchange cells of all ranks (and of one output tile after the other) one by one
+// "for the purpose of bitwise reproducing"; a running total handed from plan to plan (and from rank to rank for the cells cut by a
+// band boundary) performs the same additions in the same order.  cells == null: all source cells.
+__global__ __launch_bounds__(256) void k_accumulate_cell_sums(int n, const int *cells, int nsrc, const int *xoff, const double *xa,
+                                                               const double *c1, const double *c2, double *total)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = cells ? cells[i] : i;
+  if (s < 0 || s >= nsrc) return;
+  const int b = xoff[s], e = xoff[s + 1];
+  if (b >= e) return;
+  double a0 = total[s], a1 = total[(size_t)nsrc + s], a2 = total[2 * (size_t)nsrc + s];
+  for (int q = b; q < e; q++) { a0 += xa[q]; a1 += c1[q]; a2 += c2[q]; }
+  total[s] = a0; total[(size_t)nsrc + s] = a1; total[2 * (size_t)nsrc + s] = a2;
+}
+void fgd_accumulate_cell_sums(int n, const int *cells, int nsrc, const int *xoff, const double *xa, const double *c1, const double *c2,
+                              double *total, hipStream_t st)
+{
+  if (n > 0) k_accumulate_cell_sums<<<(n + 255) / 256, 256, 0, st>>>(n, cells, nsrc, xoff, xa, c1, c2, total);
+}

@@ -129,3 +129,80 @@ def allreduce_cell_sums_sparse(total, idx_t, ncells):
     dist.all_reduce(part)
     v[:, idx_t] = part
     return total
+
+
+def _all_reduce(t):
+    """all-reduce (sum) of a device tensor; through host memory when the backend is gloo (CPU rehearsals of the N > 1 path)"""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t)
+    return t
+
+
+def _broadcast(t, src):
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == "gloo":
+        c = t.cpu()
+        dist.broadcast(c, src=src)
+        t.copy_(c)
+    else:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def ordered_cell_sums(plans, device=0):
+    """The per-source-cell (sum area, sum clon, sum clat) of setup_conserve_interp, bit-identical for any number of ranks.
+
+    conserve_interp.c:203-221 gathers the exchange cells of every rank and adds them to the per-cell accumulators one by one --
+    "for the purpose of bitwise reproducing" -- output tile after output tile, rank after rank.  An all-reduce of per-rank
+    partial sums adds the same terms in a different association for the cells that have exchange cells on two ranks (or in two
+    output tiles), so instead ONE running total is handed along: every plan continues the sums where the previous one stopped
+    (fg_plan_accumulate_cell_sums).  Across ranks only the cells present on more than one rank need the hand-over (found with
+    one all-reduce of a presence mask: 0.3 % of the cells for 2 bands of C384); they are passed from rank to rank by broadcasts
+    of that short list, per output tile, in rank order.  Every other cell is complete on its one rank and the final all-reduce
+    adds zeros to it.  Returns the device tensor [3 * ncells_in]; identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    dev = f"cuda:{device}"
+    ncell = plans[0].ncells_in
+    total = torch.zeros(3 * ncell, dtype=torch.float64, device=dev)
+    W = world_size()
+    if W == 1:
+        for p in plans:
+            if p.nxgrid > 0:
+                p.accumulate_cell_sums(total)
+        torch.cuda.synchronize(device)
+        return total
+    rank = dist.get_rank()
+    # source cells with exchange cells on more than one rank
+    mine = torch.zeros(3 * ncell, dtype=torch.float64, device=dev)
+    for p in plans:
+        if p.nxgrid > 0:
+            p.accumulate_cell_sums(mine)
+    present = (mine[:ncell] != 0).to(torch.int32)
+    count = present.clone()
+    _all_reduce(count)
+    shared = torch.nonzero(count > 1).flatten().to(torch.int32)
+    nsh = int(shared.numel())
+    if nsh:
+        idx = shared.long()
+        idx3 = torch.cat([idx, idx + ncell, idx + 2 * ncell])
+        run = torch.zeros(3 * nsh, dtype=torch.float64, device=dev)       # the running sums of the shared cells
+        scratch = torch.zeros(3 * ncell, dtype=torch.float64, device=dev)
+        for p in plans:                                                    # output tile after output tile ...
+            for r in range(W):                                             # ... rank after rank
+                if r == rank and p.nxgrid > 0:
+                    scratch[idx3] = run
+                    p.accumulate_cell_sums(scratch, shared)
+                    run = scratch[idx3].contiguous()
+                _broadcast(run, r)
+        mine[idx3] = 0.0
+    _all_reduce(mine)                                                      # every other cell: its one rank's value + zeros
+    if nsh:
+        mine[idx3] = run
+    torch.cuda.synchronize(device)
+    return mine

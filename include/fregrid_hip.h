@@ -149,6 +149,9 @@ void *fg_dev_alloc(size_t bytes, int device);
 void fg_dev_free(void *p);
 int  fg_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
 int  fg_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+/* dst_dev[i] = src_dev[idx_dev[i]]  /  dst_dev[idx_dev[i]] = src_dev[i]  for i < n (all pointers device memory of the current device) */
+int  fg_dev_gather_f64(double *dst_dev, const double *src_dev, const int *idx_dev, long n);
+int  fg_dev_scatter_f64(double *dst_dev, const double *src_dev, const int *idx_dev, long n);
 
 /* Give back the surplus of the capacity-sized exchange-cell arrays (8*max(nsrc, ndst) entries -> nxgrid entries; device-to-device
  * copies).  For callers that keep many plans resident.  Any state after the search. */
@@ -169,6 +172,12 @@ int  fg_plan_device(const fg_plan *plan);
 double *fg_plan_cell_sums_dev(fg_plan *plan);
 /* copy those sums into a caller-owned DEVICE buffer of 3*ncells_in doubles (e.g. a torch tensor) */
 int fg_plan_copy_cell_sums(fg_plan *plan, double *dst_dev);
+/* total_dev[3][ncells_in] += this plan's exchange cells, added one by one in exchange-cell order onto the values already there
+ * (conserve_interp.c:203-221 adds the exchange cells of all output tiles and all ranks in that order "for the purpose of
+ * bitwise reproducing"): hand one running total from plan to plan, and from rank to rank for the source cells that have
+ * exchange cells on more than one rank.  cells_dev (device, may be NULL = every source cell) restricts the update to a list
+ * of source cells.  Order-2 plans, after the search and before fg_plan_finalize. */
+int fg_plan_accumulate_cell_sums(fg_plan *plan, double *total_dev, const int *cells_dev, int ncells);
 
 /*
  * Turn (clon, clat) into distances from the source-cell centroid

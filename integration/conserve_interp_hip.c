@@ -8,7 +8,7 @@
  *   setup_conserve_interp       conserve_interp.c:42-503
  *       READ   (:62-126)   remap file -> Interp_config + a resident plan (fg_remap_read, fg_plan_set_xgrid)
  *       compute(:127-367)  fg_plan_create[_great_circle] per output tile over ALL input tiles at once, per-source-cell sums
- *                          summed over ranks with mpp_sum_double (the reference gathers them, :203-221), fg_plan_finalize
+ *                          accumulated in the reference's order over output tiles and ranks (:203-221), fg_plan_finalize
  *                          (centroid pass :319-358), Interp_config arrays malloc'ed as the reference leaves them
  *       WRITE  (:368-445)  mpp_gather_field_* to the root PE, fg_remap_write_interp
  *       CHECK_CONSERVE (:450-490) the area check, verbatim semantics
@@ -136,23 +136,55 @@ void setup_conserve_interp(int ntiles_in, const Grid_config *grid_in, int ntiles
       if (nx < 0) hip_fatal("setup_conserve_interp");
     }
     if (order == 2) {
-      /* per-source-cell (area, clon, clat) summed over the output tiles and over the ranks (:203-221 gathers the exchange
-       * cells and adds them on every rank; mpp_sum_double adds the same terms rank by rank) */
+      /* per-source-cell (area, clon, clat): :203-221 gathers the exchange cells of every rank and adds them to the accumulators
+       * one by one, output tile after output tile, "for the purpose of bitwise reproducing".  One running total handed from
+       * plan to plan (fg_plan_accumulate_cell_sums continues from the values it finds) does the same additions in the same
+       * order; across ranks only the source cells that have exchange cells on more than one rank need the hand-over. */
       const size_t nsum = 3 * (size_t)ncells_in;
-      double *tot = (double *)calloc(nsum, sizeof(double)), *part = (double *)malloc(nsum * sizeof(double));
+      double *tot = (double *)calloc(nsum, sizeof(double));
       double *d_tot = (double *)fg_dev_alloc(nsum * sizeof(double), dev);
-      if (!tot || !part || !d_tot) hip_fatal("setup_conserve_interp");
-      for (n = 0; n < ntiles_out; n++) {
-        if (fg_plan_copy_cell_sums(plans[n], d_tot) || fg_dev_download(part, d_tot, nsum * sizeof(double))) hip_fatal("setup_conserve_interp");
-        for (i = 0; i < nsum; i++) tot[i] += part[i];
-      }
+      if (!tot || !d_tot || fg_dev_upload(d_tot, tot, nsum * sizeof(double))) hip_fatal("setup_conserve_interp");
+      for (n = 0; n < ntiles_out; n++)
+        if (fg_plan_nxgrid(plans[n]) > 0 && fg_plan_accumulate_cell_sums(plans[n], d_tot, NULL, 0)) hip_fatal("setup_conserve_interp");
       if (mpp_npes() > 1) {
+        const int npes = mpp_npes(), pe = mpp_pe() - mpp_root_pe();
+        int *cnt = (int *)calloc((size_t)ncells_in, sizeof(int)), *sh, nsh = 0, r, c, k;
         if (nsum > 0x7fffffff) mpp_error("setup_conserve_interp(hip): too many source cells for one mpp_sum_double");
-        mpp_sum_double((int)nsum, tot);
+        if (!cnt || fg_dev_download(tot, d_tot, nsum * sizeof(double))) hip_fatal("setup_conserve_interp");
+        for (i = 0; i < (size_t)ncells_in; i++) cnt[i] = tot[i] != 0;
+        mpp_sum_int((int)ncells_in, cnt);
+        for (i = 0; i < (size_t)ncells_in; i++) if (cnt[i] > 1) nsh++;
+        sh = (int *)malloc(((size_t)nsh + 1) * sizeof(int));
+        for (i = 0, nsh = 0; i < (size_t)ncells_in; i++) if (cnt[i] > 1) sh[nsh++] = (int)i;
+        if (nsh > 0) {                      /* the shared cells: rank after rank within an output tile, tile after tile */
+          double *run = (double *)calloc(3 * (size_t)nsh, sizeof(double));
+          int *d_sh = (int *)fg_dev_alloc((size_t)nsh * sizeof(int), dev);
+          double *d_run = (double *)fg_dev_alloc(3 * (size_t)nsh * sizeof(double), dev);
+          double *d_scr = (double *)fg_dev_alloc(nsum * sizeof(double), dev);
+          if (!run || !d_sh || !d_run || !d_scr || fg_dev_upload(d_sh, sh, (size_t)nsh * sizeof(int))) hip_fatal("setup_conserve_interp");
+          for (n = 0; n < ntiles_out; n++)
+            for (r = 0; r < npes; r++) {
+              if (r == pe && fg_plan_nxgrid(plans[n]) > 0) {
+                if (fg_dev_upload(d_run, run, 3 * (size_t)nsh * sizeof(double))) hip_fatal("setup_conserve_interp");
+                for (c = 0; c < 3; c++) if (fg_dev_scatter_f64(d_scr + (size_t)c * ncells_in, d_run + (size_t)c * nsh, d_sh, nsh)) hip_fatal("setup_conserve_interp");
+                if (fg_plan_accumulate_cell_sums(plans[n], d_scr, d_sh, nsh)) hip_fatal("setup_conserve_interp");
+                for (c = 0; c < 3; c++) if (fg_dev_gather_f64(d_run + (size_t)c * nsh, d_scr + (size_t)c * ncells_in, d_sh, nsh)) hip_fatal("setup_conserve_interp");
+                if (fg_dev_download(run, d_run, 3 * (size_t)nsh * sizeof(double))) hip_fatal("setup_conserve_interp");
+              } else if (r != pe)
+                for (k = 0; k < 3 * nsh; k++) run[k] = 0.0;
+              mpp_sum_double(3 * nsh, run);                  /* = a broadcast from rank r: the others contribute zeros */
+            }
+          for (c = 0; c < 3; c++) for (k = 0; k < nsh; k++) tot[(size_t)c * ncells_in + sh[k]] = 0.0;
+          mpp_sum_double((int)nsum, tot);                    /* every other cell is complete on its one rank */
+          for (c = 0; c < 3; c++) for (k = 0; k < nsh; k++) tot[(size_t)c * ncells_in + sh[k]] = run[(size_t)c * nsh + k];
+          fg_dev_free(d_sh); fg_dev_free(d_run); fg_dev_free(d_scr); free(run);
+        } else
+          mpp_sum_double((int)nsum, tot);
+        if (fg_dev_upload(d_tot, tot, nsum * sizeof(double))) hip_fatal("setup_conserve_interp");
+        free(cnt); free(sh);
       }
-      if (fg_dev_upload(d_tot, tot, nsum * sizeof(double))) hip_fatal("setup_conserve_interp");
       for (n = 0; n < ntiles_out; n++) if (fg_plan_finalize(plans[n], d_tot)) hip_fatal("setup_conserve_interp");
-      fg_dev_free(d_tot); free(tot); free(part);
+      fg_dev_free(d_tot); free(tot);
     } else
       for (n = 0; n < ntiles_out; n++) if (fg_plan_finalize(plans[n], NULL)) hip_fatal("setup_conserve_interp");
     for (n = 0; n < ntiles_out; n++) {

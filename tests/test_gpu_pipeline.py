@@ -338,6 +338,39 @@ def test_tripolar_both_directions(fg, gpu_ok):
     assert np.max(np.abs(got - area) / area) < 2e-3      # poly_area's great-circle-vs-parallel edge model, not a bug
 
 
+def test_six_output_tiles_accumulate_in_the_references_order(fg, gpu_ok):
+    """Order 2 onto a cubed sphere: a source cell that meets two output tiles gets its (area, clon, clat) sums from both, and
+    the reference adds the exchange cells of output tile 0, then of tile 1, ... onto ONE accumulator (conserve_interp.c:136-147
+    sit outside the n loop, :216-221).  fg_plan_accumulate_cell_sums continues the running total from plan to plan, so di / dj
+    carry the oracle's bits -- a sum of per-tile partial sums would not."""
+    no = 12
+    lo, la = fg.latlon_corners(60, 30)
+    clon, clat = fg.gnomonic_ed_corners(no)
+    grid_in = [fg.GridConfig(60, 30, lo, la)]
+    grid_out = [fg.GridConfig(no, no, clon[t], clat[t]) for t in range(6)]
+    interp = [fg.InterpConfig() for _ in range(6)]
+    fg.setup_conserve_interp(1, grid_in, 6, grid_out, interp, fg.CONSERVE_ORDER2)
+    o = orc.orc_setup(2, [(60, 30, lo, la)], [(no, no, clon[t], clat[t]) for t in range(6)])
+    shared = 0
+    for n in range(6):
+        ic = interp[n]
+        sl = slice(int(o["xoff"][n]), int(o["xoff"][n + 1]))
+        assert ic.nxgrid == sl.stop - sl.start > 0
+        for k, ok in (("i_in", "i_in"), ("j_in", "j_in"), ("i_out", "i_out"), ("j_out", "j_out")):
+            assert np.array_equal(getattr(ic, k), o[ok][sl]), (n, k)
+        if orc.host_has_fma():
+            assert np.array_equal(_bits(ic.area), _bits(o["area"][sl]))
+            assert np.array_equal(_bits(ic.di_in), _bits(o["di"][sl])) and np.array_equal(_bits(ic.dj_in), _bits(o["dj"][sl])), n
+        else:
+            assert np.allclose(ic.di_in, o["di"][sl], rtol=1e-9, atol=1e-12)
+        ic.plan.destroy()
+    src = o["j_in"].astype(np.int64) * 60 + o["i_in"]
+    tile = np.searchsorted(o["xoff"][1:], np.arange(o["n"]), side="right")
+    for c in np.unique(src):
+        shared += len(np.unique(tile[src == c])) > 1
+    assert shared > 100                                   # many source cells do meet two or three output tiles
+
+
 def test_coarse_to_fine_and_fine_to_coarse(fg, gpu_ok):
     lon, lat = fg.gnomonic_ed_corners(8)
     lo, la = fg.latlon_corners(240, 120)
