@@ -428,10 +428,13 @@ def main():
     dt = float(np.median(reps))
     fg.lib().fg_set_search_cull(0)
 
+    trace = (lambda m: print(f"[trace rank {rank}] {m}", file=sys.stderr, flush=True)) if os.environ.get("FG_BENCH_TRACE") else (lambda m: None)
+    trace("search done")
     # ---- sweep leg
     apply_steps = args.apply_steps
     for _ in range(3):
         p.apply(data_t, out_t, nz=nz, grad_x_t=gx_t, grad_y_t=gy_t)
+        torch.cuda.synchronize(); trace("apply warm-up")
     p.phase_ms()
     barrier(); torch.cuda.synchronize()
     ta = time.perf_counter()

@@ -129,6 +129,17 @@ def lib():
     L.fg_plan_copy_cell_sums.restype = C.c_int
     L.fg_plan_accumulate_cell_sums.argtypes = [vp, vp, vp, C.c_int]
     L.fg_plan_accumulate_cell_sums.restype = C.c_int
+    L.fg_dev_alloc.argtypes = [C.c_size_t, C.c_int]
+    L.fg_dev_alloc.restype = vp
+    L.fg_dev_free.argtypes = [vp]
+    L.fg_dev_free.restype = None
+    L.fg_dev_upload.argtypes = [vp, vp, C.c_size_t]
+    L.fg_dev_upload.restype = C.c_int
+    L.fg_dev_download.argtypes = [vp, vp, C.c_size_t]
+    L.fg_dev_download.restype = C.c_int
+    for f in (L.fg_dev_gather_f64, L.fg_dev_scatter_f64):
+        f.argtypes = [vp, vp, vp, C.c_long]
+        f.restype = C.c_int
     L.fg_plan_finalize.argtypes = [vp, vp]
     L.fg_plan_finalize.restype = C.c_int
     L.fg_plan_get_xgrid.argtypes = [vp] + [ip] * 5 + [dp] * 3

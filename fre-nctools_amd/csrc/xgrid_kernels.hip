@@ -368,10 +368,16 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
     const FgTile *tl0 = ts.n ? sh_tiles : tiles_in;
     const int s = blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
+    int idx_f = s;                                        // the cell's place in the field arrays: the sweep's record merge reads it for EVERY cell
     if (s < nsrc) {
       int t = 0;
       while (t + 1 < ntiles && s >= tl0[t + 1].cell_off) t++;
       const int loc = s - tl0[t].cell_off, i = loc % tl0[t].nx, j = loc / tl0[t].nx, nxp = tl0[t].nx + 1;
+      if (order == 2) {
+        int foff = 0;
+        for (int m = 0; m < t; m++) foff += (tl0[m].nx + 2) * (tl0[m].ny + 2);
+        idx_f = foff + (j + 1) * (tl0[t].nx + 2) + i + 1;
+      }
       const int n0 = j * nxp + i;
       const double y0 = tl0[t].lat[n0], y1 = tl0[t].lat[n0 + 1], y2 = tl0[t].lat[n0 + nxp + 1], y3 = tl0[t].lat[n0 + nxp];
       const double lmin = fmin(fmin(y0, y1), fmin(y2, y3)), lmax = fmax(fmax(y0, y1), fmax(y2, y3));
@@ -379,7 +385,11 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
       keep = !((lmax <= bmin) || (lmin >= bmax)) || !(lmin == lmin);        // NaN goes on to the full path (it reports the error)
     }
     if (!__syncthreads_or(keep)) {
-      if (s < nsrc) { S.nv[s] = 0; S.area[s] = 0; if (sums) { sums[s] = 0.0; sums[nsrc + s] = 0.0; sums[2 * (size_t)nsrc + s] = 0.0; } }
+      if (s < nsrc) {
+        S.nv[s] = 0; S.area[s] = 0;
+        if (src_idx_f) src_idx_f[s] = idx_f;
+        if (sums) { sums[s] = 0.0; sums[nsrc + s] = 0.0; sums[2 * (size_t)nsrc + s] = 0.0; }
+      }
       if (ts.n && blockIdx.x == 0 && (int)threadIdx.x < ts.n) tiles_out[threadIdx.x] = sh_tiles[threadIdx.x];
       return;
     }

@@ -455,6 +455,43 @@ def test_source_cell_culling_keeps_the_plan(fg, gpu_ok):
         assert live[s].all()                                                            # every cell with exchange cells was kept
 
 
+def test_culled_plan_sweeps_like_the_unculled_one(fg, gpu_ok):
+    """A culled plan must still sweep: the order-2 sweep merges field and gradients for EVERY source cell, so the field index of
+    the culled cells has to be there too (a block of source cells wholly outside the band leaves the record kernel early; the
+    2-rank bench rehearsal faulted on its uninitialised indices).  C96 against a narrow band: most 256-cell blocks are culled
+    whole.  The pool is poisoned first so that forgotten stores show up as wild indices rather than as lucky zeros."""
+    import torch
+    ni, nlon, nlat, nz = 96, 360, 180, 8
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    rng = np.random.default_rng(3)
+    src = torch.from_numpy(rng.standard_normal((nz, 6 * (ni + 2) ** 2))).to("cuda:0")
+    gx = torch.from_numpy(rng.standard_normal((nz, 6 * ni * ni))).to("cuda:0")
+    gy = torch.from_numpy(rng.standard_normal((nz, 6 * ni * ni))).to("cuda:0")
+    for (j0, j1) in ((100, 112), (0, 9)):
+        band = fg.GridConfig(nlon, j1 - j0, np.ascontiguousarray(lo[j0:j1 + 1]), np.ascontiguousarray(la[j0:j1 + 1]))
+        outs = []
+        try:
+            for cull in (0, 1):
+                # poison: blocks the pool hands out next hold 0x7f7f... (int 2139062143, a NaN-ish double)
+                for nbytes in (6 * ni * ni * 4 + 4, 6 * ni * ni * 8, 3 * 6 * ni * ni * 8):
+                    pz = fg.lib().fg_dev_alloc(nbytes, 0)
+                    junk = np.full(nbytes, 0x7f, dtype=np.uint8)
+                    assert fg.lib().fg_dev_upload(C.c_void_p(pz), junk.ctypes.data_as(C.c_void_p), nbytes) == 0
+                    fg.lib().fg_dev_free(C.c_void_p(pz))
+                fg.lib().fg_set_search_cull(cull)
+                plan = fg.XgridPlan.create(2, grids, band)
+                plan.finalize()
+                out = torch.full((nz, nlon * (j1 - j0)), np.nan, dtype=torch.float64, device="cuda:0")
+                plan.apply(src, out, nz=nz, grad_x_t=gx, grad_y_t=gy); plan.sync()
+                outs.append(out.cpu().numpy())
+                plan.destroy()
+        finally:
+            fg.lib().fg_set_search_cull(0)
+        assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
 def test_plan_trim_keeps_the_plan(fg, gpu_ok):
     """fg_plan_trim re-allocates the capacity-sized exchange-cell arrays at nxgrid entries: before or after
     fg_plan_finalize, the exchange cells and the sweep are unchanged."""
