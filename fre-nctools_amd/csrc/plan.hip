@@ -55,7 +55,16 @@ struct Pool {
     while (c < n) c += (c < (1u << 20) ? c : (c >> 2));           // x2 up to 1 MiB, then x1.25
     return c;
   }
-  void *get(int dev, size_t n)
+  // FREGRID_HIP_POISON=1 (tests): every block handed out is filled with 0x7f bytes first, so that a kernel reading something it
+  // or its predecessors never wrote meets wild indices / NaN-like doubles instead of a lucky zero or a stale valid value
+  static void *poison(void *p, size_t c)
+  {
+    static const bool on = getenv("FREGRID_HIP_POISON") && atoi(getenv("FREGRID_HIP_POISON")) != 0;
+    if (on && p) { (void)hipMemset(p, 0x7f, c); (void)hipDeviceSynchronize(); }
+    return p;
+  }
+  void *get(int dev, size_t n) { return poison(get_raw(dev, n), klass(n ? n : 1)); }
+  void *get_raw(int dev, size_t n)
   {
     if (n == 0) n = 1;
     size_t c = klass(n);
