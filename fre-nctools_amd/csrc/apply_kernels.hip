@@ -495,6 +495,9 @@ __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const dou
 // per destination row adds them in CSR order -- the same operations in the same order as k_apply_il, so the same bits, but a
 // wave's dependent chain is row pointers -> CSR staging -> ONE round of gathers -> LDS sums instead of ~7 gather rounds.
 // A tile whose rows hold more than EP_CAP exchange cells (fine -> coarse remaps) takes the row-serial loop.
+// (A persistent version -- blocks walking over tiles, the next tile's row pointers and records prefetched into registers while
+//  the current tile's gathers fly, no LDS staging -- was measured: 0.119 ms against 0.0833.  Its 108 VGPRs halve the occupancy
+//  (4 waves per SIMD against 7), and the occupancy is what hides the gather latency.)
 #define EP_ROWS 32
 template <int TPB, int CAP>
 __global__ __launch_bounds__(TPB) void k_apply_ep8(int ndst, FgCsr csr, const double *rec, double missing, double *out, double *row_sum,
