@@ -68,7 +68,7 @@ if mg:
            table(mg, ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"],
                  keys=[k for k in sorted(mg, key=lambda k: -mg[k].get("SQ_WAVE_CYCLES", 0)) if k.startswith("k_gc")]), ""]
 mw = pmc(["sweep_fetch", "sweep_write", "sweep_rd", "sweep_l2", "sweep_wr", "sweep_sq"])
-keys = [k for k in mw if k.startswith(("k_apply_il", "k_interleave3", "k_merge3"))]
+keys = [k for k in mw if k.startswith(("k_apply_il", "k_apply_ep8", "k_interleave3", "k_merge3"))]
 md += ["## PMC passes, sweep: what the fabric counters really count", "",
        "`k_interleave3<8>` is a pure streaming kernel of known size (8 levels x 884 736 doubles = 56.6 MB in, 56.6 MB out): the calibration.", "",
        table(mw, ["FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_64B_sum"], keys), "",
@@ -83,7 +83,7 @@ for k in keys:
     wr = 64 * c.get("TCC_EA0_WRREQ_64B_sum", 0) / 1e6
     hit = c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))
     lines.append(f"| `{k}` | {rd:.1f} | {c['TCC_EA0_RDREQ_sum'] * 64 / 1e6:.1f} | {wr:.1f} | {hit:.2f} |")
-    if k.startswith("k_apply_il<2, 8, 4, true"):
+    if k.startswith("k_apply_ep8"):
         traffic["k_apply"] = (rd + wr) * 1e6
 md += ["Bytes from the by-size request counters (exact on the calibration kernel: 56.6 MB read, 56.6 MB written):", "", "\n".join(lines), "",
        "Reading: nearly every fabric read is a 128-byte request, FETCH_SIZE books it as 64 bytes -- the guide's 2x correction holds for the "
@@ -92,10 +92,11 @@ md += ["Bytes from the by-size request counters (exact on the calibration kernel
        "share source records and each XCD has its own L2 (separate PMC passes, `scripts/prof_xcd.sh`, two levels per lane): tiles in row order 532 MB "
        "read, L2 hit rate 0.42, 0.0966 ms; chunks of 64 tiles per XCD (the default) 384 MB, 0.56, 0.0936 ms; one band per XCD 314 MB, 0.63, "
        "0.1105 ms.  Less traffic is NOT faster in proportion: the kernel is bound by the latency of its dependent gathers at the occupancy it "
-       "has (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.68; ~12 us per wave, 8 waves per SIMD), not by HBM or fabric bytes.  The table above is the "
-       "shipped configuration (four levels per lane, chunked tiles): 355 MB read + 66 MB written = 1.14x the algorithmic bytes, L2 hit rate 0.61, "
-       "0.0875 ms back to back (`scripts/apply_ab.py`), 0.090 ms per launch by HIP events in `bench.py`, 0.099 ms per dispatch under rocprofv3 "
-       "(which serialises dispatches with a cache write-back inside its timestamps).", ""]
+       "has (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.68; ~12 us per wave, 8 waves per SIMD), not by HBM or fabric bytes.  The tables above are the "
+       "shipped configuration: `k_apply_ep8<256, 256>` (entry-parallel, chunked tiles) for the 8-level order-2 sweep on records -- 0.0833 ms "
+       "back to back (`scripts/apply_ab.py`), 0.0885 ms per launch by HIP events in `bench.py`, a few us more per dispatch under rocprofv3 "
+       "(which serialises dispatches with a cache write-back inside its timestamps) -- and `k_apply_il<.., 4, ..>` (four levels per lane) "
+       "for the order-1 and the interleaved-array sweeps.", ""]
 k = "k_clip_quad<2>"
 if k in ms and "FETCH_SIZE" in ms[k] and "WRITE_SIZE" in ms[k]:
     traffic["k_clip_quad"] = (2 * ms[k]["FETCH_SIZE"] + ms[k]["WRITE_SIZE"]) * 1024.0
