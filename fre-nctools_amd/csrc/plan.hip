@@ -718,6 +718,10 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   static const bool env_exact = getenv("FREGRID_HIP_EXACT_SEARCH") && atoi(getenv("FREGRID_HIP_EXACT_SEARCH")) != 0;
   const bool exact = g_search_exact || env_exact;
   const long big = std::max((long)pl->nsrc, (long)pl->ndst);
+  // 32-bit prefixes (bin starts, exchange-cell offsets, CSR rows): the bin table holds up to 3 records per destination cell
+  // (+ the wide lists) and the pair list 8 per cell, so grids beyond 2^28 cells could wrap an int before the host sees a
+  // counter -- refused up front rather than guarded in every kernel
+  if (big > (1L << 28)) return fail(FG_ERR_CAPACITY, "grid of %ld cells: more than 2^28 cells per search are not supported", big);
   SearchCaps caps;
   caps.entries = exact ? 0ull : 3ull * (unsigned long long)pl->ndst + 4096ull;
   const unsigned long long cap_pairs = std::min<unsigned long long>(8ull * (unsigned long long)big + 65536ull, 2000000000ull);
