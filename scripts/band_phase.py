@@ -1,3 +1,5 @@
+"""Per-phase device times (HIP events) of the banded search for a few (ranks, rank) choices, culling on: where a rank's time goes
+when its band is an eighth / a quarter / all of the target.  usage: python scripts/band_phase.py"""
 import os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
