@@ -8,6 +8,8 @@
  * usage: b2_driver ni nlon nlat out.bin
  *   scenario 1: conserve_order2, nz = 2, plain branch          (halo'd data, grad_x, grad_y)
  *   scenario 2: conserve_order1, nz = 1, has_missing = 1       (every 7th source cell missing)
+ *   scenario 3: scenario 1 with WRITE | CHECK_CONSERVE         (remap file <out.bin>.remap.nc; the area check :450-490 prints)
+ *   scenario 4: scenario 1 with READ of that file              (fg_remap_read -> fg_plan_set_xgrid instead of a search)
  *   out.bin per scenario: int nxgrid; int t_in,i_in,j_in,i_out,j_out [nxgrid]; double area[nxgrid]; (order 2: double di, dj [nxgrid]);
  *                         double field_out[nz * nlon * nlat]
  * Input fields are index formulas that a test can restate exactly. */
@@ -17,6 +19,8 @@
 #include "globals.h"
 #include "conserve_interp.h"
 #include "mpp.h"
+#include "mpp_domain.h"
+void get_grid_area(const int *nlon, const int *nlat, const double *lon, const double *lat, double *area);   /* create_xgrid.h:38 */
 #include "fregrid_hip.h"
 
 static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if (!p) { fprintf(stderr, "out of memory\n"); exit(2); } return p; }
@@ -31,6 +35,7 @@ int main(int argc, char **argv)
   int ni, nlon, nlat, t, k, j, i, sc;
   FILE *f;
   mpp_init(&argc, &argv);
+  mpp_domain_init();                               /* fregrid.c:414-415 */
   if (argc != 5) { fprintf(stderr, "usage: b2_driver ni nlon nlat out.bin\n"); return 2; }
   ni = atoi(argv[1]); nlon = atoi(argv[2]); nlat = atoi(argv[3]);
   {
@@ -53,15 +58,28 @@ int main(int argc, char **argv)
 
     f = fopen(argv[4], "wb");
     if (!f) { perror(argv[4]); return 2; }
-    for (sc = 1; sc <= 2; sc++) {
-      const int order = (sc == 1) ? 2 : 1, nz = (sc == 1) ? 2 : 1, halo = (order == 2) ? 1 : 0;
-      const unsigned int opcode = (order == 2) ? CONSERVE_ORDER2 : CONSERVE_ORDER1;
+    for (sc = 1; sc <= 4; sc++) {
+      const int order = (sc == 2) ? 1 : 2, nz = (sc == 2) ? 1 : 2, halo = (order == 2) ? 1 : 0;
+      unsigned int opcode = (order == 2) ? CONSERVE_ORDER2 : CONSERVE_ORDER1;
+      if (sc == 3) opcode |= WRITE | CHECK_CONSERVE;
+      if (sc == 4) opcode |= READ;
       const size_t nd = (size_t)(ni + 2 * halo) * (ni + 2 * halo), nc = (size_t)ni * ni;
       Interp_config interp[1];
       Field_config field_in[6], field_out[1];
       Var_config var;
       int nx;
       memset(interp, 0, sizeof interp); memset(field_in, 0, sizeof field_in); memset(field_out, 0, sizeof field_out); memset(&var, 0, sizeof var);
+      if (sc >= 3) { snprintf(interp[0].remap_file, STRING, "%s.remap.nc", argv[4]); interp[0].file_exist = (sc == 4); }
+      if (sc == 3) {                                 /* get_input_output_cell_area, fregrid_util.c:363-408: the area check reads them */
+        for (t = 0; t < 6; t++) if (!grid_in[t].cell_area) {
+          grid_in[t].cell_area = (double *)xcalloc((size_t)ni * ni, sizeof(double));
+          get_grid_area(&ni, &ni, grid_in[t].lonc, grid_in[t].latc, grid_in[t].cell_area);
+        }
+        if (!grid_out[0].cell_area) {
+          grid_out[0].cell_area = (double *)xcalloc((size_t)nlon * nlat, sizeof(double));
+          get_grid_area(&nlon, &nlat, lono, lato, grid_out[0].cell_area);
+        }
+      }
       setup_conserve_interp(6, grid_in, 1, grid_out, interp, opcode);
       var.interp_method = order; var.has_missing = (sc == 2); var.missing = -1.e10; var.cell_methods = CELL_METHODS_MEAN;
       for (t = 0; t < 6; t++) {

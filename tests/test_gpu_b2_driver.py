@@ -40,6 +40,7 @@ def test_c_replacement_object_equals_the_python_mirror(fg, gpu_ok, tmp_path):
     out = str(tmp_path / "b2.bin")
     r = subprocess.run([EXE, str(ni), str(nlon), str(nlat), out], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "b2_driver ok" in r.stdout, r.stdout + r.stderr
+    assert "Finish reading index and weight" in r.stdout                      # the READ branch ran (conserve_interp.c:125)
     raw = open(out, "rb").read()
     pos = 0
 
@@ -52,13 +53,47 @@ def test_c_replacement_object_equals_the_python_mirror(fg, gpu_ok, tmp_path):
     lon, lat = fg.gnomonic_ed_corners(ni)
     lo, la = fg.latlon_corners(nlon, nlat)
     bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
-    for order, nz, missing in ((2, 2, None), (1, 1, -1.e10)):
+    first = {}
+    for sc, (order, nz, missing) in enumerate(((2, 2, None), (1, 1, -1.e10), (2, 2, None), (2, 2, None)), start=1):
         nx = int(take(np.int32, 1)[0])
         c = {k: take(np.int32, nx) for k in ("t_in", "i_in", "j_in", "i_out", "j_out")}
         c["area"] = take(np.float64, nx)
         if order == 2:
             c["di"], c["dj"] = take(np.float64, nx), take(np.float64, nx)
         c_out = take(np.float64, nz * nlon * nlat).reshape(nz, nlat, nlon)
+        if sc == 1:
+            first = dict(c, out=c_out)
+        if sc == 3:                                  # WRITE | CHECK_CONSERVE: the plan of scenario 1 again, and the file the C code wrote
+            for k in ("t_in", "i_in", "j_in", "i_out", "j_out"):
+                assert np.array_equal(c[k], first[k]), (sc, k)
+            for k in ("area", "di", "dj"):
+                assert np.array_equal(bits(c[k]), bits(first[k])), (sc, k)
+            assert np.array_equal(bits(c_out), bits(first["out"])), sc
+            x = fg.read_remap_file(out + ".remap.nc", 2)             # (read_mosaic.c semantics: area / garea, then * garea at :86)
+            assert np.array_equal(x["i_in"], c["i_in"]) and np.array_equal(x["j_out"], c["j_out"]) and np.array_equal(x["t_in"], c["t_in"])
+            assert np.array_equal(bits(x["di_in"]), bits(c["di"])) and np.array_equal(bits(x["dj_in"]), bits(c["dj"]))
+            continue
+        if sc == 4:                                  # READ of that file: against the Python mirror's READ branch, bit for bit
+            grid_in = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+            grid_out = [fg.GridConfig(nlon, nlat, lo, la)]
+            interp = [fg.InterpConfig(remap_file=out + ".remap.nc", file_exist=1)]
+            fg.setup_conserve_interp(6, grid_in, 1, grid_out, interp, fg.CONSERVE_ORDER2 | fg.READ)
+            ic = interp[0]
+            assert ic.nxgrid == nx
+            for k in ("t_in", "i_in", "j_in", "i_out", "j_out"):
+                assert np.array_equal(getattr(ic, k), c[k]), (sc, k)
+            assert np.array_equal(bits(ic.area), bits(c["area"])) and np.array_equal(bits(ic.di_in), bits(c["di"]))
+            field_in = _fields(fg, ni, 2, nz, None)
+            for fc in field_in:
+                fc.var = [fg.VarConfig(interp_method=fg.CONSERVE_ORDER2)]
+            field_out = [fg.FieldConfig(data=np.zeros((nz, nlat, nlon)))]
+            field_out[0].var = field_in[0].var
+            fg.do_scalar_conserve_interp(interp, 0, 6, grid_in, 1, grid_out, field_in, field_out, fg.CONSERVE_ORDER2, nz)
+            assert np.array_equal(bits(np.asarray(field_out[0].data).reshape(nz, nlat, nlon)), bits(c_out))
+            # the file stores area / (4 pi R^2) and the READ multiplies it back (:86): last-bit differences against the computed plan
+            assert np.allclose(c["area"], first["area"], rtol=1e-14, atol=0) and np.allclose(c_out, first["out"], rtol=1e-12, atol=0)
+            ic.plan.destroy()
+            continue
         # the Python mirror
         grid_in = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
         grid_out = [fg.GridConfig(nlon, nlat, lo, la)]
