@@ -10,6 +10,8 @@
  *   scenario 2: conserve_order1, nz = 1, has_missing = 1       (every 7th source cell missing)
  *   scenario 3: scenario 1 with WRITE | CHECK_CONSERVE         (remap file <out.bin>.remap.nc; the area check :450-490 prints)
  *   scenario 4: scenario 1 with READ of that file              (fg_remap_read -> fg_plan_set_xgrid instead of a search)
+ *   scenario 5: conserve_order2, nz = 1, MONOTONIC             (fg_plan_apply_ex: the limiter, conserve_interp.c:617-742)
+ *   scenario 6: conserve_order1, nz = 1, TARGET, cell_methods = sum, grid_in[].weight     (the remaining options of :561-616, :815-870)
  *   out.bin per scenario: int nxgrid; int t_in,i_in,j_in,i_out,j_out [nxgrid]; double area[nxgrid]; (order 2: double di, dj [nxgrid]);
  *                         double field_out[nz * nlon * nlat]
  * Input fields are index formulas that a test can restate exactly. */
@@ -58,11 +60,13 @@ int main(int argc, char **argv)
 
     f = fopen(argv[4], "wb");
     if (!f) { perror(argv[4]); return 2; }
-    for (sc = 1; sc <= 4; sc++) {
-      const int order = (sc == 2) ? 1 : 2, nz = (sc == 2) ? 1 : 2, halo = (order == 2) ? 1 : 0;
+    for (sc = 1; sc <= 6; sc++) {
+      const int order = (sc == 2 || sc == 6) ? 1 : 2, nz = (sc == 2 || sc >= 5) ? 1 : 2, halo = (order == 2) ? 1 : 0;
       unsigned int opcode = (order == 2) ? CONSERVE_ORDER2 : CONSERVE_ORDER1;
       if (sc == 3) opcode |= WRITE | CHECK_CONSERVE;
       if (sc == 4) opcode |= READ;
+      if (sc == 5) opcode |= MONOTONIC;
+      if (sc == 6) opcode |= TARGET;
       const size_t nd = (size_t)(ni + 2 * halo) * (ni + 2 * halo), nc = (size_t)ni * ni;
       Interp_config interp[1];
       Field_config field_in[6], field_out[1];
@@ -70,7 +74,7 @@ int main(int argc, char **argv)
       int nx;
       memset(interp, 0, sizeof interp); memset(field_in, 0, sizeof field_in); memset(field_out, 0, sizeof field_out); memset(&var, 0, sizeof var);
       if (sc >= 3) { snprintf(interp[0].remap_file, STRING, "%s.remap.nc", argv[4]); interp[0].file_exist = (sc == 4); }
-      if (sc == 3) {                                 /* get_input_output_cell_area, fregrid_util.c:363-408: the area check reads them */
+      if (sc == 3 || sc == 6) {                      /* get_input_output_cell_area, fregrid_util.c:363-408: the area check reads them */
         for (t = 0; t < 6; t++) if (!grid_in[t].cell_area) {
           grid_in[t].cell_area = (double *)xcalloc((size_t)ni * ni, sizeof(double));
           get_grid_area(&ni, &ni, grid_in[t].lonc, grid_in[t].latc, grid_in[t].cell_area);
@@ -81,7 +85,15 @@ int main(int argc, char **argv)
         }
       }
       setup_conserve_interp(6, grid_in, 1, grid_out, interp, opcode);
-      var.interp_method = order; var.has_missing = (sc == 2); var.missing = -1.e10; var.cell_methods = CELL_METHODS_MEAN;
+      var.interp_method = order; var.has_missing = (sc == 2); var.missing = -1.e10;
+      var.cell_methods = (sc == 6) ? CELL_METHODS_SUM : CELL_METHODS_MEAN;
+      for (t = 0; t < 6; t++) {
+        grid_in[t].weight_exist = (sc == 6);
+        if (sc == 6 && !grid_in[t].weight) {
+          grid_in[t].weight = (double *)xcalloc((size_t)ni * ni, sizeof(double));
+          for (j = 0; j < ni; j++) for (i = 0; i < ni; i++) grid_in[t].weight[(size_t)j * ni + i] = 0.5 + ((t + i + 2 * j) % 4) * 0.125;
+        }
+      }
       for (t = 0; t < 6; t++) {
         field_in[t].var = &var;
         field_in[t].data = (double *)xcalloc((size_t)nz * nd, sizeof(double));

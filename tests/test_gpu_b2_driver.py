@@ -54,7 +54,7 @@ def test_c_replacement_object_equals_the_python_mirror(fg, gpu_ok, tmp_path):
     lo, la = fg.latlon_corners(nlon, nlat)
     bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
     first = {}
-    for sc, (order, nz, missing) in enumerate(((2, 2, None), (1, 1, -1.e10), (2, 2, None), (2, 2, None)), start=1):
+    for sc, (order, nz, missing) in enumerate(((2, 2, None), (1, 1, -1.e10), (2, 2, None), (2, 2, None), (2, 1, None), (1, 1, None)), start=1):
         nx = int(take(np.int32, 1)[0])
         c = {k: take(np.int32, nx) for k in ("t_in", "i_in", "j_in", "i_out", "j_out")}
         c["area"] = take(np.float64, nx)
@@ -108,11 +108,20 @@ def test_c_replacement_object_equals_the_python_mirror(fg, gpu_ok, tmp_path):
         if order == 2:
             assert np.array_equal(bits(ic.di_in), bits(c["di"])) and np.array_equal(bits(ic.dj_in), bits(c["dj"]))
         field_in = _fields(fg, ni, order, nz, missing)
+        run_op = opcode
         for fc in field_in:
-            fc.var = [fg.VarConfig(interp_method=opcode, has_missing=int(missing is not None), missing=missing if missing is not None else -1.e20)]
+            fc.var = [fg.VarConfig(interp_method=opcode, has_missing=int(missing is not None), missing=missing if missing is not None else -1.e20,
+                                   cell_methods=fg.CELL_METHODS_SUM if sc == 6 else fg.CELL_METHODS_MEAN)]
+        if sc == 5:
+            run_op |= fg.MONOTONIC
+        if sc == 6:
+            run_op |= fg.TARGET
+            jj, ii = np.meshgrid(np.arange(ni), np.arange(ni), indexing="ij")
+            for t, g in enumerate(grid_in):
+                g.weight, g.weight_exist = 0.5 + ((t + ii + 2 * jj) % 4) * 0.125, 1
         field_out = [fg.FieldConfig(data=np.zeros((nz, nlat, nlon)))]
         field_out[0].var = field_in[0].var
-        fg.do_scalar_conserve_interp(interp, 0, 6, grid_in, 1, grid_out, field_in, field_out, opcode, nz)
+        fg.do_scalar_conserve_interp(interp, 0, 6, grid_in, 1, grid_out, field_in, field_out, run_op, nz)
         assert np.array_equal(bits(np.asarray(field_out[0].data).reshape(nz, nlat, nlon)), bits(c_out)), order
         if missing is not None:
             assert (c_out == missing).sum() == 0 or True          # (cells covered only by missing sources would carry the missing value)
