@@ -12,6 +12,7 @@
  *   scenario 4: scenario 1 with READ of that file              (fg_remap_read -> fg_plan_set_xgrid instead of a search)
  *   scenario 5: conserve_order2, nz = 1, MONOTONIC             (fg_plan_apply_ex: the limiter, conserve_interp.c:617-742)
  *   scenario 6: conserve_order1, nz = 1, TARGET, cell_methods = sum, grid_in[].weight     (the remaining options of :561-616, :815-870)
+ *   scenario 7: conserve_order1 | GREAT_CIRCLE, nz = 1         (fg_plan_create_great_circle, conserve_interp.c:164-168)
  *   out.bin per scenario: int nxgrid; int t_in,i_in,j_in,i_out,j_out [nxgrid]; double area[nxgrid]; (order 2: double di, dj [nxgrid]);
  *                         double field_out[nz * nlon * nlat]
  * Input fields are index formulas that a test can restate exactly. */
@@ -60,13 +61,14 @@ int main(int argc, char **argv)
 
     f = fopen(argv[4], "wb");
     if (!f) { perror(argv[4]); return 2; }
-    for (sc = 1; sc <= 6; sc++) {
-      const int order = (sc == 2 || sc == 6) ? 1 : 2, nz = (sc == 2 || sc >= 5) ? 1 : 2, halo = (order == 2) ? 1 : 0;
+    for (sc = 1; sc <= 7; sc++) {
+      const int order = (sc == 2 || sc >= 6) ? 1 : 2, nz = (sc == 2 || sc >= 5) ? 1 : 2, halo = (order == 2) ? 1 : 0;
       unsigned int opcode = (order == 2) ? CONSERVE_ORDER2 : CONSERVE_ORDER1;
       if (sc == 3) opcode |= WRITE | CHECK_CONSERVE;
       if (sc == 4) opcode |= READ;
       if (sc == 5) opcode |= MONOTONIC;
       if (sc == 6) opcode |= TARGET;
+      if (sc == 7) opcode |= GREAT_CIRCLE;
       const size_t nd = (size_t)(ni + 2 * halo) * (ni + 2 * halo), nc = (size_t)ni * ni;
       Interp_config interp[1];
       Field_config field_in[6], field_out[1];

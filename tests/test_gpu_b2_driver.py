@@ -54,7 +54,7 @@ def test_c_replacement_object_equals_the_python_mirror(fg, gpu_ok, tmp_path):
     lo, la = fg.latlon_corners(nlon, nlat)
     bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
     first = {}
-    for sc, (order, nz, missing) in enumerate(((2, 2, None), (1, 1, -1.e10), (2, 2, None), (2, 2, None), (2, 1, None), (1, 1, None)), start=1):
+    for sc, (order, nz, missing) in enumerate(((2, 2, None), (1, 1, -1.e10), (2, 2, None), (2, 2, None), (2, 1, None), (1, 1, None), (1, 1, None)), start=1):
         nx = int(take(np.int32, 1)[0])
         c = {k: take(np.int32, nx) for k in ("t_in", "i_in", "j_in", "i_out", "j_out")}
         c["area"] = take(np.float64, nx)
@@ -99,7 +99,7 @@ def test_c_replacement_object_equals_the_python_mirror(fg, gpu_ok, tmp_path):
         grid_out = [fg.GridConfig(nlon, nlat, lo, la)]
         interp = [fg.InterpConfig()]
         opcode = fg.CONSERVE_ORDER2 if order == 2 else fg.CONSERVE_ORDER1
-        fg.setup_conserve_interp(6, grid_in, 1, grid_out, interp, opcode)
+        fg.setup_conserve_interp(6, grid_in, 1, grid_out, interp, opcode | (fg.GREAT_CIRCLE if sc == 7 else 0))
         ic = interp[0]
         assert ic.nxgrid == nx > 0
         for k in ("t_in", "i_in", "j_in", "i_out", "j_out"):
