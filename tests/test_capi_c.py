@@ -179,3 +179,19 @@ def test_c99_probe_results_equal_the_oracle(tmp_path, fg, gpu_ok):
     x, y = np.array([0.1, 0.3, 0.3, 0.1]), np.array([0.2, 0.2, 0.5, 0.5])
     pa = orc.oracle().orc_poly_area(orc._dp(x), orc._dp(y), 4)
     assert abs(float(m.group(1)) - pa) <= 1e-10 * abs(pa)
+
+
+def test_b2_driver_builds_against_the_reference_headers():
+    """oracle/_ref/b2_driver = tests/capi/b2_driver.c + integration/conserve_interp_hip.c + the reference's mpp.c / mpp_domain.c,
+    built by oracle/Makefile where /root/reference is present (tests/test_gpu_b2_driver.py runs it on the GPU): it must build,
+    resolve the two entry points from OUR object and everything fg_* from libfregrid_hip.so."""
+    if not os.path.isdir(REF):
+        pytest.skip("needs /root/reference (build-time only)")
+    _run(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/b2_driver"])
+    exe = os.path.join(ROOT, "oracle", "_ref", "b2_driver")
+    assert os.path.exists(exe)
+    sym = _run(["nm", "-D", "--undefined-only", exe]).stdout
+    assert "fg_plan_create" in sym and "fg_plan_apply" in sym and "fg_plan_accumulate_cell_sums" in sym
+    defined = _run(["nm", "--defined-only", exe]).stdout
+    assert re.search(r"\bT setup_conserve_interp\b", defined) and re.search(r"\bT do_scalar_conserve_interp\b", defined)
+    assert re.search(r"\bT mpp_sum_double\b", defined) and re.search(r"\bT mpp_gather_field_int\b", defined)
