@@ -583,6 +583,10 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   }
   std::vector<hipEvent_t> ev_c(K, nullptr), ev_q(K, nullptr);
   hipEvent_t gc_e1 = nullptr, gc_e2 = nullptr;        // great-circle clip: the listed pairs run on stream B beside k_gc_walk
+  struct EvReturn {                                   // back to the cache on every way out of this function (HIPCHK / fail returns too)
+    hipEvent_t &a, &b;
+    ~EvReturn() { g_handles.put_sync_event(a); g_handles.put_sync_event(b); a = b = nullptr; }
+  } ev_return{gc_e1, gc_e2};
   if (gc_split && K == 1) {
     if (!pl->stream_b) pl->stream_b = g_handles.get_stream(pl->device);
     gc_e1 = g_handles.get_sync_event(); gc_e2 = g_handles.get_sync_event();
@@ -661,7 +665,6 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms); ptb.collect(pl->phase_ms);   // (also hands the timing events back on every exit below)
   for (hipEvent_t e : ev_c) g_handles.put_sync_event(e);
   for (hipEvent_t e : ev_q) g_handles.put_sync_event(e);
-  g_handles.put_sync_event(gc_e1); g_handles.put_sync_event(gc_e2);
   HIPCHK(hipGetLastError());
   if (hc->total[0] > nentries) { caps->entries = hc->total[0]; return FG_RETRY; }
   if (hc->total[0] > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
