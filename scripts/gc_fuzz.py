@@ -1,11 +1,12 @@
 """Randomised A/B of the great-circle clip: three passes (k_gc_screen / k_gc_solve / k_gc_walk + list) against the one-kernel clip on
 pairs of randomly rotated, randomly sized grids (lat-lon windows, cubed-sphere faces, tripolar) -- exchange cells and areas must be
-bit-identical, or both must stop with the same reference error.   usage: python scripts/gc_fuzz.py [cases] [seed]"""
+bit-identical, or both must stop with the same reference error; small cases also against the brute-force CPU oracle.   usage: python scripts/gc_fuzz.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from conftest import load_package
+import orc
 fg = load_package()
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -58,7 +59,7 @@ def run(a, b, split):
     return x, "", st
 
 
-npairs = nx_tot = nerr = ndef = 0
+npairs = nx_tot = nerr = ndef = norc = nbit = ncmp = 0
 for ci in range(ncase):
     a, b = random_grid(), random_grid()
     (x0, e0, s0), (x1, e1, s1) = run(a, b, 0), run(a, b, 1)
@@ -72,7 +73,17 @@ for ci in range(ncase):
             assert np.array_equal(x0[k], x1[k]), (ci, k)
         assert np.array_equal(x0["area"].view(np.uint64), x1["area"].view(np.uint64)), ci
     npairs += s1["pairs"]; nx_tot += len(x1["area"]); ndef += s1["deferred"]
+    if a[0] * a[1] * b[0] * b[1] <= 1_500_000:               # small enough for the brute-force CPU oracle (gc_oracle.c)
+        o = orc.orc_create_xgrid_gc(a[0], a[1], b[0], b[1], a[2], a[3], b[2], b[3])
+        assert o["n"] == len(x1["area"]), (ci, o["n"], len(x1["area"]))
+        if o["n"]:
+            for k in ("i_in", "j_in", "i_out", "j_out"):
+                assert np.array_equal(x1[k], o[k]), (ci, k)
+            assert np.max(np.abs(x1["area"] - o["area"]) / o["area"]) < 1e-10, ci
+            nbit += int(np.sum(x1["area"].view(np.uint64) == o["area"].view(np.uint64))); ncmp += o["n"]
+        norc += 1
     print(f"case {ci}: {a[0]}x{a[1]} vs {b[0]}x{b[1]}: pairs {s1['pairs']}, nxgrid {len(x1['area'])}, listed {s1['deferred']}", flush=True)
 fg.lib().fg_set_gc_split(1)
 print(f"gc_fuzz: {ncase} grid pairs, {ncase - nerr} clipped ({nerr} stopped by the same reference error in both), "
-      f"{npairs} candidate pairs, {nx_tot} exchange cells, {ndef} pairs through the list: all bit-identical")
+      f"{npairs} candidate pairs, {nx_tot} exchange cells, {ndef} pairs through the list: all bit-identical; {norc} pairs of grids also "
+      f"against the CPU oracle: lists identical, areas within 1e-10, {nbit} of {ncmp} areas bit-identical")
