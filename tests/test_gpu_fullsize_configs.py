@@ -199,3 +199,29 @@ def test_mass_gap_equals_the_references(fg, gpu_ok):
     else:
         assert abs(gap - gold["gap"]) < 1e-3 * abs(gold["gap"])
     plan.destroy()
+
+
+@pytest.mark.parametrize("ni,nlon,nlat,nexp", [(384, 1440, 720, 4160160), (768, 2880, 1440, 16674181)])
+def test_great_circle_three_passes_equal_one_kernel_at_full_size(fg, gpu_ok, ni, nlon, nlat, nexp):
+    """The three-pass great-circle clip against the one-kernel clip (the version pinned to the oracle) at the BASELINE sizes:
+    identical exchange cells, areas bit for bit; the counts are the ones every round has measured."""
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    res = []
+    try:
+        for split in (0, 1):
+            fg.lib().fg_set_gc_split(split)
+            plan = fg.XgridPlan.create_great_circle(grids, fg.GridConfig(nlon, nlat, lo, la))
+            plan.finalize()
+            x = plan.get_xgrid()
+            res.append((x["t_in"], x["i_in"], x["j_in"], x["i_out"], x["j_out"], x["area"], plan.stats()))
+            plan.destroy()
+    finally:
+        fg.lib().fg_set_gc_split(1)
+    a, b = res
+    assert len(a[5]) == len(b[5]) == nexp
+    for k in range(5):
+        assert np.array_equal(a[k], b[k])
+    assert np.array_equal(_bits(a[5]), _bits(b[5]))
+    assert a[6]["below"] == b[6]["below"] and b[6]["deferred"] < 0.03 * b[6]["pairs"]
