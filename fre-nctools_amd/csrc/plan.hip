@@ -557,9 +557,10 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     fgd_gc_cell_struct(gct_dev + pl->ntiles, 1, ndst, pl->D, st);
     fgd_src_field_index(order, pl->tiles_dev, pl->ntiles, nsrc, pl->src_idx_f, st);
   } else if (g_search_cull && !boxm) {
-    // destination cells first (their latitude range goes to dc->band_keys), then the source cells that can meet it
-    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, 0, ndst, pl->S, pl->D, bins, bin_cnt, order, nullptr, nullptr, dc->err, st, dc->band_keys, 0);
-    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, 0, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st, dc->band_keys, 1);
+    // the destination grid's latitude range from its corners (a 5 us reduction), then ONE record launch in which the source
+    // blocks that cannot meet it leave early (round 2 first ran a destination launch, then a source launch: two latency floors)
+    fgd_band_keys(d_lat_out, (long)(pl->nx_out + 1) * (pl->ny_out + 1), dc->band_keys, st);
+    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st, dc->band_keys, 2);
   } else
     fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st);
   if (boxm) fgd_box_cell_boxes(boxm->box, pl->S, st);

@@ -113,6 +113,9 @@ void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles
                       FgBins b, int *slot_cnt, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
                       unsigned long long *band_keys = nullptr, int cull = 0);
 void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c, unsigned *err, hipStream_t st);
+// band_keys[0] / [1] = ordered keys of max / ~min of lat[0..n) (the destination grid's corner latitudes); cull = 2 in fgd_cell_struct2
+// then means: keys already there, cull the source blocks in the same launch as the destination blocks
+void fgd_band_keys(const double *lat, long n, unsigned long long *band_keys, hipStream_t st);
 void fgd_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt, hipStream_t st);
 // bin fill + list of the source cells whose candidate scan gets a whole wave
 void fgd_bin_fill(int ndst, FgCells D, FgBins b, int *slot_fill, const int *slot_start, FgBinEntry *entries, int cap,

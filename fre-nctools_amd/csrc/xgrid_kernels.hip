@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
     const int d0 = ((int)blockIdx.x - nbS) * 256, d = d0 + threadIdx.x;
     const int nv = d_cell_record(tiles + ntiles, 1, ndst, D, err, d0, vtile, box, &tl);
     d_bin_insert<false>(d < ndst && nv != 0, d, box[0], box[1], box[2], box[3], box[4], b, slot_cnt, nullptr, nullptr, 0);
-    if (band_keys) {                                    // latitude range of the destination cells, for the culling of a later launch
+    if (band_keys && cull != 2) {                       // latitude range of the destination cells, for the culling of a later launch
       // one pair of atomics per BLOCK, and only when it would change the value: thousands of same-address atomics serialise
       // at ~12 ns each (a wave-level version of this cost the kernel 0.37 ms)
       __shared__ unsigned long long sh_k[2][4];
@@ -433,6 +433,32 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
       }
     }
   }
+}
+
+// latitude range of the destination grid from its corner array alone (= the range over its cells' lat_min / lat_max): lets the
+// culling search keep the ONE fused record launch instead of a destination launch followed by a source launch
+__global__ __launch_bounds__(256) void k_band_keys(const double *lat, long n, unsigned long long *band_keys)
+{
+  __shared__ unsigned long long sh_k[2][4];
+  unsigned long long kmax = 0ull, kmin = 0ull;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const unsigned long long k = d_ord_key(lat[i]);
+    kmax = max(kmax, k); kmin = max(kmin, ~k);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) { kmax = max(kmax, __shfl_xor(kmax, o)); kmin = max(kmin, __shfl_xor(kmin, o)); }
+  if ((threadIdx.x & 63) == 0) { sh_k[0][threadIdx.x >> 6] = kmax; sh_k[1][threadIdx.x >> 6] = kmin; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    kmax = max(max(sh_k[0][0], sh_k[0][1]), max(sh_k[0][2], sh_k[0][3]));
+    kmin = max(max(sh_k[1][0], sh_k[1][1]), max(sh_k[1][2], sh_k[1][3]));
+    atomicMax(&band_keys[0], kmax);
+    atomicMax(&band_keys[1], kmin);
+  }
+}
+void fgd_band_keys(const double *lat, long n, unsigned long long *band_keys, hipStream_t st)
+{
+  if (n > 0) k_band_keys<<<(int)min(64L, (n + 2047) / 2048), 256, 0, st>>>(lat, n, band_keys);
 }
 
 // stand-alone bin count for searches whose cell records come from another kernel (great circle)
