@@ -372,10 +372,12 @@ def main():
     # communication schedule of the decomposition (built once, like the band extents): the source cells cut by a band
     # boundary are the only ones whose partial sums live on more than one rank
     bidx_t = None
+    a_in_full = None
     if world > 1:
         p0 = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t, mean_dlat, mean_dlon,
                                      device=local_rank, stream=stream)
         cs = p0.get_cell_struct(0, ncell_in)          # 0 = source cells
+        a_in_full = np.asarray(p0.get_cell_area(nlon * ny_band)[0]).copy()   # (a culled plan reports area 0 for the cells it skipped)
         p0.destroy()
         bidx = fg.boundary_source_cells(cs["lat_min"], cs["lat_max"], la, nlat, world)
         bidx_t = torch.from_numpy(bidx.astype(np.int64)).to(dev)
@@ -561,7 +563,7 @@ def main():
             except Exception:
                 pass
         # mass conservation (conserve_interp.c:874-907): input flux uses get_grid_area cell areas
-        a_in = np.concatenate([np.asarray(fg_area) for fg_area in [p.get_cell_area(nlon * ny_band)[0]]])
+        a_in = a_in_full if a_in_full is not None else np.asarray(p.get_cell_area(nlon * ny_band)[0])
         gsum_in = float(np.sum(src_h[0] * a_in))
         line = {
             "metric": "exchange-cells/s", "value": value, "unit": "exchange-cells/s",
