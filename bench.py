@@ -550,6 +550,17 @@ def main():
                   "kernel_ms_separate_arrays": apply_kernel_ms}
         roof_a["frac"] = roof_a["achieved"] / HBM_PEAK_GBS if roof_a["achieved"] else None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and world > 1:       # a band's launch: the per-pair instruction count of the single-GPU PMC pass, scaled
+            try:
+                tr = json.load(open(pmc))
+                if tr.get("k_clip_quad_valu_insts") and tr.get("k_clip_quad_pairs") and clip_ms > 0:
+                    insts = tr["k_clip_quad_valu_insts"] * stats["pairs"] / tr["k_clip_quad_pairs"]
+                    roof["achieved"] = 4.0 * insts / (clip_ms * 1e-3)
+                    roof["frac"] = roof["achieved"] / valu_peak
+                    roof["valu_insts_source"] = ("profiles/pmc_traffic.json (static: SQ_INSTS_VALU of the single-GPU launch, scaled by this "
+                                                 "rank's candidate pairs / the profiled launch's)")
+            except Exception:
+                pass
         if os.path.exists(pmc) and world == 1:      # the PMC passes were taken on the single-GPU launch sizes
             try:
                 tr = json.load(open(pmc))

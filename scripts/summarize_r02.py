@@ -105,6 +105,7 @@ if k in ms and "SQ_INSTS_VALU" in ms[k]:
 for kk in ("k_gc_walk", "k_gc_solve", "k_gc_screen"):
     if kk in mg and "FETCH_SIZE" in mg[kk] and "WRITE_SIZE" in mg[kk]:
         traffic[kk] = (2 * mg[kk]["FETCH_SIZE"] + mg[kk]["WRITE_SIZE"]) * 1024.0
+traffic["k_clip_quad_pairs"] = 4589624      # candidate pairs of the launch the counters were taken on (C384 -> 1440x720, one rank)
 traffic["round"] = "round 2"
 traffic["_note"] = ("HBM-side bytes per launch from rocprofv3 PMC, C384 -> 1440x720: k_apply from the by-size fabric request counters "
                     "(TCC_EA0_RDREQ_{32,64,128}B, TCC_EA0_WRREQ_64B); k_clip_quad and the k_gc_* kernels = 2*FETCH_SIZE + WRITE_SIZE; "
