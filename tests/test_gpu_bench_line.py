@@ -32,3 +32,23 @@ def test_bench_line_schema(gpu_ok):
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "exchange-cells/s" and cb["sample"]
     assert abs(d["mass_rel_err"]) < 2e-9 and abs(d["mass_rel_err_xgrid"]) < 1e-13
+
+
+def test_bench_two_ranks_rehearsal(gpu_ok):
+    """`bench.py --gpus 2` the way the driver launches it (torch.distributed.run, one process per rank), but with both ranks on
+    this one GPU and gloo for the collectives (FG_BENCH_BACKEND=gloo): times mean nothing, the N > 1 code path does -- the
+    banded, culled search, the boundary-cell exchange, the sweep of a band, the C768 job.  (This rehearsal found a fault and a
+    wrong flux sum that no single-process test could see.)"""
+    env = dict(os.environ, FG_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "1",
+                        "--apply-steps", "5"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["nxgrid"] == 4160000                           # the two bands together: the single-rank count
+    assert abs(d["mass_rel_err"]) < 2e-9 and abs(d["mass_rel_err_xgrid"]) < 1e-13
+    assert d["c768_order2"]["nxgrid"] == 16673872 and d["c768_order2"]["n_gpus"] == 2
+    assert 0 < d["roofline"]["frac"] <= 1 and d["value"] > 0
