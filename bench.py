@@ -247,12 +247,8 @@ def banded_search_job(fg, torch, dist, dev, local_rank, world, rank, ni, nlon, n
             plan[0].destroy()
         p = mk()
         if world > 1:
-            p.copy_cell_sums(total)
-            fg.allreduce_cell_sums_sparse(total, bidx_t, ncell)
-            torch.cuda.current_stream().synchronize()
-            p.finalize(total.data_ptr())
-        else:
-            p.finalize(None)
+            exchange_in_place(fg, torch, p, bidx_t, ncell, dev)
+        p.finalize(None)
         plan[0] = p
         return p
     fg.lib().fg_set_profiling(0)
@@ -281,6 +277,20 @@ def banded_search_job(fg, torch, dist, dev, local_rank, world, rank, ni, nlon, n
             "nxgrid": int(nx.item()), "ms_per_step": med / steps * 1e3, "ms_per_step_min": min(reps) / steps * 1e3,
             "exchange_cells_per_s": steps * int(nx.item()) / med, "steps": steps, "repeats": repeats, "n_gpus": world,
             "boundary_cells_exchanged": (int(bidx_t.numel()) if bidx_t is not None else 0)}
+
+
+class _DeviceDoubles:
+    """__cuda_array_interface__ view of n doubles at a device pointer: torch.as_tensor aliases it (no copy)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def exchange_in_place(fg, torch, plan, bidx_t, ncell, dev):
+    """The boundary cells' (area, clon, clat) sums all-reduced IN the plan's own array (no 21 MB copy, no host sync: the plan's
+    stream is torch's current stream, and torch orders the collective after the search and before the centroid pass)."""
+    sums = torch.as_tensor(_DeviceDoubles(plan.cell_sums_ptr(), 3 * ncell), device=dev)
+    fg.allreduce_cell_sums_sparse(sums, bidx_t, ncell)
 
 
 def main():
@@ -373,6 +383,7 @@ def main():
     # boundary are the only ones whose partial sums live on more than one rank
     bidx_t = None
     a_in_full = None
+    exchange_check = None
     if world > 1:
         p0 = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t, mean_dlat, mean_dlon,
                                      device=local_rank, stream=stream)
@@ -382,6 +393,19 @@ def main():
         bidx = fg.boundary_source_cells(cs["lat_min"], cs["lat_max"], la, nlat, world)
         bidx_t = torch.from_numpy(bidx.astype(np.int64)).to(dev)
         fg.lib().fg_set_search_cull(1)          # each rank builds records only for the source cells that can meet its band
+        # one-off check of the exchange the timed steps use (in place, boundary cells only) against a dense all-reduce of copies
+        pc = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t, mean_dlat, mean_dlon,
+                                     device=local_rank, stream=stream)
+        dense = torch.empty(3 * ncell_in, dtype=torch.float64, device=dev)
+        pc.copy_cell_sums(dense)
+        mine = dense[:ncell_in] != 0
+        fg.allreduce_cell_sums(dense)
+        exchange_in_place(fg, torch, pc, bidx_t, ncell_in, dev)
+        got = torch.as_tensor(_DeviceDoubles(pc.cell_sums_ptr(), 3 * ncell_in), device=dev).view(3, ncell_in)[:, mine]
+        want = dense.view(3, ncell_in)[:, mine]
+        exchange_check = float(((got - want).abs() / want.abs().clamp_min(1e-300)).max().item()) if int(mine.sum()) else 0.0
+        torch.cuda.synchronize()
+        pc.destroy()
 
     def step():
         if plan[0] is not None:
@@ -389,12 +413,8 @@ def main():
         p = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t,
                                     mean_dlat, mean_dlon, device=local_rank, stream=stream)
         if world > 1:
-            p.copy_cell_sums(total_sums)
-            fg.allreduce_cell_sums_sparse(total_sums, bidx_t, ncell_in)
-            torch.cuda.current_stream().synchronize()
-            p.finalize(total_sums.data_ptr())
-        else:
-            p.finalize(None)
+            exchange_in_place(fg, torch, p, bidx_t, ncell_in, dev)
+        p.finalize(None)
         plan[0] = p
         return p
 
@@ -590,6 +610,7 @@ def main():
                        "exchange": (None if world == 1 else f"all-reduce of the (area, clon, clat) sums of the {int(bidx_t.numel())} source "
                                     f"cells cut by band boundaries ({100.0 * int(bidx_t.numel()) / ncell_in:.1f} % of {ncell_in}): partial sums, one collective; "
                                     f"setup_conserve_interp's default hands running sums from rank to rank instead (bit-reproducible, parallel.ordered_cell_sums)")},
+            "exchange_check_max_rel": exchange_check,
             "remapped_points_per_s": remap_pts, "apply_ms_per_call": dta / apply_steps * 1e3, "apply_levels": nz,
             "apply_device_ms_per_call": apply_call_ms,
             "remapped_points_per_s_interleaved": apply_steps * ndst * nb / dtb,

@@ -52,3 +52,4 @@ def test_bench_two_ranks_rehearsal(gpu_ok):
     assert abs(d["mass_rel_err"]) < 2e-9 and abs(d["mass_rel_err_xgrid"]) < 1e-13
     assert d["c768_order2"]["nxgrid"] == 16673872 and d["c768_order2"]["n_gpus"] == 2
     assert 0 < d["roofline"]["frac"] <= 1 and d["value"] > 0
+    assert d["exchange_check_max_rel"] is not None and d["exchange_check_max_rel"] < 1e-13      # in-place boundary exchange == dense all-reduce
