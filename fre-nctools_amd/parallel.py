@@ -167,7 +167,8 @@ def ordered_cell_sums(plans, device=0):
     adds zeros to it.  Returns the device tensor [3 * ncells_in]; identical on every rank."""
     import torch
     import torch.distributed as dist
-    dev = f"cuda:{device}"
+    dev = device if isinstance(device, str) else f"cuda:{device}"         # ("cpu" with stand-in plans: the gloo test of this logic)
+    on_gpu = dev.startswith("cuda")
     ncell = plans[0].ncells_in
     total = torch.zeros(3 * ncell, dtype=torch.float64, device=dev)
     W = world_size()
@@ -175,7 +176,8 @@ def ordered_cell_sums(plans, device=0):
         for p in plans:
             if p.nxgrid > 0:
                 p.accumulate_cell_sums(total)
-        torch.cuda.synchronize(device)
+        if on_gpu:
+            torch.cuda.synchronize(dev)
         return total
     rank = dist.get_rank()
     # source cells with exchange cells on more than one rank
@@ -204,5 +206,6 @@ def ordered_cell_sums(plans, device=0):
     _all_reduce(mine)                                                      # every other cell: its one rank's value + zeros
     if nsh:
         mine[idx3] = run
-    torch.cuda.synchronize(device)
+    if on_gpu:
+        torch.cuda.synchronize(dev)
     return mine

@@ -188,3 +188,78 @@ def test_write_branch_gathers_to_one_file(fg, tmp_path):
     op, o1 = np.argsort(kp, kind="stable"), np.argsort(k1, kind="stable")
     for k in ("area", "di_in", "dj_in"):
         assert np.allclose(par[k][op], one[k][o1], rtol=1e-12, atol=1e-300)
+
+
+class _CpuPlan:
+    """Stand-in for XgridPlan in the hand-over logic of parallel.ordered_cell_sums: exchange cells of ONE (rank, output tile) as
+    (source cell, area, clon, clat) lists in exchange-cell order; accumulate_cell_sums adds them one by one onto a running total,
+    as fg_plan_accumulate_cell_sums does on the device."""
+
+    def __init__(self, ncell, src, vals):
+        self.ncells_in, self.src, self.vals, self.nxgrid = ncell, src, vals, len(src)
+
+    def accumulate_cell_sums(self, total, cells=None):
+        allow = None if cells is None else set(int(c) for c in cells.tolist())
+        t = total.view(3, self.ncells_in)
+        for s, v in zip(self.src, self.vals):
+            if allow is None or s in allow:
+                for c in range(3):
+                    t[c, s] = t[c, s] + v[c]
+
+
+def _ordered_case(ncell, world, ntile, seed=5):
+    """random exchange cells per (tile, rank): cell -> list of (area, clon, clat), with cells shared by 2 and by 3 ranks and by two tiles"""
+    rng = np.random.default_rng(seed)
+    plans = [[None] * world for _ in range(ntile)]
+    for n in range(ntile):
+        for r in range(world):
+            src, vals = [], []
+            for s in range(ncell):
+                on = (s % world == r) or (s % 5 == 0 and (r - s) % world in (0, 1)) or (s % 7 == 0) or (n == 1 and s % 3 == 0 and r == 0)
+                if on:
+                    for _ in range(int(rng.integers(1, 4))):
+                        src.append(s); vals.append(tuple(float(x) for x in rng.uniform(0.1, 1.0, 3) * 10.0 ** rng.integers(-3, 4)))
+            order = np.argsort(np.asarray(src), kind="stable")
+            plans[n][r] = ([src[i] for i in order], [vals[i] for i in order])
+    return plans
+
+
+def _ordered_worker(rank, world, initfile, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from conftest import load_package
+    fg = load_package()
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    ncell, ntile = 60, 2
+    case = _ordered_case(ncell, world, ntile)
+    plans = [_CpuPlan(ncell, *case[n][rank]) for n in range(ntile)]
+    total = fg.ordered_cell_sums(plans, device="cpu")
+    np.save(os.path.join(outdir, f"ordered_{rank}.npy"), total.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ordered_cell_sums_hand_over_equals_the_serial_sum(fg, tmp_path, world):
+    """parallel.ordered_cell_sums on CPU stand-ins (gloo): the totals every rank ends with must carry the bits of the reference's
+    serial accumulation -- output tile after output tile, rank after rank, exchange cell after exchange cell
+    (conserve_interp.c:203-221) -- also for cells present on three ranks and in two tiles, where a sum of partial sums differs."""
+    import torch.multiprocessing as mp
+    td = str(tmp_path)
+    mp.spawn(_ordered_worker, args=(world, os.path.join(td, "init"), td), nprocs=world, join=True)
+    ncell, ntile = 60, 2
+    case = _ordered_case(ncell, world, ntile)
+    want = np.zeros((3, ncell))
+    partial = np.zeros((3, ncell))
+    for n in range(ntile):
+        for r in range(world):
+            part = np.zeros((3, ncell))
+            for s, v in zip(*case[n][r]):
+                for c in range(3):
+                    want[c, s] = want[c, s] + v[c]
+                    part[c, s] = part[c, s] + v[c]
+            partial += part
+    got = [np.load(os.path.join(td, f"ordered_{r}.npy")).reshape(3, ncell) for r in range(world)]
+    for g in got:
+        assert np.array_equal(g.view(np.uint64), want.view(np.uint64))
+    assert not np.array_equal(partial.view(np.uint64), want.view(np.uint64))          # the test data does tell the two orders apart
