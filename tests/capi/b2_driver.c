@@ -13,6 +13,7 @@
  *   scenario 5: conserve_order2, nz = 1, MONOTONIC             (fg_plan_apply_ex: the limiter, conserve_interp.c:617-742)
  *   scenario 6: conserve_order1, nz = 1, TARGET, cell_methods = sum, grid_in[].weight     (the remaining options of :561-616, :815-870)
  *   scenario 7: conserve_order1 | GREAT_CIRCLE, nz = 1         (fg_plan_create_great_circle, conserve_interp.c:164-168)
+ *   scenario 8: conserve_order2, nz = 1, has_missing = 1, grad_mask set on every 5th diagonal   (conserve_interp.c:743-813 with missing data)
  *   out.bin per scenario: int nxgrid; int t_in,i_in,j_in,i_out,j_out [nxgrid]; double area[nxgrid]; (order 2: double di, dj [nxgrid]);
  *                         double field_out[nz * nlon * nlat]
  * Input fields are index formulas that a test can restate exactly. */
@@ -61,8 +62,8 @@ int main(int argc, char **argv)
 
     f = fopen(argv[4], "wb");
     if (!f) { perror(argv[4]); return 2; }
-    for (sc = 1; sc <= 7; sc++) {
-      const int order = (sc == 2 || sc >= 6) ? 1 : 2, nz = (sc == 2 || sc >= 5) ? 1 : 2, halo = (order == 2) ? 1 : 0;
+    for (sc = 1; sc <= 8; sc++) {
+      const int order = (sc == 2 || sc == 6 || sc == 7) ? 1 : 2, nz = (sc == 2 || sc >= 5) ? 1 : 2, halo = (order == 2) ? 1 : 0;
       unsigned int opcode = (order == 2) ? CONSERVE_ORDER2 : CONSERVE_ORDER1;
       if (sc == 3) opcode |= WRITE | CHECK_CONSERVE;
       if (sc == 4) opcode |= READ;
@@ -87,7 +88,7 @@ int main(int argc, char **argv)
         }
       }
       setup_conserve_interp(6, grid_in, 1, grid_out, interp, opcode);
-      var.interp_method = order; var.has_missing = (sc == 2); var.missing = -1.e10;
+      var.interp_method = order; var.has_missing = (sc == 2 || sc == 8); var.missing = -1.e10;
       var.cell_methods = (sc == 6) ? CELL_METHODS_SUM : CELL_METHODS_MEAN;
       for (t = 0; t < 6; t++) {
         grid_in[t].weight_exist = (sc == 6);
@@ -101,7 +102,7 @@ int main(int argc, char **argv)
         field_in[t].data = (double *)xcalloc((size_t)nz * nd, sizeof(double));
         for (k = 0; k < nz; k++) for (j = 0; j < ni + 2 * halo; j++) for (i = 0; i < ni + 2 * halo; i++) {
           double v = f_data(t, k, j, i);
-          if (sc == 2 && (t + j * ni + i) % 7 == 0) v = var.missing;
+          if ((sc == 2 || sc == 8) && (t + j * ni + i) % 7 == 0) v = var.missing;
           field_in[t].data[(size_t)k * nd + (size_t)j * (ni + 2 * halo) + i] = v;
         }
         if (order == 2) {
@@ -111,6 +112,7 @@ int main(int argc, char **argv)
           for (k = 0; k < nz; k++) for (j = 0; j < ni; j++) for (i = 0; i < ni; i++) {
             field_in[t].grad_x[(size_t)k * nc + (size_t)j * ni + i] = f_gx(t, k, j, i);
             field_in[t].grad_y[(size_t)k * nc + (size_t)j * ni + i] = f_gy(t, k, j, i);
+            if (sc == 8) field_in[t].grad_mask[(size_t)j * ni + i] = ((i + j) % 5 == 0);
           }
         }
       }

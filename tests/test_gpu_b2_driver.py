@@ -54,7 +54,7 @@ def test_c_replacement_object_equals_the_python_mirror(fg, gpu_ok, tmp_path):
     lo, la = fg.latlon_corners(nlon, nlat)
     bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
     first = {}
-    for sc, (order, nz, missing) in enumerate(((2, 2, None), (1, 1, -1.e10), (2, 2, None), (2, 2, None), (2, 1, None), (1, 1, None), (1, 1, None)), start=1):
+    for sc, (order, nz, missing) in enumerate(((2, 2, None), (1, 1, -1.e10), (2, 2, None), (2, 2, None), (2, 1, None), (1, 1, None), (1, 1, None), (2, 1, -1.e10)), start=1):
         nx = int(take(np.int32, 1)[0])
         c = {k: take(np.int32, nx) for k in ("t_in", "i_in", "j_in", "i_out", "j_out")}
         c["area"] = take(np.float64, nx)
@@ -108,6 +108,10 @@ def test_c_replacement_object_equals_the_python_mirror(fg, gpu_ok, tmp_path):
         if order == 2:
             assert np.array_equal(bits(ic.di_in), bits(c["di"])) and np.array_equal(bits(ic.dj_in), bits(c["dj"]))
         field_in = _fields(fg, ni, order, nz, missing)
+        if sc == 8:
+            jj, ii = np.meshgrid(np.arange(ni), np.arange(ni), indexing="ij")
+            for fc in field_in:
+                fc.grad_mask = ((ii + jj) % 5 == 0).astype(np.int32)
         run_op = opcode
         for fc in field_in:
             fc.var = [fg.VarConfig(interp_method=opcode, has_missing=int(missing is not None), missing=missing if missing is not None else -1.e20,
