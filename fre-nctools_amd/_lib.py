@@ -17,7 +17,8 @@ class FregridHipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfregrid_hip.so")
+    # FREGRID_HIP_LIB: another build of the same library (same-box A/B timing of kernel variants, scripts/); never a fallback
+    return os.environ.get("FREGRID_HIP_LIB") or os.path.join(_HERE, "libfregrid_hip.so")
 
 
 # every symbol include/fregrid_hip.h declares (tests/test_cpu_capi_and_oracle.py::test_library_exports_every_declared_symbol)

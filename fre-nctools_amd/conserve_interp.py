@@ -241,7 +241,14 @@ class XgridPlan:
 
     def accumulate_cell_sums(self, total_t, cells_t=None):
         """total_t[3, ncells_in] += this plan's exchange cells, one by one in exchange-cell order, continuing from the values
-        already there (conserve_interp.c:203-221); cells_t: int32 device tensor restricting the update to those source cells."""
+        already there (conserve_interp.c:203-221); cells_t: int32 device tensor restricting the update to those source cells.
+
+        The kernel runs on the PLAN's stream while total_t / cells_t are usually the product of torch ops still queued on torch's
+        current stream (a zero fill, an index_put of the sums received from another rank, the wait on a collective): that
+        stream is drained first, or the kernel would read stale values.  The C call returns with the plan's stream drained, so
+        torch ops issued afterwards see the result."""
+        if getattr(total_t, "is_cuda", False):
+            _torch().cuda.current_stream(total_t.device).synchronize()
         check(lib().fg_plan_accumulate_cell_sums(self._h, C.c_void_p(total_t.data_ptr()),
                                                  C.c_void_p(cells_t.data_ptr()) if cells_t is not None else None,
                                                  int(cells_t.numel()) if cells_t is not None else 0))

@@ -694,10 +694,37 @@ __device__ int gc_clip_fast(const double *a, const double *b, double *out)
 // FgCells reuse: verts[c*16 + 0..11] = corners xyz (clockwise), [12..14] = cap centre, [15] = cos(cap radius), or -2
 // when the cell is too large for a useful cap.  lat/lon box = the cap's, so the candidate scan is a superset.
 #define GC_CAP_MARGIN 2.e-6
-__global__ __launch_bounds__(256) void k_gc_cell_struct(const FgTileXyz *tiles, int ntiles, int ncells, FgCells c)
+// band_mode 1 (the destination launch of a culling search): the block also folds its cells' latitude ranges into band_keys
+// {max key of lat_max, max of ~key of lat_min} -- one pair of atomics per block, and only when they would change the value.
+// band_mode 2 (the source launch that follows): a cell whose cap latitude range cannot meet that band -- the candidate scan's
+// strict latitude reject (d_box_pass) would drop every one of its pairs -- gets nv = 0, area 0 and nothing else: no record, no
+// spherical-excess area (the software-x87 acosl is the expensive part of this kernel), no query, no candidates.
+__device__ __forceinline__ bool d_gc_cell_record(const FgTileXyz *tiles, int ntiles, int s, FgCells c, const unsigned long long *cull,
+                                                 double *lat_lo, double *lat_hi);
+__global__ __launch_bounds__(256) void k_gc_cell_struct(const FgTileXyz *tiles, int ntiles, int ncells, FgCells c,
+                                                         unsigned long long *band_keys, int band_mode)
 {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ncells) return;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  double lo = 0, hi = 0;
+  const bool live = s < ncells && d_gc_cell_record(tiles, ntiles, s, c, band_mode == 2 ? band_keys : nullptr, &lo, &hi);
+  if (band_mode != 1) return;
+  __shared__ unsigned long long sh_k[2][4];
+  unsigned long long kmax = live ? d_ord_key(hi) : 0ull, kmin = live ? ~d_ord_key(lo) : 0ull;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) { kmax = max(kmax, __shfl_xor(kmax, o)); kmin = max(kmin, __shfl_xor(kmin, o)); }
+  if ((threadIdx.x & 63) == 0) { sh_k[0][threadIdx.x >> 6] = kmax; sh_k[1][threadIdx.x >> 6] = kmin; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    kmax = max(max(sh_k[0][0], sh_k[0][1]), max(sh_k[0][2], sh_k[0][3]));
+    kmin = max(max(sh_k[1][0], sh_k[1][1]), max(sh_k[1][2], sh_k[1][3]));
+    if (kmax > __hip_atomic_load(&band_keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&band_keys[0], kmax);
+    if (kmin > __hip_atomic_load(&band_keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&band_keys[1], kmin);
+  }
+}
+// returns false for a culled cell; *lat_lo / *lat_hi = the latitude range of the cell's box
+__device__ __forceinline__ bool d_gc_cell_record(const FgTileXyz *tiles, int ntiles, int s, FgCells c, const unsigned long long *cull,
+                                                 double *lat_lo, double *lat_hi)
+{
   int t = 0;
   while (t + 1 < ntiles && s >= tiles[t + 1].cell_off) t++;
   const FgTileXyz T = tiles[t];
@@ -707,15 +734,6 @@ __global__ __launch_bounds__(256) void k_gc_cell_struct(const FgTileXyz *tiles, 
   for (int k = 0; k < 4; k++) { v[k * 3] = T.x[idx[k]]; v[k * 3 + 1] = T.y[idx[k]]; v[k * 3 + 2] = T.z[idx[k]]; }
   double *o = c.verts + (size_t)s * 16;
   for (int k = 0; k < 12; k++) o[k] = v[k];
-  // cell area on the de-duplicated vertex list (addEnd merges the two pole corners of a lat-lon cap cell)
-  double p[12]; int n = 0;
-  for (int k = 0; k < 4; k++) {
-    bool dup = false;
-    for (int m = 0; m < n; m++) if (gc_same_point(p[m * 3], p[m * 3 + 1], p[m * 3 + 2], v[k * 3], v[k * 3 + 1], v[k * 3 + 2])) dup = true;
-    if (!dup) { p[n * 3] = v[k * 3]; p[n * 3 + 1] = v[k * 3 + 1]; p[n * 3 + 2] = v[k * 3 + 2]; n++; }
-  }
-  c.area[s] = gc_area(n, p, 3);
-  c.nv[s] = 4;
   // bounding cap
   double cx = v[0] + v[3] + v[6] + v[9], cy = v[1] + v[4] + v[7] + v[10], cz = v[2] + v[5] + v[8] + v[11];
   const double nrm = sqrt(cx * cx + cy * cy + cz * cz);
@@ -736,17 +754,33 @@ __global__ __launch_bounds__(256) void k_gc_cell_struct(const FgTileXyz *tiles, 
     if (r > 0.5) nocap = true;
   }
   const double hpi = 0.5 * GC_PI, tpi = 2.0 * GC_PI;
+  const double latc = nocap ? 0.0 : asin(fmin(1.0, fmax(-1.0, cz)));
+  const double lat_min = nocap ? -hpi : fmax(-hpi, latc - r), lat_max = nocap ? hpi : fmin(hpi, latc + r);
+  *lat_lo = lat_min; *lat_hi = lat_max;
+  c.lat_min[s] = lat_min; c.lat_max[s] = lat_max;
+  if (cull && cull[0]) {
+    const double bmax = d_ord_val(cull[0]), bmin = d_ord_val(~cull[1]);
+    if (lat_max <= bmin || lat_min >= bmax) { c.nv[s] = 0; c.area[s] = 0; return false; }
+  }
+  {
+    // cell area on the de-duplicated vertex list (addEnd merges the two pole corners of a lat-lon cap cell)
+    double p[12]; int n = 0;
+    for (int k = 0; k < 4; k++) {
+      bool dup = false;
+      for (int m = 0; m < n; m++) if (gc_same_point(p[m * 3], p[m * 3 + 1], p[m * 3 + 2], v[k * 3], v[k * 3 + 1], v[k * 3 + 2])) dup = true;
+      if (!dup) { p[n * 3] = v[k * 3]; p[n * 3 + 1] = v[k * 3 + 1]; p[n * 3 + 2] = v[k * 3 + 2]; n++; }
+    }
+    c.area[s] = gc_area(n, p, 3);
+    c.nv[s] = 4;
+  }
   if (nocap) {
     o[12] = 0; o[13] = 0; o[14] = 1; o[15] = -2.0;
-    c.lat_min[s] = -hpi; c.lat_max[s] = hpi; c.lon_min[s] = 0.0; c.lon_max[s] = tpi; c.lon_avg[s] = GC_PI;
-    return;
+    c.lon_min[s] = 0.0; c.lon_max[s] = tpi; c.lon_avg[s] = GC_PI;
+    return true;
   }
   o[12] = cx; o[13] = cy; o[14] = cz; o[15] = cos(r);
-  const double latc = asin(fmin(1.0, fmax(-1.0, cz)));
   double lonc = atan2(cy, cx);
   if (lonc < 0) lonc += tpi;
-  c.lat_min[s] = fmax(-hpi, latc - r);
-  c.lat_max[s] = fmin(hpi, latc + r);
   // longitude: a great-circle arc that stays clear of the pole is monotone in longitude, so the polygon's extent is
   // that of its corners; the angular margin becomes margin / cos(lat) in longitude.  Cells whose cap reaches a pole
   // (or nearly) take the whole circle.
@@ -764,6 +798,7 @@ __global__ __launch_bounds__(256) void k_gc_cell_struct(const FgTileXyz *tiles, 
     const double mlon = (GC_CAP_MARGIN + 1.e-9) / cosmin + 1.e-9;
     c.lon_min[s] = lonc + dmin - mlon; c.lon_max[s] = lonc + dmax + mlon; c.lon_avg[s] = lonc;
   }
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------ pair kernels
@@ -1262,9 +1297,9 @@ __global__ __launch_bounds__(64) void k_gc_clip_list(const int *list, int stride
 
 static inline int gc_nblk(long n, int t) { return (int)((n + t - 1) / t); }
 
-void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st)
+void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st, unsigned long long *band_keys, int band_mode)
 {
-  if (ncells > 0) k_gc_cell_struct<<<gc_nblk(ncells, 256), 256, 0, st>>>(tiles_dev, ntiles, ncells, c);
+  if (ncells > 0) k_gc_cell_struct<<<gc_nblk(ncells, 256), 256, 0, st>>>(tiles_dev, ntiles, ncells, c, band_keys, band_keys ? band_mode : 0);
 }
 
 void fgd_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D,

@@ -553,8 +553,10 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   ptot.begin(PH_SEARCH_TOTAL);
   pt.begin(PH_CELL_STRUCT);
   if (gc) {
-    fgd_gc_cell_struct(gct_dev, pl->ntiles, nsrc, pl->S, st);
-    fgd_gc_cell_struct(gct_dev + pl->ntiles, 1, ndst, pl->D, st);
+    // destination cells first: a culling search (a rank's band of the target) folds their latitude ranges into band_keys, and
+    // the source launch drops the cells that cannot meet that range before their (expensive) spherical-excess area
+    fgd_gc_cell_struct(gct_dev + pl->ntiles, 1, ndst, pl->D, st, g_search_cull ? dc->band_keys : nullptr, 1);
+    fgd_gc_cell_struct(gct_dev, pl->ntiles, nsrc, pl->S, st, g_search_cull ? dc->band_keys : nullptr, 2);
     fgd_src_field_index(order, pl->tiles_dev, pl->ntiles, nsrc, pl->src_idx_f, st);
   } else if (g_search_cull && !boxm) {
     // the destination grid's latitude range from its corners (a 5 us reduction), then ONE record launch in which the source

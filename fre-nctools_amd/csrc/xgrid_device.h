@@ -78,6 +78,19 @@ __device__ __forceinline__ bool d_pair_live(const FgPairSpace &ps, int p)
 }
 #endif
 static inline long fgd_pairs_total(const FgPairSpace &ps) { return (long)ps.regcap * ps.nreg; }
+#ifdef __HIPCC__
+// doubles as unsigned keys with the same order (atomicMax over latitudes: the band of a culling search)
+__device__ __forceinline__ unsigned long long d_ord_key(double v)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double d_ord_val(unsigned long long k)
+{
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+#endif
 
 // source tiles + the destination tile as a kernel argument (no descriptor upload before the first kernel)
 #define FG_TILESET_MAX 8
@@ -231,7 +244,9 @@ void fgd_accumulate_cell_sums(int n, const int *cells, int nsrc, const int *xoff
                               double *total, hipStream_t st);
 
 // ---- great-circle path (gc_kernels.hip)
-void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st);
+// band_keys / band_mode: see k_gc_cell_struct (1: fold this launch's latitude ranges into the keys, 2: cull by them)
+void fgd_gc_cell_struct(const FgTileXyz *tiles_dev, int ntiles, int ncells, FgCells c, hipStream_t st,
+                        unsigned long long *band_keys = nullptr, int band_mode = 0);
 void fgd_gc_clip(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
                  double *tmp_area, int *nacc, int *defer_list, int *defer_cnt, unsigned long long *stats, unsigned *err, hipStream_t st);
 // buffers of the three-pass clip (k_gc_screen / k_gc_solve / k_gc_walk, gc_kernels.hip)

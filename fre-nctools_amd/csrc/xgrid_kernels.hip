@@ -27,6 +27,9 @@
 // trees, sin/cos included (geom.hip.h, sincos_glibc.h): lists, areas and centroid integrals are the reference's bits.
 // Launched either for exact sizes or for fixed capacities with the true counts read from device memory (np_dev, cap).
 #include "xgrid_device.h"
+#ifndef FG_EXP
+#define FG_EXP 0      // timing experiments (scripts/exp_build.sh): 1 = no integrals, 2 = no clip loop
+#endif
 // The 3.5 KB sin/cos table of sincos_glibc.h is copied into LDS by every kernel of this file that takes sines: the lookups
 // are per-lane gathers (index = latitude * 128), and from LDS they cost the clip kernel 0.42 ms instead of 0.48 ms from global
 // memory, although the extra LDS and registers lower its occupancy from 5 to 4 waves per SIMD.
@@ -179,17 +182,7 @@ void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *st
 // ---------------------------------------------------------------------------------------
 // per-cell records
 // ---------------------------------------------------------------------------------------
-// doubles as unsigned keys with the same order (for atomicMax over latitudes)
-__device__ __forceinline__ unsigned long long d_ord_key(double v)
-{
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double d_ord_val(unsigned long long k)
-{
-  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-  return __longlong_as_double((long long)b);
-}
+// (d_ord_key / d_ord_val: xgrid_device.h)
 
 // body shared by the two kernels below: record of cell s0 + threadIdx.x of `ncells` cells described by `tiles`; the 16 vertex
 // doubles are staged so that the block stores its 256 records as one contiguous run (a lane writing its own 128-byte
@@ -818,48 +811,65 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
     return make_double2(__longlong_as_double((b0x & m0) | (b1x & m1) | (b2x & m2) | (b3x & m3)),
                         __longlong_as_double((b0y & m0) | (b1y & m1) | (b2y & m2) | (b3y & m3)));
   };
+  // Sutherland-Hodgman against one cutting edge at a time, restructured so that the expensive part -- the intersection (two
+  // FP64 divisions) -- is not inside the per-vertex loop: a convex polygon crosses the line of a cutting edge at most twice, so
+  // (1) the inside flags of all vertices are collected into bit masks (cheap, every lane busy), (2) the at most two crossings
+  // are computed by code that runs twice per cutting edge instead of once per vertex slot with a third of the lanes active
+  // (PMC, profiles/r03_summary.md: the old per-vertex loop kept 32.6 of 64 lanes busy), (3) the new polygon is written at
+  // positions counted from the masks.  Same intersection formulas on the same operands, same output order as the reference's
+  // loop (for every k: the crossing of edge (k-1, k) if there is one, then vertex k if it is inside, create_xgrid.c:1301-1333).
+  // A polygon with more than two crossings of one line (non-convex source cell) goes to the general kernel.
   int n_cur = n1;
   bool overflow = false, parallel = false;
   double2 e0 = cut(n2 - 1);
+#if FG_EXP == 2
+  for (int e = 0; e < 0; e++) {
+#else
   for (int e = 0; e < n2 && n_cur > 0; e++) {
+#endif
     double2 e1 = cut(e);
     const double x2_0 = e0.x, y2_0 = e0.y, x2_1 = e1.x, y2_1 = e1.y;
     double2 c[8];
+    unsigned inmask = 0u;
 #pragma unroll
-    for (int k = 0; k < 8; k++) if (k < n_cur) c[k] = sh_poly[k][tid];
-    double2 lastv = sh_poly[n_cur - 1][tid];
-    double x1_0 = lastv.x, y1_0 = lastv.y;
-    int inside_last = d_inside_edge(x2_0, y2_0, x2_1, y2_1, x1_0, y1_0);
-    int n_new = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 8; k++)
       if (k < n_cur) {
-        double x1_1 = c[k].x, y1_1 = c[k].y;
-        int inside = d_inside_edge(x2_0, y2_0, x2_1, y2_1, x1_1, y1_1);
-        if (inside != inside_last) {
-          double dy1 = y1_1 - y1_0;
-          double dy2 = y2_1 - y2_0;
-          double dx1 = x1_1 - x1_0;
-          double dx2 = x2_1 - x2_0;
-          double ds1 = y1_0 * x1_1 - y1_1 * x1_0;
-          double ds2 = y2_0 * x2_1 - y2_1 * x2_0;
-          double determ = dy2 * dx1 - dy1 * dx2;
-          if (fabs(determ) < 1.0e-30) parallel = true;
-          if (n_new < 8) sh_poly[n_new][tid] = make_double2((dx2 * ds1 - dx1 * ds2) / determ,
-                                                            (dy2 * ds1 - dy1 * ds2) / determ);
-          else overflow = true;
-          n_new++;
-        }
-        if (inside) {
-          if (n_new < 8) sh_poly[n_new][tid] = make_double2(x1_1, y1_1);
-          else overflow = true;
-          n_new++;
-        }
-        x1_0 = x1_1; y1_0 = y1_1; inside_last = inside;
+        c[k] = sh_poly[k][tid];
+        inmask |= (unsigned)d_inside_edge(x2_0, y2_0, x2_1, y2_1, c[k].x, c[k].y) << k;
       }
+    const unsigned full = (1u << n_cur) - 1u;
+    const unsigned prevmask = ((inmask << 1) | (inmask >> (n_cur - 1))) & full;     // bit k: vertex k-1 (cyclic) is inside
+    const unsigned tmask = inmask ^ prevmask;                                        // bit k: edge (k-1, k) crosses the line
+    const int ncross = __popc(tmask);
+    if (ncross > 2 || ncross + __popc(inmask) > 8) { overflow = true; break; }
+    if (tmask) {
+      const int ka = __ffs((int)tmask) - 1, kb = 31 - __clz((int)tmask);
+      double2 I[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int k = j ? kb : ka;
+        const double2 p0 = sh_poly[k ? k - 1 : n_cur - 1][tid], p1 = sh_poly[k][tid];
+        const double x1_0 = p0.x, y1_0 = p0.y, x1_1 = p1.x, y1_1 = p1.y;
+        double dy1 = y1_1 - y1_0;
+        double dy2 = y2_1 - y2_0;
+        double dx1 = x1_1 - x1_0;
+        double dx2 = x2_1 - x2_0;
+        double ds1 = y1_0 * x1_1 - y1_1 * x1_0;
+        double ds2 = y2_0 * x2_1 - y2_1 * x2_0;
+        double determ = dy2 * dx1 - dy1 * dx2;
+        if (fabs(determ) < 1.0e-30) parallel = true;
+        I[j] = make_double2((dx2 * ds1 - dx1 * ds2) / determ, (dy2 * ds1 - dy1 * ds2) / determ);
+      }
+      // (all reads of the old polygon are done: c[] and I[] are registers)
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (k < n_cur && ((inmask >> k) & 1u))
+          sh_poly[__popc(inmask & ((1u << k) - 1u)) + __popc(tmask & ((2u << k) - 1u))][tid] = c[k];
+      sh_poly[__popc(inmask & ((1u << ka) - 1u))][tid] = I[0];                       // no crossing before the first one
+      sh_poly[__popc(inmask & ((1u << kb) - 1u)) + 1][tid] = I[1];
     }
-    n_cur = n_new;
-    if (overflow) break;
+    // (no crossing: every vertex inside -> the polygon stays as it is; every vertex outside -> it is empty)
+    n_cur = ncross + __popc(inmask);
     e0 = e1;
   }
   if (overflow) return false;
@@ -867,8 +877,12 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
   ClipOut o; o.area = -1.0; o.clon = 0; o.clat = 0;
   if (n_cur > 0) {
     const double *px = (const double *)&sh_poly[0][tid];
+#if FG_EXP == 1
+    o.area = n_cur + px[0] + px[1];
+#else
     d_finish_pair<ORDER, 2 * CLIP_THREADS>(px, px + 1, n_cur, mask ? mask[s] : 1.0, S.area[s], D.area[d],
                                             lon_in_avg, &o, stats);
+#endif
   }
   *o_out = o;
   return true;
