@@ -7,8 +7,9 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on; f
 One "step" = one full weight generation for the job: exchange-grid search for all 6 source tiles
 against this rank's latitude band of the target + the order-2 centroid pass + the destination-row
 (CSR) build.  With N > 1 ranks the target rows are split into N bands (the reference's
-fregrid_parallel decomposition, fregrid_util.c:592-597); the only collective is the all-reduce of the
-per-source-cell (area, clon, clat) sums (RCCL), conserve_interp.c:203-221.  Fixed total work => "strong".
+fregrid_parallel decomposition, fregrid_util.c:592-597); the only exchange is that of the per-source-cell
+(area, clon, clat) sums of the cells present on several ranks, handed from rank to rank in the reference's
+order (RCCL broadcasts of a short list, conserve_interp.c:203-221).  Fixed total work => "strong".
 
 value = steps * (sum over ranks of nxgrid) / max-over-ranks wall time, inputs resident in HBM.
 A second timed region measures the sweep (do_scalar_conserve_interp) on nz levels: remapped-points/s.
@@ -222,24 +223,22 @@ def config5_leg(fg, torch, dev, device, nz=50, nt=20, nfields=3):
 
 def banded_search_job(fg, torch, dist, dev, local_rank, world, rank, ni, nlon, nlat, steps, warmup, repeats):
     """One strong-scaling weight-generation job: C<ni> -> nlon x nlat, order 2, this rank's latitude band of the target (equal
-    rows: measured max/mean <= 1.06 up to 8 ranks, scripts/band_time.py), source cells culled to the band, the per-source-cell sums
-    of the cells cut by a band boundary all-reduced (RCCL).  Returns median seconds per region of `steps` steps, max over ranks."""
+    rows: measured max/mean <= 1.06 up to 8 ranks, scripts/band_time.py), source cells culled to the band, and the product's
+    exchange: the running sums of the source cells present on several ranks handed from rank to rank (parallel.CellSumExchange,
+    bit-reproducible; schedule built once).  Returns median seconds per region of `steps` steps, max over ranks."""
     lon, lat = fg.gnomonic_ed_corners(ni)
     lo, la = fg.latlon_corners(nlon, nlat)
     j0, j1 = fg.band_rows(nlat, world, rank)
     h2d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     lon_t = [h2d(lon[t]) for t in range(6)]; lat_t = [h2d(lat[t]) for t in range(6)]
     lo_t, la_t = h2d(lo[j0:j1 + 1]), h2d(la[j0:j1 + 1])
-    ncell = 6 * ni * ni
     stream = torch.cuda.current_stream().cuda_stream
     mk = lambda: fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, j1 - j0, lo_t, la_t, np.pi / nlat, 2 * np.pi / nlon,
                                          device=local_rank, stream=stream)
-    bidx_t = None
-    total = torch.empty(3 * ncell, dtype=torch.float64, device=dev)
+    ex = None
     if world > 1:
-        p0 = mk(); cs = p0.get_cell_struct(0, ncell); p0.destroy()
-        bidx_t = h2d(fg.boundary_source_cells(cs["lat_min"], cs["lat_max"], la, nlat, world).astype(np.int64))
         fg.lib().fg_set_search_cull(1)
+        p0 = mk(); ex = fg.CellSumExchange([p0], str(dev)); p0.destroy()
     plan = [None]
 
     def step():
@@ -247,8 +246,10 @@ def banded_search_job(fg, torch, dist, dev, local_rank, world, rank, ni, nlon, n
             plan[0].destroy()
         p = mk()
         if world > 1:
-            exchange_in_place(fg, torch, p, bidx_t, ncell, dev)
-        p.finalize(None)
+            total = ex.run([p], complete=False)
+            p.finalize(total.data_ptr())
+        else:
+            p.finalize(None)
         plan[0] = p
         return p
     fg.lib().fg_set_profiling(0)
@@ -276,7 +277,78 @@ def banded_search_job(fg, torch, dist, dev, local_rank, world, rank, ni, nlon, n
     return {"workload": f"C{ni} (6 tiles) -> {nlon}x{nlat}, conservative_order2, search + centroid pass + CSR build per step",
             "nxgrid": int(nx.item()), "ms_per_step": med / steps * 1e3, "ms_per_step_min": min(reps) / steps * 1e3,
             "exchange_cells_per_s": steps * int(nx.item()) / med, "steps": steps, "repeats": repeats, "n_gpus": world,
-            "boundary_cells_exchanged": (int(bidx_t.numel()) if bidx_t is not None else 0)}
+            "shared_cells_handed_over": (ex.nsh if ex is not None else 0)}
+
+
+def banded_gc_job(fg, torch, dist, dev, local_rank, world, rank, ni, nlon, nlat, steps, warmup):
+    """BASELINE config 4 under ranks: C<ni> -> nlon x nlat with create_xgrid_great_circle semantics (first order), this rank's band of
+    the target, source cells culled to the band by their bounding caps; search + finalize per step (no data-path collective:
+    first order has no per-source-cell sums), then ONCE the WRITE branch -- exchange cells to the host, gathered on the root in rank
+    order, one remap file (conserve_interp.c:368-445) -- timed separately.  Unit vectors come from the host libm as the reference's
+    latlon2xyz makes them (not timed)."""
+    import tempfile
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    j0, j1 = fg.band_rows(nlat, world, rank)
+    h2d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    th = time.perf_counter()
+    xin = [tuple(h2d(a) for a in fg.latlon2xyz(lon[t], lat[t])) for t in range(6)]
+    xout = tuple(h2d(a) for a in fg.latlon2xyz(lo[j0:j1 + 1], la[j0:j1 + 1]))
+    t_xyz = time.perf_counter() - th
+    stream = torch.cuda.current_stream().cuda_stream
+    fg.lib().fg_set_search_cull(1 if world > 1 else 0)
+    plan = [None]
+
+    def step():
+        if plan[0] is not None:
+            plan[0].destroy()
+        p = fg.XgridPlan.create_great_circle_dev([ni] * 6, [ni] * 6, xin, nlon, j1 - j0, xout, np.pi / nlat, 2 * np.pi / nlon,
+                                                  device=local_rank, stream=stream)
+        p.finalize(None)
+        plan[0] = p
+        return p
+    fg.lib().fg_set_profiling(0)
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        p = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    fg.lib().fg_set_search_cull(0); fg.lib().fg_set_profiling(1)
+    # WRITE: every rank's exchange cells to its host, gathered, one file on the root
+    tmp = tempfile.mkdtemp(prefix="fg_remap_gc_") if rank == 0 else None
+    if world > 1:
+        box = [tmp]
+        dist.broadcast_object_list(box, src=0)
+        tmp = box[0]
+    path = os.path.join(tmp, "remap_gc.nc")
+    tw = time.perf_counter()
+    x = p.get_xgrid()
+    ic = fg.InterpConfig(nxgrid=p.nxgrid, i_in=x["i_in"], j_in=x["j_in"], i_out=x["i_out"], j_out=x["j_out"], t_in=x["t_in"], area=x["area"],
+                         remap_file=path)
+    g = fg.GridConfig(nlon, j1 - j0, None, None); g.isc, g.jsc = 0, j0
+    n_glob = fg.write_remap_gathered(ic, g, 1)
+    t_write = time.perf_counter() - tw
+    size = os.path.getsize(path) if rank == 0 else 0
+    if rank == 0:
+        os.remove(path); os.rmdir(tmp)
+    tt = torch.tensor([dt, t_write], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt, t_write = float(tt[0]), float(tt[1])
+    p.destroy(); plan[0] = None
+    del xin, xout
+    fg.lib().fg_pool_release()
+    return {"workload": f"C{ni} (6 tiles) -> {nlon}x{nlat}, create_xgrid_great_circle semantics (first order), search + CSR build per step, "
+                        "then the gathered remap-file write once",
+            "nxgrid": n_glob, "ms_per_step": dt / steps * 1e3, "exchange_cells_per_s": steps * n_glob / dt, "steps": steps, "n_gpus": world,
+            "remap_write_s": t_write, "remap_file_bytes": size, "host_latlon2xyz_and_upload_ms": t_xyz * 1e3,
+            "note": "remap_write_s = device -> host copy of this rank's exchange cells + gather on the root (rank order) + file write; max over ranks"}
 
 
 class _DeviceDoubles:
@@ -305,7 +377,8 @@ def main():
     ap.add_argument("--apply-steps", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--no-phase-timing", action="store_true", help="skip the separate pass that records per-phase HIP events")
-    ap.add_argument("--legs", default="all", help="comma list of extra legs: gc,pcie,config4,config5,cpu (or all / none)")
+    ap.add_argument("--legs", default="all", help="comma list of extra legs: gc,pcie,config4,config5,cpu,c768,c768gc (or all / none); "
+                                                  "all = the first five; with --gpus N > 1 the c768 jobs always run")
     ap.add_argument("--cpu-rows", type=int, default=32, help="source rows in the CPU baseline sample (0 = skip)")
     ap.add_argument("--gc-steps", type=int, default=3, help="timed great-circle searches of the same grids (N=1 only; 0 = skip)")
     args = ap.parse_args()
@@ -379,42 +452,50 @@ def main():
             dist.barrier()
 
     plan = [None]
-    # communication schedule of the decomposition (built once, like the band extents): the source cells cut by a band
-    # boundary are the only ones whose partial sums live on more than one rank
+    # communication schedule of the decomposition (built once, like the band extents): the source cells with exchange cells on
+    # more than one rank are the only ones whose sums need an exchange
     bidx_t = None
     a_in_full = None
     exchange_check = None
+    ex = None
+    mk = lambda: fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t, mean_dlat, mean_dlon,
+                                         device=local_rank, stream=stream)
     if world > 1:
-        p0 = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t, mean_dlat, mean_dlon,
-                                     device=local_rank, stream=stream)
-        cs = p0.get_cell_struct(0, ncell_in)          # 0 = source cells
-        a_in_full = np.asarray(p0.get_cell_area(nlon * ny_band)[0]).copy()   # (a culled plan reports area 0 for the cells it skipped)
-        p0.destroy()
+        lo_full, la_full = torch.from_numpy(lo).to(dev), torch.from_numpy(la).to(dev)
+        pf = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, nlat, lo_full, la_full, mean_dlat, mean_dlon,
+                                     device=local_rank, stream=stream)        # the un-banded job: the single-rank sums, for the check
+        cs = pf.get_cell_struct(0, ncell_in)          # 0 = source cells
+        a_in_full = np.asarray(pf.get_cell_area(nlon * nlat)[0]).copy()       # (a culled plan reports area 0 for the cells it skipped)
+        serial = torch.empty(3 * ncell_in, dtype=torch.float64, device=dev)
+        pf.copy_cell_sums(serial)
+        pf.destroy(); del lo_full, la_full
         bidx = fg.boundary_source_cells(cs["lat_min"], cs["lat_max"], la, nlat, world)
         bidx_t = torch.from_numpy(bidx.astype(np.int64)).to(dev)
         fg.lib().fg_set_search_cull(1)          # each rank builds records only for the source cells that can meet its band
-        # one-off check of the exchange the timed steps use (in place, boundary cells only) against a dense all-reduce of copies
-        pc = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t, mean_dlat, mean_dlon,
-                                     device=local_rank, stream=stream)
-        dense = torch.empty(3 * ncell_in, dtype=torch.float64, device=dev)
-        pc.copy_cell_sums(dense)
-        mine = dense[:ncell_in] != 0
-        fg.allreduce_cell_sums(dense)
-        exchange_in_place(fg, torch, pc, bidx_t, ncell_in, dev)
-        got = torch.as_tensor(_DeviceDoubles(pc.cell_sums_ptr(), 3 * ncell_in), device=dev).view(3, ncell_in)[:, mine]
-        want = dense.view(3, ncell_in)[:, mine]
-        exchange_check = float(((got - want).abs() / want.abs().clamp_min(1e-300)).max().item()) if int(mine.sum()) else 0.0
+        pc = mk()
+        ex = fg.CellSumExchange([pc], str(dev))
+        # one-off check of the exchange the timed steps use: for every source cell with exchange cells on this rank the handed-over
+        # sums must carry the BITS of the single-rank search's sums (bands in rank order = ascending destination index)
+        total = ex.run([pc], complete=False)
+        loc = torch.empty(3 * ncell_in, dtype=torch.float64, device=dev)
+        pc.copy_cell_sums(loc)
+        mine3 = (loc[:ncell_in] != 0).repeat(3)
+        exchange_check = {"cells_on_this_rank": int(mine3.sum().item()) // 3, "shared_cells": ex.nsh,
+                          "bit_identical_to_single_rank_sums": bool(torch.equal(total[mine3], serial[mine3]))}
         torch.cuda.synchronize()
-        pc.destroy()
+        pc.destroy(); del serial, loc, total
 
-    def step():
+    def step(mode="ordered"):
         if plan[0] is not None:
             plan[0].destroy()
-        p = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, ny_band, lo_t, la_t,
-                                    mean_dlat, mean_dlon, device=local_rank, stream=stream)
-        if world > 1:
-            exchange_in_place(fg, torch, p, bidx_t, ncell_in, dev)
-        p.finalize(None)
+        p = mk()
+        if world > 1 and mode == "ordered":
+            total = ex.run([p], complete=False)
+            p.finalize(total.data_ptr())
+        else:
+            if world > 1:
+                exchange_in_place(fg, torch, p, bidx_t, ncell_in, dev)
+            p.finalize(None)
         plan[0] = p
         return p
 
@@ -430,6 +511,18 @@ def main():
             p = step()
         torch.cuda.synchronize(); barrier()
         reps.append(time.perf_counter() - t0)
+    alt_ms = None
+    if world > 1:            # the same steps with the cheaper, NOT bit-reproducible exchange (one sparse all-reduce of partial sums)
+        for _ in range(2):
+            step("allreduce")
+        barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step("allreduce")
+        torch.cuda.synchronize(); barrier()
+        alt_t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(alt_t, op=dist.ReduceOp.MAX)
+        alt_ms = float(alt_t[0]) / args.steps * 1e3
+        step()
     p = plan[0]
     nx_local = p.nxgrid
     stats = p.stats()
@@ -607,10 +700,13 @@ def main():
             "config": {"workload": f"C{ni} cubed sphere (6 tiles) -> {nlon}x{nlat} lat-lon, conservative_order2: "
                                    "exchange-grid search + centroid pass + CSR build per step",
                        "nxgrid": nx_total, "parallelism": f"{world} latitude band(s) of the target, one per GPU", "world_size": world,
-                       "exchange": (None if world == 1 else f"all-reduce of the (area, clon, clat) sums of the {int(bidx_t.numel())} source "
-                                    f"cells cut by band boundaries ({100.0 * int(bidx_t.numel()) / ncell_in:.1f} % of {ncell_in}): partial sums, one collective; "
-                                    f"setup_conserve_interp's default hands running sums from rank to rank instead (bit-reproducible, parallel.ordered_cell_sums)")},
-            "exchange_check_max_rel": exchange_check,
+                       "exchange": (None if world == 1 else f"the product's: running (area, clon, clat) sums of the {ex.nsh} source cells present on "
+                                    f"several ranks ({100.0 * ex.nsh / ncell_in:.2f} % of {ncell_in}) handed from rank to rank by {world} broadcasts "
+                                    "(parallel.CellSumExchange, conserve_interp.c:203-221's order: bit-identical to one rank)")},
+            "exchange_check": exchange_check,
+            "ms_per_step_allreduce_exchange": alt_ms,
+            "allreduce_exchange_note": (None if world == 1 else "same steps with ONE sparse all-reduce of partial sums in place of the hand-over: "
+                                        "cheaper, but the last bits of di / dj then depend on the rank count -- not the product's default"),
             "remapped_points_per_s": remap_pts, "apply_ms_per_call": dta / apply_steps * 1e3, "apply_levels": nz,
             "apply_device_ms_per_call": apply_call_ms,
             "remapped_points_per_s_interleaved": apply_steps * ndst * nb / dtb,
@@ -633,12 +729,16 @@ def main():
         pass
     # ---- the larger job of BASELINE config 4 (C768 -> 0.125 deg, 16.7 M exchange cells), same decomposition: where strong scaling
     # is not bound by launch latency.  Collective: every rank takes part.
-    c768 = None
+    c768 = c768gc = None
     if world > 1 or "c768" in legs:
         c768 = banded_search_job(fg, torch, dist if world > 1 else None, dev, local_rank, world, rank, 768, 2880, 1440, 5, 2, 3)
+    if world > 1 or "c768gc" in legs:
+        c768gc = banded_gc_job(fg, torch, dist if world > 1 else None, dev, local_rank, world, rank, 768, 2880, 1440, 3, 1)
     if rank == 0:
         if c768 is not None:
             line["c768_order2"] = c768
+        if c768gc is not None:
+            line["c768_great_circle"] = c768gc
         if world == 1 and args.gc_steps > 0 and "gc" in legs:
             # BASELINE config 4's clip method on the same grids (create_xgrid_great_circle semantics, first order): unit
             # vectors made on the host with libm as the reference does (not timed), search timed with inputs resident

@@ -29,7 +29,7 @@ EXPORTS = [
     "get_maxxgrid_", "get_grid_area_", "create_xgrid_2dx2d_order1_", "create_xgrid_2dx2d_order2_",
     "fg_last_error", "fg_device_count", "fg_plan_create", "fg_plan_create_dev", "fg_plan_create_empty",
     "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
-    "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_accumulate_cell_sums", "fg_dev_gather_f64", "fg_dev_scatter_f64", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
+    "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_accumulate_cell_sums", "fg_plan_accumulate_cell_sums_async", "fg_dev_gather_f64", "fg_dev_scatter_f64", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
     "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_apply_records", "fg_plan_apply_ex", "fg_plan_mono_begin",
     "fg_plan_mono_minmax_dev", "fg_plan_mono_copy_minmax", "fg_plan_mono_end",
     "fg_plan_create_great_circle", "fg_plan_create_great_circle_dev", "fg_latlon2xyz", "create_xgrid_great_circle",
@@ -130,6 +130,8 @@ def lib():
     L.fg_plan_copy_cell_sums.restype = C.c_int
     L.fg_plan_accumulate_cell_sums.argtypes = [vp, vp, vp, C.c_int]
     L.fg_plan_accumulate_cell_sums.restype = C.c_int
+    L.fg_plan_accumulate_cell_sums_async.argtypes = [vp, vp, vp, C.c_int]
+    L.fg_plan_accumulate_cell_sums_async.restype = C.c_int
     L.fg_dev_alloc.argtypes = [C.c_size_t, C.c_int]
     L.fg_dev_alloc.restype = vp
     L.fg_dev_free.argtypes = [vp]

@@ -243,15 +243,20 @@ class XgridPlan:
         """total_t[3, ncells_in] += this plan's exchange cells, one by one in exchange-cell order, continuing from the values
         already there (conserve_interp.c:203-221); cells_t: int32 device tensor restricting the update to those source cells.
 
-        The kernel runs on the PLAN's stream while total_t / cells_t are usually the product of torch ops still queued on torch's
-        current stream (a zero fill, an index_put of the sums received from another rank, the wait on a collective): that
-        stream is drained first, or the kernel would read stale values.  The C call returns with the plan's stream drained, so
-        torch ops issued afterwards see the result."""
+        The kernel runs on the PLAN's stream while total_t / cells_t are usually the product of torch ops queued on torch's
+        current stream (a zero fill, an index_put of the sums received from another rank, the wait on a collective).  If the
+        plan IS on torch's current stream (create_dev(stream=...) / set_stream) stream order does it all and the call only
+        queues the kernel; otherwise torch's stream is drained first -- the kernel would read stale values -- and the C call
+        returns with the plan's stream drained, so torch ops issued afterwards see the result."""
+        args = (self._h, C.c_void_p(total_t.data_ptr()), C.c_void_p(cells_t.data_ptr()) if cells_t is not None else None,
+                int(cells_t.numel()) if cells_t is not None else 0)
         if getattr(total_t, "is_cuda", False):
-            _torch().cuda.current_stream(total_t.device).synchronize()
-        check(lib().fg_plan_accumulate_cell_sums(self._h, C.c_void_p(total_t.data_ptr()),
-                                                 C.c_void_p(cells_t.data_ptr()) if cells_t is not None else None,
-                                                 int(cells_t.numel()) if cells_t is not None else 0))
+            cur = _torch().cuda.current_stream(total_t.device)
+            if int(self.stream() or 0) == int(cur.cuda_stream):      # (a plan with a stream of its own never reports 0)
+                check(lib().fg_plan_accumulate_cell_sums_async(*args))
+                return
+            cur.synchronize()
+        check(lib().fg_plan_accumulate_cell_sums(*args))
 
     def stats(self):
         s = (C.c_long * 10)()
@@ -394,11 +399,22 @@ def _torch():
     return torch
 
 
-def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opcode, device=0, fetch=True):
+def get_input_output_cell_area(ntiles_in, grid_in, ntiles_out, grid_out, opcode):
+    """fregrid_util.c:363-408: grid_in[].cell_area and grid_out[].cell_area from get_grid_area, or get_grid_great_circle_area
+    with GREAT_CIRCLE (the B1 entry points of the library: device work, host arrays in and out)."""
+    from . import get_grid_area, get_grid_great_circle_area
+    fn = get_grid_great_circle_area if (opcode & GREAT_CIRCLE) else get_grid_area
+    for g in list(grid_in[:ntiles_in]) + list(grid_out[:ntiles_out]):
+        g.cell_area = fn(g.nx, g.ny, g.lonc, g.latc)
+
+
+def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opcode, device=0, fetch=True, cull=None):
     """conserve_interp.c:42, compute branch (:127-358).  Fills interp[n] for each output tile.
 
-    With torch.distributed initialised (world_size > 1) each rank passes its own band of the
-    output grid and the per-source-cell sums are all-reduced (RCCL) before the centroid pass.
+    With torch.distributed initialised (world_size > 1) each rank passes its own band of the output grid (grid_out[n] with
+    isc / jsc set), searches it with the source cells culled to the band (cull=None: on exactly then) and the per-source-cell
+    sums of the cells present on several ranks are handed from rank to rank in the reference's order before the centroid
+    pass (parallel.CellSumExchange, :203-221).  GREAT_CIRCLE: first order, no exchange at all; WRITE gathers on the root.
     """
     order = 2 if (opcode & CONSERVE_ORDER2) else 1
     if not (opcode & (CONSERVE_ORDER1 | CONSERVE_ORDER2)):
@@ -431,20 +447,33 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
     great_circle = bool(opcode & GREAT_CIRCLE)
     if great_circle and order != 1:
         raise ValueError("fregrid: when clip_method is 'conserve_great_circle', interp_method must be 'conserve_order1'")  # fregrid.c:763
-    for n in range(ntiles_out):
-        if great_circle:                                               # conserve_interp.c:164-168 (whole tiles, no row trim)
-            plans.append(XgridPlan.create_great_circle(grid_in[:ntiles_in], grid_out[n], device=device))
-        else:
-            plans.append(XgridPlan.create(order, grid_in[:ntiles_in], grid_out[n], device=device))
-    # cell areas (fregrid_util.c:363-408) come for free from the search
-    for n in range(ntiles_out):
-        a_in, a_out = plans[n].get_cell_area(grid_out[n].nx * grid_out[n].ny)
-        grid_out[n].cell_area = a_out
-        if n == 0:
-            off = 0
-            for g in grid_in[:ntiles_in]:
-                g.cell_area = a_in[off:off + g.nx * g.ny].copy()
-                off += g.nx * g.ny
+    # A rank of a banded job (fregrid_parallel: grid_out[n] is this rank's latitude band, fregrid_util.c:592-603) meets a fraction
+    # of the source cells: the search then skips the others when it builds the per-cell records (fg_set_search_cull) -- the
+    # counterpart of the reference's jstart / jend row trim (conserve_interp.c:169-184), for the great-circle search too.
+    from .parallel import world_size
+    cull = world_size() > 1 if cull is None else bool(cull)
+    lib().fg_set_search_cull(1 if cull else 0)
+    try:
+        for n in range(ntiles_out):
+            if great_circle:                                           # conserve_interp.c:164-168 (whole tiles, no row trim)
+                plans.append(XgridPlan.create_great_circle(grid_in[:ntiles_in], grid_out[n], device=device))
+            else:
+                plans.append(XgridPlan.create(order, grid_in[:ntiles_in], grid_out[n], device=device))
+    finally:
+        lib().fg_set_search_cull(0)
+    if cull:
+        # a culling search holds no area for the source cells it skipped
+        get_input_output_cell_area(ntiles_in, grid_in, ntiles_out, grid_out, opcode)
+    else:
+        # cell areas (fregrid_util.c:363-408) come for free from the search
+        for n in range(ntiles_out):
+            a_in, a_out = plans[n].get_cell_area(grid_out[n].nx * grid_out[n].ny)
+            grid_out[n].cell_area = a_out
+            if n == 0:
+                off = 0
+                for g in grid_in[:ntiles_in]:
+                    g.cell_area = a_in[off:off + g.nx * g.ny].copy()
+                    off += g.nx * g.ny
     if order == 2:
         from .parallel import ordered_cell_sums
         total = ordered_cell_sums(plans, device)   # the one exchange step of the path, in the reference's order

@@ -1034,7 +1034,7 @@ extern "C" int fg_plan_copy_cell_sums(fg_plan *pl, double *dst_dev)
 // total_dev[3][ncells_in] (sum of area, of the clon integral, of the clat integral per source cell) += this plan's exchange cells,
 // added one by one in exchange-cell order onto what total_dev already holds; cells_dev (may be null = all) restricts it to a list
 // of source cells.  Before fg_plan_finalize only.
-extern "C" int fg_plan_accumulate_cell_sums(fg_plan *pl, double *total_dev, const int *cells_dev, int ncells)
+static int accumulate_cell_sums(fg_plan *pl, double *total_dev, const int *cells_dev, int ncells, bool sync)
 {
   if (!pl || !total_dev) return fail(FG_ERR_ARG, "null argument");
   if (pl->order != 2 || !pl->searched || pl->finalized || !pl->xoff)
@@ -1042,8 +1042,19 @@ extern "C" int fg_plan_accumulate_cell_sums(fg_plan *pl, double *total_dev, cons
   HIPCHK(hipSetDevice(pl->device));
   if (pl->nx > 0)
     fgd_accumulate_cell_sums(cells_dev ? ncells : pl->nsrc, cells_dev, pl->nsrc, pl->xoff, pl->x_area, pl->x_c1, pl->x_c2, total_dev, pl->stream);
-  HIPCHK(hipStreamSynchronize(pl->stream));
+  if (sync) HIPCHK(hipStreamSynchronize(pl->stream));
+  HIPCHK(hipGetLastError());
   return 0;
+}
+extern "C" int fg_plan_accumulate_cell_sums(fg_plan *pl, double *total_dev, const int *cells_dev, int ncells)
+{
+  return accumulate_cell_sums(pl, total_dev, cells_dev, ncells, true);
+}
+// the same, only queued on the plan's stream: for callers that put the plan on the stream their other device work is ordered on
+// (fg_plan_set_stream / the stream argument of fg_plan_create_dev), so that a rank-to-rank hand-over needs no host round trip
+extern "C" int fg_plan_accumulate_cell_sums_async(fg_plan *pl, double *total_dev, const int *cells_dev, int ncells)
+{
+  return accumulate_cell_sums(pl, total_dev, cells_dev, ncells, false);
 }
 extern "C" void *fg_plan_stream(fg_plan *pl) { return pl ? (void *)pl->stream : nullptr; }
 extern "C" int fg_plan_sync(fg_plan *pl)

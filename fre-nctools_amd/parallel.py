@@ -154,58 +154,82 @@ def _broadcast(t, src):
     return t
 
 
-def ordered_cell_sums(plans, device=0):
+class CellSumExchange:
     """The per-source-cell (sum area, sum clon, sum clat) of setup_conserve_interp, bit-identical for any number of ranks.
 
     conserve_interp.c:203-221 gathers the exchange cells of every rank and adds them to the per-cell accumulators one by one --
     "for the purpose of bitwise reproducing" -- output tile after output tile, rank after rank.  An all-reduce of per-rank
     partial sums adds the same terms in a different association for the cells that have exchange cells on two ranks (or in two
     output tiles), so instead ONE running total is handed along: every plan continues the sums where the previous one stopped
-    (fg_plan_accumulate_cell_sums).  Across ranks only the cells present on more than one rank need the hand-over (found with
-    one all-reduce of a presence mask: 0.3 % of the cells for 2 bands of C384); they are passed from rank to rank by broadcasts
-    of that short list, per output tile, in rank order.  Every other cell is complete on its one rank and the final all-reduce
-    adds zeros to it.  Returns the device tensor [3 * ncells_in]; identical on every rank."""
-    import torch
-    import torch.distributed as dist
-    dev = device if isinstance(device, str) else f"cuda:{device}"         # ("cpu" with stand-in plans: the gloo test of this logic)
-    on_gpu = dev.startswith("cuda")
-    ncell = plans[0].ncells_in
-    total = torch.zeros(3 * ncell, dtype=torch.float64, device=dev)
-    W = world_size()
-    if W == 1:
+    (fg_plan_accumulate_cell_sums).  Across ranks only the cells present on more than one rank need the hand-over; they are
+    passed from rank to rank by broadcasts of that short list, per output tile, in rank order.
+
+    The object is the communication SCHEDULE of one decomposition: the list of shared cells depends only on the grids and the
+    bands (found with one all-reduce of a presence mask: 0.3 % of the cells for 2 bands of C384), so a job that searches the
+    same grids again (bench.py's timed steps) builds it once and calls run() per search.  run() issues no host synchronisation
+    of its own when the plans sit on torch's current stream (XgridPlan.accumulate_cell_sums then only queues its kernel):
+    search, hand-over and centroid pass are ordered by the stream."""
+
+    def __init__(self, plans, device=0):
+        import torch
+        import torch.distributed as dist
+        self.dev = device if isinstance(device, str) else f"cuda:{device}"      # ("cpu" with stand-in plans: the gloo test of this logic)
+        self.on_gpu = self.dev.startswith("cuda")
+        self.ncell = plans[0].ncells_in
+        self.W = world_size()
+        self.rank = dist.get_rank() if self.W > 1 else 0
+        self.shared = self.idx3 = None
+        self.nsh = 0
+        if self.W == 1:
+            return
+        mine = torch.zeros(3 * self.ncell, dtype=torch.float64, device=self.dev)
         for p in plans:
             if p.nxgrid > 0:
+                p.accumulate_cell_sums(mine)
+        count = (mine[:self.ncell] != 0).to(torch.int32)                     # source cells with exchange cells on this rank
+        _all_reduce(count)
+        self.shared = torch.nonzero(count > 1).flatten().to(torch.int32)     # ... on more than one rank
+        self.nsh = int(self.shared.numel())
+        if self.nsh:
+            idx = self.shared.long()
+            self.idx3 = torch.cat([idx, idx + self.ncell, idx + 2 * self.ncell])
+            self.scratch = torch.zeros(3 * self.ncell, dtype=torch.float64, device=self.dev)
+
+    def run(self, plans, complete=True):
+        """Returns the device tensor [3 * ncells_in].  complete=True: identical on every rank (a dense all-reduce fills in the
+        cells of the other ranks, as conserve_interp.c's cell_in arrays are).  complete=False: exact for every source cell
+        that has exchange cells on THIS rank -- all the centroid pass (fg_plan_finalize) reads -- and without the dense
+        all-reduce (21 MB at C384)."""
+        import torch
+        total = torch.zeros(3 * self.ncell, dtype=torch.float64, device=self.dev)
+        for p in plans:                                                        # output tile after output tile
+            if p.nxgrid > 0:
                 p.accumulate_cell_sums(total)
-        if on_gpu:
-            torch.cuda.synchronize(dev)
+        if self.W > 1:
+            run = None
+            if self.nsh:
+                run = torch.zeros(3 * self.nsh, dtype=torch.float64, device=self.dev)     # the running sums of the shared cells
+                for p in plans:                                                # output tile after output tile ...
+                    for r in range(self.W):                                    # ... rank after rank
+                        if r == self.rank and p.nxgrid > 0:
+                            self.scratch[self.idx3] = run
+                            p.accumulate_cell_sums(self.scratch, self.shared)
+                            run = self.scratch[self.idx3].contiguous()
+                        _broadcast(run, r)
+            if complete:
+                if self.nsh:
+                    total[self.idx3] = 0.0
+                _all_reduce(total)                                             # every other cell: its one rank's value + zeros
+            if self.nsh:
+                total[self.idx3] = run
         return total
-    rank = dist.get_rank()
-    # source cells with exchange cells on more than one rank
-    mine = torch.zeros(3 * ncell, dtype=torch.float64, device=dev)
-    for p in plans:
-        if p.nxgrid > 0:
-            p.accumulate_cell_sums(mine)
-    present = (mine[:ncell] != 0).to(torch.int32)
-    count = present.clone()
-    _all_reduce(count)
-    shared = torch.nonzero(count > 1).flatten().to(torch.int32)
-    nsh = int(shared.numel())
-    if nsh:
-        idx = shared.long()
-        idx3 = torch.cat([idx, idx + ncell, idx + 2 * ncell])
-        run = torch.zeros(3 * nsh, dtype=torch.float64, device=dev)       # the running sums of the shared cells
-        scratch = torch.zeros(3 * ncell, dtype=torch.float64, device=dev)
-        for p in plans:                                                    # output tile after output tile ...
-            for r in range(W):                                             # ... rank after rank
-                if r == rank and p.nxgrid > 0:
-                    scratch[idx3] = run
-                    p.accumulate_cell_sums(scratch, shared)
-                    run = scratch[idx3].contiguous()
-                _broadcast(run, r)
-        mine[idx3] = 0.0
-    _all_reduce(mine)                                                      # every other cell: its one rank's value + zeros
-    if nsh:
-        mine[idx3] = run
-    if on_gpu:
-        torch.cuda.synchronize(dev)
-    return mine
+
+
+def ordered_cell_sums(plans, device=0, complete=True):
+    """One-shot form of CellSumExchange (schedule + run); returns with the device idle."""
+    import torch
+    ex = CellSumExchange(plans, device)
+    total = ex.run(plans, complete=complete)
+    if ex.on_gpu:
+        torch.cuda.synchronize(ex.dev)
+    return total

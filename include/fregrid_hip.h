@@ -178,6 +178,10 @@ int fg_plan_copy_cell_sums(fg_plan *plan, double *dst_dev);
  * exchange cells on more than one rank.  cells_dev (device, may be NULL = every source cell) restricts the update to a list
  * of source cells.  Order-2 plans, after the search and before fg_plan_finalize. */
 int fg_plan_accumulate_cell_sums(fg_plan *plan, double *total_dev, const int *cells_dev, int ncells);
+/* The same, queued on the plan's stream without waiting for it: for a caller whose other device work is ordered on that very
+ * stream (fg_plan_set_stream, or the stream handed to fg_plan_create_dev).  total_dev / cells_dev must stay valid until the
+ * stream has passed the kernel. */
+int fg_plan_accumulate_cell_sums_async(fg_plan *plan, double *total_dev, const int *cells_dev, int ncells);
 
 /*
  * Turn (clon, clat) into distances from the source-cell centroid

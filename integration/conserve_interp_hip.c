@@ -122,6 +122,9 @@ void setup_conserve_interp(int ntiles_in, const Grid_config *grid_in, int ntiles
     for (m = 0; m < ntiles_in; m++) { lon[m] = grid_in[m].lonc; lat[m] = grid_in[m].latc; }
     if ((opcode & GREAT_CIRCLE) && order != 1)
       mpp_error("fregrid: when clip_method is 'conserve_great_circle', interp_method must be 'conserve_order1'");   /* fregrid.c:763 */
+    /* a rank of fregrid_parallel meets only the source cells near its band: the search skips the others when it builds its
+     * per-cell records (the counterpart of the row trim, :169-184; the great-circle search culls by bounding caps) */
+    fg_set_search_cull(mpp_npes() > 1);
     for (n = 0; n < ntiles_out; n++) {
       /* this rank's band of output tile n: nxc x nyc cells, corner arrays lonc / latc (get_output_grid_by_size,
        * fregrid_util.c:645-654).  All input tiles are searched in one call; the reference's row trim (:169-184) is an
@@ -135,6 +138,7 @@ void setup_conserve_interp(int ntiles_in, const Grid_config *grid_in, int ntiles
                             grid_out[n].lonc, grid_out[n].latc, dev, &plans[n]);
       if (nx < 0) hip_fatal("setup_conserve_interp");
     }
+    fg_set_search_cull(0);
     if (order == 2) {
       /* per-source-cell (area, clon, clat): :203-221 gathers the exchange cells of every rank and adds them to the accumulators
        * one by one, output tile after output tile, "for the purpose of bitwise reproducing".  One running total handed from

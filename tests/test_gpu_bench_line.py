@@ -37,7 +37,7 @@ def test_bench_line_schema(gpu_ok):
 def test_bench_two_ranks_rehearsal(gpu_ok):
     """`bench.py --gpus 2` the way the driver launches it (torch.distributed.run, one process per rank), but with both ranks on
     this one GPU and gloo for the collectives (FG_BENCH_BACKEND=gloo): times mean nothing, the N > 1 code path does -- the
-    banded, culled search, the boundary-cell exchange, the sweep of a band, the C768 job.  (This rehearsal found a fault and a
+    banded, culled search, the rank-to-rank hand-over of the shared cells' sums, the sweep of a band, the C768 jobs (legacy and great circle).  (This rehearsal found a fault and a
     wrong flux sum that no single-process test could see.)"""
     env = dict(os.environ, FG_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -52,4 +52,9 @@ def test_bench_two_ranks_rehearsal(gpu_ok):
     assert abs(d["mass_rel_err"]) < 2e-9 and abs(d["mass_rel_err_xgrid"]) < 1e-13
     assert d["c768_order2"]["nxgrid"] == 16673872 and d["c768_order2"]["n_gpus"] == 2
     assert 0 < d["roofline"]["frac"] <= 1 and d["value"] > 0
-    assert d["exchange_check_max_rel"] is not None and d["exchange_check_max_rel"] < 1e-13      # in-place boundary exchange == dense all-reduce
+    ck = d["exchange_check"]                                         # the timed steps' hand-over carries the single-rank sums' bits
+    assert ck["bit_identical_to_single_rank_sums"] is True and ck["cells_on_this_rank"] > 400000
+    # (two bands meet on the equator, a grid line of the cubed sphere: no source cell is shared; tests/test_gpu_multirank.py hands cells over on 3 ranks)
+    assert d["ms_per_step_allreduce_exchange"] > 0
+    g = d["c768_great_circle"]                                       # BASELINE config 4: great circle under ranks + gathered remap file
+    assert g["nxgrid"] == 16674181 and g["n_gpus"] == 2 and g["remap_write_s"] > 0 and g["remap_file_bytes"] > 16674181 * 28
