@@ -271,6 +271,8 @@ struct fg_plan {
   FgTile *tiles_dev = nullptr;
   double *mask_dev = nullptr;
   FgCells S{}, D{};
+  bool rect = false;            // searched on the rectilinear path: D holds areas only, the cells are in rect_tab (FgRect)
+  FgRect rect_tab{};
   // exchange cells
   long nx = 0;
   int *x_src = nullptr, *x_dst = nullptr;
@@ -411,7 +413,7 @@ static int g_search_cull = 0;
 // 0 = the one-kernel clip for every pair (fg_set_gc_split; the tests compare the two)
 static int g_gc_split = 1;
 extern "C" void fg_set_gc_split(int on) { g_gc_split = on < 0 ? 0 : on; }      // 2: a task space 64 times too small (tests of the overflow path)
-struct SearchCaps { unsigned long long entries; int regcap, nreg; };
+struct SearchCaps { unsigned long long entries; int regcap, nreg; bool rect; };
 // Chunks of source cells per search (1 = everything on one stream, in sequence; fg_set_search_chunks / FREGRID_HIP_CHUNKS).  Measured at C384 -> 0.25 deg with 4 chunks: the
 // kernels slow each other down by more than the overlap wins (clip 4 x 184 us against 482, step 1.48 ms against 1.30), so the
 // default is ONE chunk; the machinery stays for grids where the balance differs.
@@ -425,6 +427,23 @@ static int choose_chunks(int nsrc, int nreg)
   const bool forced = g_search_chunks > 0 || env_k > 0;
   while (k > 1 && (nreg / k < 1 || (!forced && nsrc / k < 4096))) k--;
   return k;
+}
+// Rectilinear destination grids (k_rect_tables, xgrid_kernels.hip): 1 = try the index-arithmetic path first and verify the grid on
+// the device in the same stream (default), 0 = always the generic bins path.  A target that fails the check costs the attempt's
+// launches (every kernel leaves at once) and one more synchronisation, ~0.1 ms; callers with host arrays are spared even that by
+// a look at a few corners (host_says_not_rect).
+static int g_search_rect = 1;
+extern "C" void fg_set_search_rect(int on) { g_search_rect = on ? 1 : 0; }
+static bool host_says_not_rect(int nx, int ny, const double *lon, const double *lat)
+{
+  const long nxp = nx + 1;
+  const int js[3] = {ny, ny / 2, 1}, is[3] = {nx, nx / 2, 1};
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      const long e = (long)js[a] * nxp + is[b];
+      if (memcmp(&lon[e], &lon[is[b]], sizeof(double)) || memcmp(&lat[e], &lat[(long)js[a] * nxp], sizeof(double))) return true;
+    }
+  return false;
 }
 #define FG_RETRY (-1000L)
 static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
@@ -482,21 +501,31 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   }
 
   // --- sizes known up front
+  const bool rect = caps->rect && !gc && !boxm;
+  pl->rect = rect;
   FgBins bins;
   choose_bins(pl, mean_dlat, mean_dlon, &bins);
+  if (rect) { bins.nblat = 0; bins.nblon = 0; }       // no bins on the rectilinear path
   const long nbins = (long)bins.nblat * bins.nblon;
   const long nslots = nbins + bins.nblat;             // regular bins + one wide list per bin row
-  const unsigned long long nentries = caps->entries;
+  const unsigned long long nentries = rect ? 0ull : caps->entries;
   const int ecap = (int)std::min<unsigned long long>(nentries, 2147483647ull);     // records the buffer holds: writes and reads stop there
   FgPairSpace ps{};
   ps.nreg = caps->nreg; ps.regcap = caps->regcap;
   const long npairs = fgd_pairs_total(ps);            // capacity of the pair list
   const long nx_alloc = npairs;                       // nxgrid <= candidate pairs <= capacity
 
-  if (!alloc_cells(pl, &pl->S, nsrc) || !alloc_cells(pl, &pl->D, ndst)) return fail(FG_ERR_HIP, "out of device memory");
+  if (!alloc_cells(pl, &pl->S, nsrc)) return fail(FG_ERR_HIP, "out of device memory");
+  double *rect_blk = nullptr;
+  if (rect) {
+    pl->D = FgCells{};
+    pl->D.area = pl->alloc<double>(ndst);
+    rect_blk = pl->alloc<double>(8 + (size_t)(pl->ny_out + 1) + (size_t)(pl->nx_out + 1) + 8 * (size_t)pl->nx_out);
+    if (!pl->D.area || !rect_blk) return fail(FG_ERR_HIP, "out of device memory");
+  } else if (!alloc_cells(pl, &pl->D, ndst)) return fail(FG_ERR_HIP, "out of device memory");
   // one zeroed block: [counters | region fill counters | tickets | look-back words of the three scans | bin counts |
   //                    bin fill cursors | destination-row counts | accepted pairs per source cell]
-  const int K = choose_chunks(nsrc, ps.nreg);
+  const int K = rect ? 1 : choose_chunks(nsrc, ps.nreg);
   const long t_bins = fgd_scan_tiles(nslots), t_rows = fgd_scan_tiles(ndst), t_comp = fgd_scan_tiles(nsrc) + K;
   const size_t zc = (sizeof(FgCounters) + 127) / 128 * 128;
   const size_t zfill = (size_t)FG_NREG * FG_FILL_STRIDE * sizeof(unsigned);      // (nreg <= FG_NREG)
@@ -558,6 +587,16 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     fgd_gc_cell_struct(gct_dev + pl->ntiles, 1, ndst, pl->D, st, g_search_cull ? dc->band_keys : nullptr, 1);
     fgd_gc_cell_struct(gct_dev, pl->ntiles, nsrc, pl->S, st, g_search_cull ? dc->band_keys : nullptr, 2);
     fgd_src_field_index(order, pl->tiles_dev, pl->ntiles, nsrc, pl->src_idx_f, st);
+  } else if (rect) {
+    // tables + on-device verification of the grid, then the source records, the heavy list and the destination AREAS in one launch
+    FgRect &R = pl->rect_tab;
+    R.hdr = rect_blk; R.lat_ax = rect_blk + 8; R.lon_ax = rect_blk + 8 + (pl->ny_out + 1); R.col = rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1);
+    R.bad = &dc->rect_bad; R.nx = pl->nx_out; R.ny = pl->ny_out;
+    if (g_search_cull) fgd_band_keys(d_lat_out, (long)(pl->nx_out + 1) * (pl->ny_out + 1), dc->band_keys, st);
+    fgd_rect_tables(d_lon_out, d_lat_out, pl->nx_out, pl->ny_out, rect_blk, rect_blk + 8, rect_blk + 8 + (pl->ny_out + 1),
+                    rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1), &dc->rect_bad, dc->err, st);
+    fgd_cell_struct2r(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D.area, R, pl->mask_dev, order, pl->src_idx_f, pl->sums,
+                      dc->err, st, dc->band_keys, g_search_cull ? 2 : 0, heavy_list, &dc->heavy_cnt);
   } else if (g_search_cull && !boxm) {
     // the destination grid's latitude range from its corners (a 5 us reduction), then ONE record launch in which the source
     // blocks that cannot meet it leave early (round 2 first ran a destination launch, then a source launch: two latency floors)
@@ -570,11 +609,13 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pt.end();
   pl->have_geom = true;
 
-  pt.begin(PH_BINS);
-  if (gc) fgd_bin_count(ndst, pl->D, bins, bin_cnt, st);
-  fgd_exclusive_scan1(bin_cnt, nslots, bin_start, lb_bins, &tickets[0], &dc->total[0], dc->err, st);
-  fgd_bin_fill(ndst, pl->D, bins, bin_fill, bin_start, bin_entries, ecap, nsrc, pl->S, pl->mask_dev, heavy_list, &dc->heavy_cnt, st);
-  pt.end();
+  if (!rect) {
+    pt.begin(PH_BINS);
+    if (gc) fgd_bin_count(ndst, pl->D, bins, bin_cnt, st);
+    fgd_exclusive_scan1(bin_cnt, nslots, bin_start, lb_bins, &tickets[0], &dc->total[0], dc->err, st);
+    fgd_bin_fill(ndst, pl->D, bins, bin_fill, bin_start, bin_entries, ecap, nsrc, pl->S, pl->mask_dev, heavy_list, &dc->heavy_cnt, st);
+    pt.end();
+  }
 
   // --- per chunk of source cells: candidates (stream A) -> clip (stream B) -> scan + compaction (stream A again).  The clip of
   // chunk k is VALU bound, its neighbours in the schedule wait on memory: side by side they fill each other's gaps.
@@ -603,8 +644,11 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
                                q.fill = ps.fill + (size_t)k * nreg_k * FG_FILL_STRIDE; return q; };
   pt.begin(PH_CANDIDATES);
   for (int k = 0; k < K; k++) {
-    fgd_candidates1(cb[k], cb[k + 1], pl->S, pl->mask_dev, bins, bin_start, bin_entries, ecap, chunk_ps(k), pair_beg, pair_cnt, heavy_list,
-                    &dc->heavy_cnt, big_list + cb[k], &dc->big_cnt[k], st);
+    if (rect)
+      fgd_candidates_rect(nsrc, pl->S, pl->mask_dev, pl->rect_tab, chunk_ps(k), pair_beg, pair_cnt, heavy_list, &dc->heavy_cnt, big_list, &dc->big_cnt[k], st);
+    else
+      fgd_candidates1(cb[k], cb[k + 1], pl->S, pl->mask_dev, bins, bin_start, bin_entries, ecap, chunk_ps(k), pair_beg, pair_cnt, heavy_list,
+                      &dc->heavy_cnt, big_list + cb[k], &dc->big_cnt[k], st);
     if (K > 1) { ev_c[k] = g_handles.get_sync_event(); HIPCHK(hipEventRecord(ev_c[k], st)); }
   }
   pt.end();
@@ -631,10 +675,10 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
       ptb.end();
     } else {
       ptb.begin(PH_CLIP_QUAD);
-      fgd_clip_quad(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb);
+      fgd_clip_quad(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb, rect ? &pl->rect_tab : nullptr);
       ptb.end();
       ptb.begin(PH_CLIP_GENERAL);
-      fgd_clip_general(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb);
+      fgd_clip_general(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb, rect ? &pl->rect_tab : nullptr);
       ptb.end();
     }
     if (K > 1) { ev_q[k] = g_handles.get_sync_event(); HIPCHK(hipEventRecord(ev_q[k], sb)); }
@@ -669,6 +713,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   for (hipEvent_t e : ev_c) g_handles.put_sync_event(e);
   for (hipEvent_t e : ev_q) g_handles.put_sync_event(e);
   HIPCHK(hipGetLastError());
+  if (rect && hc->rect_bad) { caps->rect = false; return FG_RETRY; }   // not a rectilinear grid after all: every kernel of this attempt left at once
   if (hc->total[0] > nentries) { caps->entries = hc->total[0]; return FG_RETRY; }
   if (hc->total[0] > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
   if (hc->total[3] > (unsigned long long)ps.regcap) {
@@ -697,6 +742,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pl->stats[FG_STAT_HEAVY] = hc->heavy_cnt;
   pl->stats[FG_STAT_BELOW] = (long)hc->stats[FG_STAT_BELOW];
 
+  pl->rect_tab.bad = nullptr;                          // (lives in the scratch block released below; nothing reads it after the search)
   // scratch no longer needed
   void *scratch[] = {zero_blk, bin_start, bin_entries, heavy_list, big_list, pair_beg, pair_cnt, ps.src, ps.dst,
                      tmp_area, tmp_clon, tmp_clat, defer_list, gc_meta, gc_tbase, gc_task, gc_res};
@@ -719,7 +765,7 @@ extern "C" void fg_set_search_cull(int on) { g_search_cull = on ? 1 : 0; }
 static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
                         double mean_dlat, double mean_dlon, const GcXyz *gc_in = nullptr, const GcXyz *gc_out = nullptr,
-                        const BoxMode *boxm = nullptr)
+                        const BoxMode *boxm = nullptr, int rect_hint = 1)
 {
   static const bool env_exact = getenv("FREGRID_HIP_EXACT_SEARCH") && atoi(getenv("FREGRID_HIP_EXACT_SEARCH")) != 0;
   const bool exact = g_search_exact || env_exact;
@@ -735,6 +781,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   // that small grids do not pile their pairs into a few small regions
   caps.nreg = (int)std::max(1L, std::min((long)FG_NREG, ((long)pl->nsrc + 1023) / 1024));
   caps.regcap = exact ? 0 : (int)((cap_pairs / caps.nreg + 255) / 256 * 256);
+  caps.rect = g_search_rect && rect_hint && !gc_in && !boxm && pl->nx_out <= 8192 && pl->nx_out >= 2;
   const size_t keep = pl->owned.size();              // blocks the caller staged before the search stay
   long rc = FG_RETRY;
   int attempts = 0;
@@ -745,7 +792,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
       pl->tiles_dev = nullptr; pl->mask_dev = nullptr; pl->S = FgCells{}; pl->D = FgCells{};
       pl->x_src = pl->x_dst = nullptr; pl->x_area = pl->x_c1 = pl->x_c2 = nullptr; pl->xoff = nullptr; pl->x_rowpos = nullptr;
       pl->perm = nullptr; pl->csr.row_ptr = nullptr; pl->src_idx_f = nullptr; pl->sums = nullptr;
-      pl->have_geom = false;
+      pl->have_geom = false; pl->rect = false; pl->rect_tab = FgRect{};
     }
     rc = plan_search_core(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon, gc_in, gc_out, boxm, &caps);
   }
@@ -812,7 +859,8 @@ extern "C" long fg_plan_create(int order, int ntiles_in, const int *nx_in, const
   if (!ok || !dlo || !dla) { fg_plan_destroy(pl); return fail(FG_ERR_HIP, "grid upload failed (out of device memory?)"); }
   double mdlat, mdlon;
   sample_extents(nx_out, ny_out, lon_out, lat_out, &mdlat, &mdlon);
-  long nx = plan_search(pl, dlon.data(), dlat.data(), mask_in ? dmask.data() : nullptr, dlo, dla, mdlat, mdlon);
+  long nx = plan_search(pl, dlon.data(), dlat.data(), mask_in ? dmask.data() : nullptr, dlo, dla, mdlat, mdlon, nullptr, nullptr, nullptr,
+                        host_says_not_rect(nx_out, ny_out, lon_out, lat_out) ? 0 : 1);
   if (nx < 0) { fg_plan_destroy(pl); return nx; }
   for (void *p : staged) pl->release(p);
   *plan_out = pl;
@@ -1211,7 +1259,21 @@ extern "C" int fg_plan_get_cell_struct(const fg_plan *pl, int which, double *lat
   if (!pl->have_geom) return fail(FG_ERR_STATE, "plan holds no cell records");
   HIPCHK(hipSetDevice(pl->device));
   HIPCHK(hipStreamSynchronize(pl->stream));
-  const FgCells &c = which ? pl->D : pl->S;
+  FgCells tmp{};
+  std::vector<void *> tmp_blocks;
+  struct Free { std::vector<void *> &v; ~Free() { for (void *p : v) g_pool.put(p); } } free_tmp{tmp_blocks};
+  if (which && pl->rect) {                       // a rectilinear plan keeps tables, not records: spell them out for the caller
+    const size_t nd = (size_t)pl->ndst;
+    auto get = [&](size_t bytes) { void *p = g_pool.get(pl->device, bytes); if (p) tmp_blocks.push_back(p); return p; };
+    tmp.lat_min = (double *)get(nd * 8); tmp.lat_max = (double *)get(nd * 8); tmp.lon_min = (double *)get(nd * 8);
+    tmp.lon_max = (double *)get(nd * 8); tmp.lon_avg = (double *)get(nd * 8); tmp.nv = (int *)get(nd * 4); tmp.verts = (double *)get(nd * 128);
+    tmp.area = pl->D.area;
+    if (tmp_blocks.size() != 7) return fail(FG_ERR_HIP, "out of device memory");
+    FgRect R = pl->rect_tab;
+    fgd_rect_materialize(pl->ndst, R, tmp, pl->stream);
+    HIPCHK(hipStreamSynchronize(pl->stream));
+  }
+  const FgCells &c = which ? (pl->rect ? tmp : pl->D) : pl->S;
   size_t n = which ? pl->ndst : pl->nsrc;
   if (lat_min) HIPCHK(hipMemcpy(lat_min, c.lat_min, n * sizeof(double), hipMemcpyDeviceToHost));
   if (lat_max) HIPCHK(hipMemcpy(lat_max, c.lat_max, n * sizeof(double), hipMemcpyDeviceToHost));

@@ -106,7 +106,8 @@ struct FgCounters {
   unsigned long long band_keys[2]; // latitude range of the destination cells as ordered keys (source-cell culling)
   unsigned long long xtot[FG_MAX_CHUNKS];   // running nxgrid after chunk k of the source cells (the last one is nxgrid)
   unsigned err[4];
-  int heavy_cnt, pad0;
+  int heavy_cnt;
+  unsigned rect_bad;               // rectilinear path: != 0 = the destination grid failed the check (k_rect_tables)
   int defer_cnt[FG_MAX_CHUNKS], big_cnt[FG_MAX_CHUNKS];
   int gc_list2_cnt[FG_MAX_CHUNKS];           // great-circle path: pairs k_gc_walk handed to the one-kernel clip
   unsigned long long stats[FG_NSTATS];
@@ -137,12 +138,31 @@ void fgd_bin_fill(int ndst, FgCells D, FgBins b, int *slot_fill, const int *slot
 void fgd_candidates1(int c0, int c1, FgCells S, const double *mask, FgBins b, const int *slot_start, const FgBinEntry *entries, int ecap,
                      FgPairSpace ps, int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt, int *big_list, int *big_cnt,
                      hipStream_t st);
+// A rectilinear destination grid (lon_out a function of the column, lat_out of the row, bit for bit): see k_rect_tables.
+// All pointers are device pointers; bad != 0 after the check kernel = the grid is NOT rectilinear (the tables are then junk).
+struct FgRect {
+  const double *lon_ax;   // [nx+1] raw longitude axis (copy of row 0 of lon_out)
+  const double *lat_ax;   // [ny+1] compact copy of lat_out[j][0]
+  const double *col;      // [nx][8] per column: the four longitudes after fix_lon (SW, SE, NE, NW), lon_min, lon_max, lon_avg, width
+  const double *hdr;      // [8] lon[0], nx / (lon[nx] - lon[0]), lat[0], ny / (lat[ny] - lat[0])
+  const unsigned *bad;
+  int nx, ny;
+};
+void fgd_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax, double *lon_ax, double *col,
+                     unsigned *bad, unsigned *err, hipStream_t st);
+void fgd_cell_struct2r(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, double *area_out,
+                       FgRect R, const double *mask, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
+                       unsigned long long *band_keys, int cull, int *heavy_list, int *heavy_cnt);
+void fgd_rect_materialize(int ndst, FgRect R, FgCells D, hipStream_t st);
+void fgd_candidates_rect(int nsrc, FgCells S, const double *mask, FgRect R, FgPairSpace ps, int *pair_beg, int *pair_cnt,
+                         const int *heavy_list, const int *heavy_cnt, int *big_list, int *big_cnt, hipStream_t st);
+// rect != null: the destination cells come from the rectilinear tables (D holds areas only)
 void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-              unsigned long long *stats, unsigned *err, hipStream_t st);
+              unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect = nullptr);
 void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-              unsigned long long *stats, unsigned *err, hipStream_t st);
+              unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect = nullptr);
 // accepted pairs -> exchange cells in canonical order (xoff = scan of the clip kernels' nacc), per-source-cell sums,
 // destination-row sizes and slots
 struct FgCompactIo {

@@ -26,6 +26,7 @@
 // No MFMA: this is FP64 VALU + irregular gather work.  Every floating-point operation uses the reference's expression
 // trees, sin/cos included (geom.hip.h, sincos_glibc.h): lists, areas and centroid integrals are the reference's bits.
 // Launched either for exact sizes or for fixed capacities with the true counts read from device memory (np_dev, cap).
+#include <algorithm>
 #include "xgrid_device.h"
 #ifndef FG_EXP
 #define FG_EXP 0      // timing experiments (scripts/exp_build.sh): 1 = no integrals, 2 = no clip loop
@@ -742,6 +743,342 @@ __global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCel
                           ids, s, psrc, pdst, wloc, (unsigned)ps.regcap);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// rectilinear destination grid
+// ---------------------------------------------------------------------------------------
+// lon_out depends on the column only and lat_out on the row only, bit for bit: what get_output_grid_by_size
+// (fregrid_util.c:588-654) makes for every --nlon/--nlat target, global or regional, whole or a rank's band.  Then
+//   * fix_lon's result for a cell depends on its column only (no lone pole vertex, no |dlon| = pi edge: checked), so a cell is
+//     four values of a per-column record + two values of the latitude axis -- no 128-byte vertex record, no per-cell boxes;
+//   * the reference's latitude reject (create_xgrid.c:1055) depends on the row only and its longitude reject (:1062-1079) on the
+//     column only: the candidates of a source cell are (rows found on the latitude axis) x (columns that pass the exact
+//     longitude test), found by index arithmetic -- no bins, no 48-byte record scans -- and come out in ascending destination
+//     index, the reference's order.
+// k_rect_tables VERIFIES the property on the device (every corner against its axis value, bitwise) in the same stream; every
+// later kernel of the rectilinear path leaves at once when the check failed, and the host repeats the search with the generic
+// path (plan.hip).  Results are the generic path's, bit for bit (tests/test_gpu_rect.py, scripts/legacy_fuzz.py).
+#define RECT_COLW 8           // doubles per column record: x'[0..3] after fix_lon (SW, SE, NE, NW), lon_min, lon_max, lon_avg, spare
+#define RECT_HDR 8            // header of the tables: lon[0], nx / (lon[nx] - lon[0]), lat[0], ny / (lat[ny] - lat[0])
+#define RECT_EPS 1.e-9
+#define RECT_HEAVY 48         // rows x window columns above which a source cell's candidates are made by a whole wave
+
+__global__ __launch_bounds__(256) void k_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax,
+                                                      double *lon_ax, double *col, unsigned *bad, unsigned *err)
+{
+  const long np = (long)(nx + 1) * (ny + 1);
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x, gsz = (long)gridDim.x * 256;
+  bool b = false;
+  for (long e = gid; e < np; e += gsz) {
+    const long j = e / (nx + 1); const int i = (int)(e - j * (nx + 1));
+    if (__double_as_longlong(lon[e]) != __double_as_longlong(lon[i]) ||
+        __double_as_longlong(lat[e]) != __double_as_longlong(lat[j * (nx + 1)])) b = true;
+  }
+  if (gid <= ny) {
+    const double y = lat[gid * (nx + 1)];
+    lat_ax[gid] = y;
+    if (!(y >= -G_HPI - 1.e-6) || !(y <= G_HPI + 1.e-6)) atomicOr(err, G_ERRBIT_BADLAT);       // (also NaN)
+    if (gid < ny && !(lat[(gid + 1) * (nx + 1)] > y)) b = true;                                 // strictly ascending rows
+    if (gid > 0 && gid < ny && d_is_pole(y)) b = true;                                          // a pole only as the outer edge of an outer row
+  }
+  if (gid <= nx) lon_ax[gid] = lon[gid];                                                        // (a copy: the caller's array may go away)
+  if (gid < nx) {
+    const double x0 = lon[gid], x1 = lon[gid + 1];
+    if (!(x1 > x0) || !(x1 - x0 < G_PI - 1.e-6)) b = true;                                      // ascending columns narrower than pi
+    double x[G_FIXCAP], y[G_FIXCAP];
+    x[0] = x0; x[1] = x1; x[2] = x1; x[3] = x0;
+    y[0] = 0.0; y[1] = 0.0; y[2] = 0.1; y[3] = 0.1;
+    const int n = d_fix_lon(x, y, 4, G_PI);
+    double *c = col + (size_t)gid * RECT_COLW;
+    if (n != 4) { b = true; for (int k = 0; k < RECT_COLW; k++) c[k] = 0.0; }
+    else {
+      double xmin = x[0], xmax = x[0], xs = 0;                                                  // as in d_cell_record
+      for (int k = 1; k < 4; k++) { if (x[k] < xmin) xmin = x[k]; if (x[k] > xmax) xmax = x[k]; }
+      for (int k = 0; k < 4; k++) xs += x[k];
+      xs /= 4;
+      c[0] = x[0]; c[1] = x[1]; c[2] = x[2]; c[3] = x[3]; c[4] = xmin; c[5] = xmax; c[6] = xs; c[7] = x1 - x0;
+    }
+  }
+  if (gid == 0) {
+    if (!(lon[nx] - lon[0] <= G_TPI + 1.e-9)) b = true;                                         // one turn at most
+    hdr[0] = lon[0]; hdr[1] = nx / (lon[nx] - lon[0]); hdr[2] = lat[0]; hdr[3] = ny / (lat[(long)ny * (nx + 1)] - lat[0]);
+  }
+  if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+
+// smallest k in [0, n] with ax[k] > v (STRICT) / ax[k] >= v (!STRICT); ax ascending.  (x0, inv): the uniform-axis guess that
+// is right for the regular grids this path mostly sees (two loads); a binary search otherwise.
+template <bool STRICT>
+__device__ __forceinline__ int d_axis_first(const double *ax, int n, double v, double x0, double inv)
+{
+  const double t = fmin(fmax(floor((v - x0) * inv), -1.0), (double)(n - 1));
+  const int g = (int)t;
+  auto above = [&](double a) { return STRICT ? a > v : a >= v; };
+  const bool lo_ok = (g < 0) || !above(ax[g]);
+  const bool hi_ok = (g + 1 >= n) || above(ax[g + 1]);
+  if (lo_ok && hi_ok) return g + 1;
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (above(ax[mid])) hi = mid; else lo = mid + 1; }
+  return lo;
+}
+
+struct RectQuery { int j0, j1; int nw; int wa[3], wb[3]; };   // rows [j0, j1]; nw column windows [wa, wb], disjoint, ascending
+
+__device__ __forceinline__ RectQuery d_rect_query(const FgRect &R, double lat_in_min, double lat_in_max, double lon_in_min, double lon_in_max)
+{
+  RectQuery q;
+  const double lon0 = R.hdr[0], inv_lon = R.hdr[1], lat0 = R.hdr[2], inv_lat = R.hdr[3];
+  // rows that pass create_xgrid.c:1055: lat[j+1] > lat_in_min && lat[j] < lat_in_max
+  q.j0 = max(d_axis_first<true>(R.lat_ax, R.ny + 1, lat_in_min, lat0, inv_lat) - 1, 0);
+  q.j1 = min(d_axis_first<false>(R.lat_ax, R.ny + 1, lat_in_max, lat0, inv_lat) - 1, R.ny - 1);
+  q.nw = 0;
+  if (lon_in_max - lon_in_min > G_PI) { q.nw = 1; q.wa[0] = 0; q.wb[0] = R.nx - 1; return q; }   // pole caps: every column is tested
+  // a column passes only if its raw interval, moved by a whole number of turns, meets (lon_in_min, lon_in_max): fix_lon moves the
+  // cell by 0 / +-2pi, the reference's test by another 0 / +-2pi.  The windows for different turns are disjoint (columns are
+  // narrower than pi, the source range is at most pi, the axis spans one turn at most); the exact test decides inside them.
+  const double axl = R.lon_ax[0], axh = R.lon_ax[R.nx];
+#pragma unroll
+  for (int t = 2; t >= -2; t--) {                      // descending shift = ascending columns
+    const double T = t * G_TPI;
+    const double lo = lon_in_min - RECT_EPS - T, hi = lon_in_max + RECT_EPS - T;
+    if (!(axh > lo) || !(axl < hi)) continue;
+    const int a = max(d_axis_first<true>(R.lon_ax, R.nx + 1, lo, lon0, inv_lon) - 1, 0);
+    const int b = min(d_axis_first<false>(R.lon_ax, R.nx + 1, hi, lon0, inv_lon) - 1, R.nx - 1);
+    if (a <= b && q.nw < 3) { q.wa[q.nw] = a; q.wb[q.nw] = b; q.nw++; }
+  }
+  return q;
+}
+__device__ __forceinline__ int d_rect_ncols(const RectQuery &q)
+{
+  int n = 0;
+  for (int w = 0; w < q.nw; w++) n += q.wb[w] - q.wa[w] + 1;
+  return n;
+}
+__device__ __forceinline__ bool d_rect_heavy(const RectQuery &q)
+{
+  const int nr = q.j1 - q.j0 + 1, nc = d_rect_ncols(q);
+  return nr > 0 && nc > 0 && (nc > 64 || (long)nr * nc > RECT_HEAVY);
+}
+// column k of the query's concatenated windows
+__device__ __forceinline__ int d_rect_col(const RectQuery &q, int k)
+{
+  int i = q.wa[0] + k;
+  const int l0 = q.wb[0] - q.wa[0] + 1;
+  if (q.nw > 1 && k >= l0) { i = q.wa[1] + (k - l0); const int l1 = q.wb[1] - q.wa[1] + 1; if (q.nw > 2 && k - l0 >= l1) i = q.wa[2] + (k - l0 - l1); }
+  return i;
+}
+// the reference's longitude reject for column record c (create_xgrid.c:1062-1079)
+__device__ __forceinline__ bool d_rect_col_pass(const double *c, double lon_in_min, double lon_in_max, double lon_in_avg)
+{
+  double lon_out_min = c[4], lon_out_max = c[5];
+  const double dx = c[6] - lon_in_avg;
+  if (dx < -G_PI)     { lon_out_min += G_TPI; lon_out_max += G_TPI; }
+  else if (dx > G_PI) { lon_out_min -= G_TPI; lon_out_max -= G_TPI; }
+  return !(lon_out_min >= lon_in_max || lon_out_max <= lon_in_min);
+}
+
+// Rectilinear twin of k_cell_struct2: source blocks make the full records (and list the cells whose candidates a whole wave
+// will make), destination blocks store the cell AREA only.
+__global__ __launch_bounds__(256) void k_cell_struct2r(FgTileSet ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst,
+                                                        int nbS, FgCells S, double *area_out, FgRect R, const double *mask, int order, int *src_idx_f,
+                                                        double *sums, unsigned *err, unsigned long long *band_keys, int cull,
+                                                        int *heavy_list, int *heavy_cnt)
+{
+  __shared__ double vtile[256 * 17];
+  __shared__ FgTile sh_tiles[FG_TILESET_MAX];
+  if (*R.bad) return;
+  if (ts.n && (int)threadIdx.x < ts.n) sh_tiles[threadIdx.x] = ts.t[threadIdx.x];
+  const bool isD = (int)blockIdx.x >= nbS;
+  if (cull && !isD && band_keys[0]) {                      // (as in k_cell_struct2: blocks wholly outside the band leave early)
+    __syncthreads();
+    const FgTile *tl0 = ts.n ? sh_tiles : tiles_in;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    int idx_f = s;
+    if (s < nsrc) {
+      int t = 0;
+      while (t + 1 < ntiles && s >= tl0[t + 1].cell_off) t++;
+      const int loc = s - tl0[t].cell_off, i = loc % tl0[t].nx, j = loc / tl0[t].nx, nxp = tl0[t].nx + 1;
+      if (order == 2) {
+        int foff = 0;
+        for (int m = 0; m < t; m++) foff += (tl0[m].nx + 2) * (tl0[m].ny + 2);
+        idx_f = foff + (j + 1) * (tl0[t].nx + 2) + i + 1;
+      }
+      const int n0 = j * nxp + i;
+      const double y0 = tl0[t].lat[n0], y1 = tl0[t].lat[n0 + 1], y2 = tl0[t].lat[n0 + nxp + 1], y3 = tl0[t].lat[n0 + nxp];
+      const double lmin = fmin(fmin(y0, y1), fmin(y2, y3)), lmax = fmax(fmax(y0, y1), fmax(y2, y3));
+      const double bmax = d_ord_val(band_keys[0]), bmin = d_ord_val(~band_keys[1]);
+      keep = !((lmax <= bmin) || (lmin >= bmax)) || !(lmin == lmin);
+    }
+    if (!__syncthreads_or(keep)) {
+      if (s < nsrc) {
+        S.nv[s] = 0; S.area[s] = 0;
+        if (src_idx_f) src_idx_f[s] = idx_f;
+        if (sums) { sums[s] = 0.0; sums[nsrc + s] = 0.0; sums[2 * (size_t)nsrc + s] = 0.0; }
+      }
+      if (ts.n && blockIdx.x == 0 && (int)threadIdx.x < ts.n) tiles_out[threadIdx.x] = sh_tiles[threadIdx.x];
+      return;
+    }
+  }
+  d_load_trig_table();                                   // (barrier inside)
+  const FgTile *tiles = ts.n ? sh_tiles : tiles_in;
+  if (ts.n && blockIdx.x == 0 && (int)threadIdx.x < ts.n) tiles_out[threadIdx.x] = sh_tiles[threadIdx.x];
+  if (!isD) {
+    double box[5] = {0, 0, 0, 0, 0};
+    int tl = 0;
+    const int s0 = blockIdx.x * 256, s = s0 + threadIdx.x, lane = threadIdx.x & 63;
+    const int nv = d_cell_record(tiles, ntiles, nsrc, S, err, s0, vtile, box, &tl, cull ? band_keys : nullptr);
+    if (s < nsrc && sums) { sums[s] = 0.0; sums[nsrc + s] = 0.0; sums[2 * (size_t)nsrc + s] = 0.0; }
+    if (s < nsrc && src_idx_f) {
+      if (order != 2) src_idx_f[s] = s;
+      else {
+        int foff = 0;
+        for (int t = 0; t < tl; t++) foff += (tiles[t].nx + 2) * (tiles[t].ny + 2);
+        const int loc = s - tiles[tl].cell_off, i = loc % tiles[tl].nx, j = loc / tiles[tl].nx;
+        src_idx_f[s] = foff + (j + 1) * (tiles[tl].nx + 2) + i + 1;
+      }
+    }
+    bool heavy = false;
+    if (s < nsrc && nv > 0 && (!mask || mask[s] > 0.5)) heavy = d_rect_heavy(d_rect_query(R, box[0], box[1], box[2], box[3]));
+    const unsigned long long m = __ballot(heavy);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(heavy_cnt, __popcll(m));
+      base = __shfl(base, 0);
+      if (heavy) heavy_list[base + __popcll(m & ((1ull << lane) - 1ull))] = s;
+    }
+  } else {
+    const int d = ((int)blockIdx.x - nbS) * 256 + threadIdx.x;
+    if (d < ndst) {
+      const int j = d / R.nx, i = d - j * R.nx;
+      const double *c = R.col + (size_t)i * RECT_COLW;
+      const double ya = R.lat_ax[j], yb = R.lat_ax[j + 1];
+      double x[4] = {c[0], c[1], c[2], c[3]}, y[4] = {ya, ya, yb, yb};
+      area_out[d] = d_poly_area<1>(x, y, 4);
+    }
+  }
+}
+
+// the full destination records of a rectilinear plan, for fg_plan_get_cell_struct (tests): what k_cell_struct2 would have stored
+__global__ __launch_bounds__(256) void k_rect_materialize(int ndst, FgRect R, FgCells D)
+{
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= ndst) return;
+  const int j = d / R.nx, i = d - j * R.nx;
+  const double *c = R.col + (size_t)i * RECT_COLW;
+  const double ya = R.lat_ax[j], yb = R.lat_ax[j + 1];
+  D.lat_min[d] = ya; D.lat_max[d] = yb; D.lon_min[d] = c[4]; D.lon_max[d] = c[5]; D.lon_avg[d] = c[6]; D.nv[d] = 4;
+  double *v = D.verts + (size_t)d * 16;
+  for (int k = 0; k < 16; k++) v[k] = 0.0;
+  v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; v[3] = c[3];
+  v[8] = ya; v[9] = ya; v[10] = yb; v[11] = yb;
+}
+
+// Candidates on a rectilinear destination grid.  Blocks [0, H): a wave per listed source cell (pole caps: every column);
+// blocks [H, ...): one lane per source cell.  Pairs of a cell are contiguous and in ascending destination index.
+__global__ __launch_bounds__(64) void k_candidates_rect(int nsrc, int H, FgCells S, const double *mask, FgRect R, FgPairSpace ps,
+                                                         int *pair_beg, int *pair_cnt, const int *heavy_list, const int *heavy_cnt,
+                                                         int *big_list, int *big_cnt)
+{
+  if (*R.bad) return;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x < H) {
+    const int nheavy = *heavy_cnt;
+    for (int h = blockIdx.x; h < nheavy; h += H) {
+      const int s = heavy_list[h];
+      const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
+      const RectQuery q = d_rect_query(R, S.lat_min[s], S.lat_max[s], lon_in_min, lon_in_max);
+      const int nwc = d_rect_ncols(q), nr = q.j1 - q.j0 + 1;
+      // pass 1: the columns that pass (the same set for every row of the query); pass 2 writes row after row -- the flags are
+      // recomputed per 64-column chunk instead of listed (a list in LDS would cost every block of the launch its occupancy)
+      int nc = 0;
+      for (int kb = 0; kb < nwc; kb += 64) {
+        const int k = kb + lane;
+        const bool pass = k < nwc && d_rect_col_pass(R.col + (size_t)d_rect_col(q, k) * RECT_COLW, lon_in_min, lon_in_max, lon_in_avg);
+        nc += __popcll(__ballot(pass));
+      }
+      const long cnt_l = (long)nr * nc;
+      const int cnt = (int)min(cnt_l, 0x7fffffffL);
+      const int r = (int)(((unsigned)s * 2654435761u >> 12) % (unsigned)ps.nreg);
+      unsigned base = 0;
+      if (lane == 0 && cnt) base = atomicAdd(&ps.fill[r * FG_FILL_STRIDE], (unsigned)cnt);
+      base = __shfl(base, 0);
+      const int loc0 = (int)min(base, (unsigned)ps.regcap), n_ok = min(cnt, ps.regcap - loc0);
+      const int wbase = r * ps.regcap + loc0;
+      int cbase = 0;
+      for (int kb = 0; kb < nwc && n_ok > 0; kb += 64) {
+        const int k = kb + lane;
+        int i = 0; bool pass = false;
+        if (k < nwc) { i = d_rect_col(q, k); pass = d_rect_col_pass(R.col + (size_t)i * RECT_COLW, lon_in_min, lon_in_max, lon_in_avg); }
+        const unsigned long long m = __ballot(pass);
+        const int at = cbase + __popcll(m & ((1ull << lane) - 1ull));
+        if (pass)
+          for (int jr = 0; jr < nr; jr++) {
+            const long kk = (long)jr * nc + at;
+            if (kk < n_ok) { ps.src[wbase + kk] = s; ps.dst[wbase + kk] = (q.j0 + jr) * R.nx + i; }
+          }
+        cbase += __popcll(m);
+      }
+      if (lane == 0) { pair_beg[s] = wbase; pair_cnt[s] = n_ok; if (n_ok > CP_SMALL) big_list[atomicAdd(big_cnt, 1)] = s; }
+    }
+    return;
+  }
+  const int bR = (int)blockIdx.x - H;
+  const int s = bR * 64 + lane;
+  int cnt = 0, nr = 0;
+  unsigned long long cmask = 0ull;
+  RectQuery q{};
+  bool heavy = false;
+  if (s < nsrc && d_src_active(S, mask, s)) {
+    const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
+    q = d_rect_query(R, S.lat_min[s], S.lat_max[s], lon_in_min, lon_in_max);
+    heavy = d_rect_heavy(q);                             // listed by k_cell_struct2r; a whole wave writes its pairs
+    nr = q.j1 - q.j0 + 1;
+    if (!heavy && nr > 0) {
+      const int nwc = d_rect_ncols(q);                   // <= 64
+      for (int k = 0; k < nwc; k++)
+        if (d_rect_col_pass(R.col + (size_t)d_rect_col(q, k) * RECT_COLW, lon_in_min, lon_in_max, lon_in_avg)) cmask |= 1ull << k;
+      cnt = nr * __popcll(cmask);
+    }
+  }
+  const unsigned incl = wave_incl_scan((unsigned)cnt, lane);
+  const unsigned total = __shfl(incl, 63);
+  const unsigned excl = incl - (unsigned)cnt;
+  const int r = (int)((((unsigned)bR) * 2654435761u >> 12) % (unsigned)ps.nreg);
+  unsigned base = 0;
+  if (lane == 0 && total) base = atomicAdd(&ps.fill[r * FG_FILL_STRIDE], total);
+  base = __shfl(base, 0);
+  int n_ok = 0;
+  const unsigned first = base + excl;
+  if (s < nsrc && !heavy) {
+    const int loc0 = (int)min(first, (unsigned)ps.regcap);
+    n_ok = min(cnt, ps.regcap - loc0);
+    pair_beg[s] = r * ps.regcap + loc0;
+    pair_cnt[s] = n_ok;
+  }
+  {
+    const bool bigc = n_ok > CP_SMALL;
+    const unsigned long long bm = __ballot(bigc);
+    if (bm) {
+      int qq = 0;
+      if (lane == 0) qq = atomicAdd(big_cnt, __popcll(bm));
+      qq = __shfl(qq, 0);
+      if (bigc) big_list[qq + __popcll(bm & ((1ull << lane) - 1ull))] = s;
+    }
+  }
+  if (n_ok <= 0) return;
+  int *psrc = ps.src + (size_t)r * ps.regcap + first, *pdst = ps.dst + (size_t)r * ps.regcap + first;
+  int w = 0;
+  for (int j = q.j0; j <= q.j1 && w < n_ok; j++) {
+    unsigned long long m = cmask;
+    while (m && w < n_ok) {
+      const int k = __ffsll((long long)m) - 1; m &= m - 1ull;
+      psrc[w] = s; pdst[w] = j * R.nx + d_rect_col(q, k);
+      w++;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // clip + area (+ centroid integrals)
 // ---------------------------------------------------------------------------------------
@@ -769,27 +1106,40 @@ __device__ __forceinline__ void d_finish_pair(const double *px, const double *py
 // Quad x quad fast path.  LDS: polygon [8][256] double2 (32 KiB); the cutting quad lives in registers.
 // Returns false if the pair must go to the general kernel (more than 4 vertices on a side, or more than 8
 // in an intermediate polygon); otherwise *o holds the result (area >= 0 accepted, -1 empty, -2 below threshold).
-template <int ORDER>
+// RECT: the destination cell is four values of its column record and two of the latitude axis (FgRect) -- D holds areas only.
+template <int ORDER, bool RECT>
 __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS], const int tid, const int s, const int d,
-                                                 const FgCells &S, const double *mask, const FgCells &D,
+                                                 const FgCells &S, const double *mask, const FgCells &D, const FgRect &R,
                                                  ClipOut *o_out, unsigned long long *stats, unsigned *err)
 {
-  const int n1 = S.nv[s], n2 = D.nv[d];
+  const int n1 = S.nv[s], n2 = RECT ? 4 : D.nv[d];
   if (n1 > 4 || n2 > 4) return false;
 
-  const double *sv = S.verts + (size_t)s * 16, *dv = D.verts + (size_t)d * 16;
+  const double *sv = S.verts + (size_t)s * 16;
   const double lon_in_avg = S.lon_avg[s];
+  double x1[4], y1[4], x2[4], y2[4];
+  double lon_out_avg;
+  if (RECT) {
+    const int j = d / R.nx, i = d - j * R.nx;
+    const double *c = R.col + (size_t)i * RECT_COLW;
+    const double ya = R.lat_ax[j], yb = R.lat_ax[j + 1];
+    x2[0] = c[0]; x2[1] = c[1]; x2[2] = c[2]; x2[3] = c[3]; lon_out_avg = c[6];
+    y2[0] = ya; y2[1] = ya; y2[2] = yb; y2[3] = yb;
+  } else {
+    const double *dv = D.verts + (size_t)d * 16;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x2[k] = dv[k]; y2[k] = dv[8 + k]; }
+    lon_out_avg = D.lon_avg[d];
+  }
   double shift = 0.0;
   {
-    double dx = D.lon_avg[d] - lon_in_avg;           // create_xgrid.c:1064-1074
+    double dx = lon_out_avg - lon_in_avg;            // create_xgrid.c:1064-1074
     if (dx < -G_PI) shift = G_TPI; else if (dx > G_PI) shift = -G_TPI;
   }
-  double x1[4], y1[4], x2[4], y2[4];
   bool wrap = false;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     x1[k] = sv[k]; y1[k] = sv[8 + k];
-    x2[k] = dv[k]; y2[k] = dv[8 + k];
     if (shift != 0.0) x2[k] += shift;
     if (k < n1 && (x1[k] > G_TPI || x1[k] < 0.0)) wrap = true;  // create_xgrid.c:1282
   }
@@ -893,13 +1243,14 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
 // (The integrals loop over the polygon's edges and a wave runs as many iterations as its largest polygon has.  Re-binning the
 // block's 256 polygons by vertex count through LDS before the integrals, so that a wave sees polygons of equal size, was
 // measured: 502 us against 482 -- the extra barriers and the scattered LDS columns cost more than the divergence.)
-template <int ORDER>
-__global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D,
+template <int ORDER, bool RECT>
+__global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D, FgRect R,
                                                             double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
                                                             int *defer_list, int *defer_cnt,
                                                             unsigned long long *stats, unsigned *err)
 {
   __shared__ double2 sh_poly[8][CLIP_THREADS];
+  if (RECT && *R.bad) return;
   {                                                   // the launch covers the regions' CAPACITY: blocks beyond a region's fill leave at once
     const unsigned first = blockIdx.x * CLIP_THREADS, r = first / (unsigned)ps.regcap;
     if (first - r * (unsigned)ps.regcap >= ps.fill[r * FG_FILL_STRIDE]) return;
@@ -913,7 +1264,7 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCe
     s = ps.src[p];
     const int d = ps.dst[p];
     ClipOut o;
-    if (!d_clip_quad_pair<ORDER>(sh_poly, tid, s, d, S, mask, D, &o, stats, err)) defer = true;   // rare; the general kernel finishes this pair
+    if (!d_clip_quad_pair<ORDER, RECT>(sh_poly, tid, s, d, S, mask, D, R, &o, stats, err)) defer = true;   // rare; the general kernel finishes this pair
     else if (o.area >= 0) {
       acc = true;
       tmp_area[p] = o.area;
@@ -951,28 +1302,44 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCe
 // LDS: two [16][64] double2 ping-pong buffers + cutter [8][64] double2 = 40 KiB.
 #define GEN_THREADS 64
 #define GEN_CAP 16
-template <int ORDER>
+template <int ORDER, bool RECT>
 __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_list, const int *defer_cnt,
                                                               const int *pair_src, int *pair_dst,
-                                                              FgCells S, const double *mask, FgCells D,
+                                                              FgCells S, const double *mask, FgCells D, FgRect R,
                                                               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
                                                               unsigned long long *stats, unsigned *err)
 {
   __shared__ double2 sh_a[GEN_CAP][GEN_THREADS];
   __shared__ double2 sh_b[GEN_CAP][GEN_THREADS];
   __shared__ double2 sh_cut[G_MAXV][GEN_THREADS];
+  if (RECT && *R.bad) return;
   d_load_trig_table();
   const int tid = threadIdx.x;
   const int ndefer = *defer_cnt;
   for (int q = blockIdx.x * GEN_THREADS + tid; q < ndefer; q += gridDim.x * GEN_THREADS) {
     const int p = defer_list[q];
     const int s = pair_src[p], d = pair_dst[p];
-    const int n1 = S.nv[s], n2 = D.nv[d];
-    const double *sv = S.verts + (size_t)s * 16, *dv = D.verts + (size_t)d * 16;
+    const int n1 = S.nv[s], n2 = RECT ? 4 : D.nv[d];
+    const double *sv = S.verts + (size_t)s * 16;
     const double lon_in_avg = S.lon_avg[s];
+    double dvx[G_MAXV], dvy[G_MAXV], lon_out_avg;
+    if (RECT) {
+      const int j = d / R.nx, i = d - j * R.nx;
+      const double *c = R.col + (size_t)i * RECT_COLW;
+      const double ya = R.lat_ax[j], yb = R.lat_ax[j + 1];
+      dvx[0] = c[0]; dvx[1] = c[1]; dvx[2] = c[2]; dvx[3] = c[3]; lon_out_avg = c[6];
+      dvy[0] = ya; dvy[1] = ya; dvy[2] = yb; dvy[3] = yb;
+#pragma unroll
+      for (int k = 4; k < G_MAXV; k++) { dvx[k] = 0.0; dvy[k] = 0.0; }
+    } else {
+      const double *dv = D.verts + (size_t)d * 16;
+#pragma unroll
+      for (int k = 0; k < G_MAXV; k++) { dvx[k] = dv[k]; dvy[k] = dv[8 + k]; }
+      lon_out_avg = D.lon_avg[d];
+    }
     double shift = 0.0;
     {
-      double dx = D.lon_avg[d] - lon_in_avg;
+      double dx = lon_out_avg - lon_in_avg;
       if (dx < -G_PI) shift = G_TPI; else if (dx > G_PI) shift = -G_TPI;
     }
     bool wrap = false;
@@ -981,10 +1348,12 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
       double xv = sv[k]; if (wrap) xv = d_pimod1(xv);
       sh_a[k][tid] = make_double2(xv, sv[8 + k]);
     }
-    for (int k = 0; k < n2; k++) {
-      double xv = dv[k]; if (shift != 0.0) xv += shift; if (wrap) xv = d_pimod1(xv);
-      sh_cut[k][tid] = make_double2(xv, dv[8 + k]);
-    }
+#pragma unroll
+    for (int k = 0; k < G_MAXV; k++)
+      if (k < n2) {
+        double xv = dvx[k]; if (shift != 0.0) xv += shift; if (wrap) xv = d_pimod1(xv);
+        sh_cut[k][tid] = make_double2(xv, dvy[k]);
+      }
     double2 (*cur)[GEN_THREADS] = sh_a;
     double2 (*nxt)[GEN_THREADS] = sh_b;
     int n_cur = n1;
@@ -1317,27 +1686,60 @@ void fgd_candidates1(int c0, int c1, FgCells S, const double *mask, FgBins b, co
 
 void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
                    double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-                   unsigned long long *stats, unsigned *err, hipStream_t st)
+                   unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect)
 {
   const long np = fgd_pairs_total(ps);
   if (np <= 0) return;
-  if (order == 2)
-    k_clip_quad<2><<<nblk(np, CLIP_THREADS), CLIP_THREADS, 0, st>>>(ps, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err);
-  else
-    k_clip_quad<1><<<nblk(np, CLIP_THREADS), CLIP_THREADS, 0, st>>>(ps, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err);
+  const FgRect R = rect ? *rect : FgRect{};
+  const int g = nblk(np, CLIP_THREADS);
+#define FG_LAUNCH_QUAD(O, RC) k_clip_quad<O, RC><<<g, CLIP_THREADS, 0, st>>>(ps, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err)
+  if (order == 2) { if (rect) FG_LAUNCH_QUAD(2, true); else FG_LAUNCH_QUAD(2, false); }
+  else            { if (rect) FG_LAUNCH_QUAD(1, true); else FG_LAUNCH_QUAD(1, false); }
+#undef FG_LAUNCH_QUAD
 }
 
 void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
                       double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-                      unsigned long long *stats, unsigned *err, hipStream_t st)
+                      unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect)
 {
   const long np = fgd_pairs_total(ps);
   if (np <= 0) return;
   int grid = nblk(np, GEN_THREADS); if (grid > 1024) grid = 1024;
-  if (order == 2)
-    k_clip_general<2><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
-  else
-    k_clip_general<1><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, tmp_area, tmp_clon, tmp_clat, nacc, stats, err);
+  const FgRect R = rect ? *rect : FgRect{};
+#define FG_LAUNCH_GEN(O, RC) k_clip_general<O, RC><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, stats, err)
+  if (order == 2) { if (rect) FG_LAUNCH_GEN(2, true); else FG_LAUNCH_GEN(2, false); }
+  else            { if (rect) FG_LAUNCH_GEN(1, true); else FG_LAUNCH_GEN(1, false); }
+#undef FG_LAUNCH_GEN
+}
+
+// ---- rectilinear destination grid
+void fgd_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax, double *lon_ax, double *col, unsigned *bad,
+                     unsigned *err, hipStream_t st)
+{
+  const long np = (long)(nx + 1) * (ny + 1);
+  const int g = (int)std::min<long>(1024, std::max<long>((np + 255) / 256, (std::max(nx, ny) + 1 + 255) / 256));
+  k_rect_tables<<<std::max(g, 1), 256, 0, st>>>(lon, lat, nx, ny, hdr, lat_ax, lon_ax, col, bad, err);
+}
+void fgd_cell_struct2r(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, double *area_out,
+                       FgRect R, const double *mask, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
+                       unsigned long long *band_keys, int cull, int *heavy_list, int *heavy_cnt)
+{
+  const int nbS = nblk(nsrc, 256), nbD = nblk(ndst, 256);
+  if (nbS + nbD > 0)
+    k_cell_struct2r<<<nbS + nbD, 256, 0, st>>>(ts, tiles_in, tiles_out, ntiles, nsrc, ndst, nbS, S, area_out, R, mask, order, src_idx_f, sums, err,
+                                               band_keys, cull, heavy_list, heavy_cnt);
+}
+void fgd_rect_materialize(int ndst, FgRect R, FgCells D, hipStream_t st)
+{
+  if (ndst > 0) k_rect_materialize<<<nblk(ndst, 256), 256, 0, st>>>(ndst, R, D);
+}
+void fgd_candidates_rect(int nsrc, FgCells S, const double *mask, FgRect R, FgPairSpace ps, int *pair_beg, int *pair_cnt,
+                         const int *heavy_list, const int *heavy_cnt, int *big_list, int *big_cnt, hipStream_t st)
+{
+  if (nsrc <= 0) return;
+  const int nbR = nblk(nsrc, 64);
+  const int H = min(HEAVY_BLOCKS, max(64, nblk(nsrc, 64)));
+  k_candidates_rect<<<nbR + H, 64, 0, st>>>(nsrc, H, S, mask, R, ps, pair_beg, pair_cnt, heavy_list, heavy_cnt, big_list, big_cnt);
 }
 
 void fgd_compact(int order, int nsrc, FgPairSpace ps, const FgCompactIo &io, hipStream_t st)

@@ -320,6 +320,12 @@ void fg_set_search_chunks(int chunks);
  * rank of a banded multi-GPU job meets a fraction of the source cells); fg_plan_get_cell_area / _cell_struct then return 0 /
  * unspecified values for those cells.  The exchange cells are unchanged.  Default 0. */
 void fg_set_search_cull(int on);
+/* Rectilinear destination grids -- lon_out a function of the column and lat_out of the row, bit for bit: every target
+ * get_output_grid_by_size makes (fregrid_util.c:588-654), whole or a rank's band.  1 (default): the legacy search finds the
+ * candidates of a source cell by index arithmetic on the two axes and builds destination cells from per-column / per-row tables
+ * (no bins, no per-cell records); the property is verified on the device inside the search, and a grid that fails it is searched
+ * by the generic path in the same call.  0: always the generic path.  Results do not depend on it (tests/test_gpu_rect.py). */
+void fg_set_search_rect(int on);
 /* Sweep tuning hook: 1 (default) = 8-level order-2 sweeps on merged records use the entry-parallel kernel when rows are short
  * (nxgrid <= 6 x destination cells), 0 = always the row-serial kernel.  Results do not depend on it. */
 void fg_set_apply_ep(int on);

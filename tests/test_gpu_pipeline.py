@@ -405,7 +405,15 @@ def test_fast_search_overflow_falls_back_to_exact_mode(fg, gpu_ok):
     assert st2["exact_mode"] == 1 and n1 == n2 and st1["pairs"] == st2["pairs"]
 
 
-def test_chunked_search_gives_the_same_plan(fg, gpu_ok):
+@pytest.fixture
+def generic_path(fg):
+    """the machinery of the generic (bins) search on lat-lon targets, which the rectilinear path would otherwise take"""
+    fg.lib().fg_set_search_rect(0)
+    yield
+    fg.lib().fg_set_search_rect(1)
+
+
+def test_chunked_search_gives_the_same_plan(fg, gpu_ok, generic_path):
     """Large grids are searched in chunks of source cells (clip of one chunk on a second stream beside the candidate scan of
     the next): force 1, 3 and 8 chunks on a small case -- exchange cells, order-2 integrals and the sweep must not change."""
     lon, lat = fg.gnomonic_ed_corners(24)
@@ -585,7 +593,7 @@ def test_entry_parallel_sweep_keeps_the_bits(fg, gpu_ok, ni, nlon, nlat):
     assert np.array_equal(outs[0], outs[1])
 
 
-def test_bin_record_overflow_falls_back_to_exact_mode(fg, gpu_ok):
+def test_bin_record_overflow_falls_back_to_exact_mode(fg, gpu_ok, generic_path):
     """Bins no larger than the target cells (the caller's mean cell size is an input): every target cell then spans four bin
     rows, lands in the per-row wide lists four times and the single-sync search's record buffer (3 per target cell) is too
     small -- the kernels must stay inside it and the search must be repeated with exact sizes, giving the oracle's list."""
