@@ -102,6 +102,33 @@ __device__ inline int d_fix_lon(double *x, double *y, int n, double tlon)
   return nn;
 }
 
+// fix_lon of a quadrilateral without a pole vertex and without a |dlon| = pi edge -- every cell of a grid but the handful at
+// the poles: the reference's first three loops do nothing then, and what is left is the unwrap and the recentring on four
+// statically indexed values (the general routine walks 12-element private arrays with dynamic indices, which the compiler turns
+// into select chains: it was most of the ~6000 instructions per wave of the cell-record kernel).  Returns 4, or -1 when the cell
+// needs the general routine (nothing has been modified then).  Same operations in the same order as d_fix_lon on this path.
+__device__ __forceinline__ int d_fix_lon_quad_fast(double *x, const double *y, double tlon)
+{
+  if (d_is_pole(y[0]) || d_is_pole(y[1]) || d_is_pole(y[2]) || d_is_pole(y[3])) return -1;
+  {
+    const double d0 = x[0] - x[3], d1 = x[1] - x[0], d2 = x[2] - x[1], d3 = x[3] - x[2];
+    if (fabs(d0 + G_PI) < G_SMALL || fabs(d0 - G_PI) < G_SMALL || fabs(d1 + G_PI) < G_SMALL || fabs(d1 - G_PI) < G_SMALL ||
+        fabs(d2 + G_PI) < G_SMALL || fabs(d2 - G_PI) < G_SMALL || fabs(d3 + G_PI) < G_SMALL || fabs(d3 - G_PI) < G_SMALL) return -1;
+  }
+  double x_sum = x[0];
+#pragma unroll
+  for (int i = 1; i < 4; i++) {
+    double dx = x[i] - x[i - 1];
+    if (dx < -G_PI)     dx = dx + G_TPI;
+    else if (dx > G_PI) dx = dx - G_TPI;
+    x_sum += (x[i] = x[i - 1] + dx);
+  }
+  const double d = (x_sum / 4) - tlon;
+  if (d < -G_PI)     { x[0] += G_TPI; x[1] += G_TPI; x[2] += G_TPI; x[3] += G_TPI; }
+  else if (d > G_PI) { x[0] -= G_TPI; x[1] -= G_TPI; x[2] -= G_TPI; x[3] -= G_TPI; }
+  return 4;
+}
+
 __device__ __forceinline__ int d_inside_edge(double x0, double y0, double x1, double y1, double x, double y)
 {
   double product = (x - x0) * (y1 - y0) + (x0 - x1) * (y - y0);

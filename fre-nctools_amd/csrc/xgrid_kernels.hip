@@ -225,7 +225,8 @@ __device__ __forceinline__ int d_cell_record(const FgTile *tiles, int ntiles, in
       const double bmax = d_ord_val(cull[0]), bmin = d_ord_val(~cull[1]);
       out_of_band = (lmax <= bmin) || (lmin >= bmax);
     }
-    int n = out_of_band ? 0 : d_fix_lon(x, y, 4, G_PI);
+    int n = out_of_band ? 0 : d_fix_lon_quad_fast(x, y, G_PI);
+    if (n < 0) n = d_fix_lon(x, y, 4, G_PI);             // cells with a pole vertex / a half-turn edge: the general routine
     if (out_of_band) { c.nv[s] = 0; c.area[s] = 0; }
     else if (n < 0 || n > G_MAXV) {
       atomicOr(err, G_ERRBIT_MAXV);
@@ -1112,12 +1113,15 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
                                                  const FgCells &S, const double *mask, const FgCells &D, const FgRect &R,
                                                  ClipOut *o_out, unsigned long long *stats, unsigned *err)
 {
+  // RECT: the cutting cell is always a quad, so source cells of up to 8 vertices (the pole-fixed ones) fit this kernel too --
+  // the general kernel then only sees the rare pair whose intermediate polygon outgrows 8 vertices
+  constexpr int NV1 = RECT ? 8 : 4;
   const int n1 = S.nv[s], n2 = RECT ? 4 : D.nv[d];
-  if (n1 > 4 || n2 > 4) return false;
+  if (n1 > NV1 || n2 > 4) return false;
 
   const double *sv = S.verts + (size_t)s * 16;
   const double lon_in_avg = S.lon_avg[s];
-  double x1[4], y1[4], x2[4], y2[4];
+  double x1[NV1], y1[NV1], x2[4], y2[4];
   double lon_out_avg;
   if (RECT) {
     const int j = d / R.nx, i = d - j * R.nx;
@@ -1138,17 +1142,20 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
   }
   bool wrap = false;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    x1[k] = sv[k]; y1[k] = sv[8 + k];
-    if (shift != 0.0) x2[k] += shift;
+  for (int k = 0; k < NV1; k++) {
+    if (k < 4 || k < n1) { x1[k] = sv[k]; y1[k] = sv[8 + k]; } else { x1[k] = 0.0; y1[k] = 0.0; }
     if (k < n1 && (x1[k] > G_TPI || x1[k] < 0.0)) wrap = true;  // create_xgrid.c:1282
   }
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (shift != 0.0) x2[k] += shift;
   if (wrap) {                                          // :1290
 #pragma unroll
-    for (int k = 0; k < 4; k++) { x1[k] = d_pimod1(x1[k]); x2[k] = d_pimod1(x2[k]); }
+    for (int k = 0; k < NV1; k++) x1[k] = d_pimod1(x1[k]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) x2[k] = d_pimod1(x2[k]);
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) sh_poly[k][tid] = make_double2(x1[k], y1[k]);
+  for (int k = 0; k < NV1; k++) if (k < 4 || k < n1) sh_poly[k][tid] = make_double2(x1[k], y1[k]);
   // the cutting quad stays in registers; its vertex e is picked with selects (n2 <= 4)
   // vertex e of the cutting quad, picked with bit masks (a ?: chain on e is turned into a scratch-memory
   // table by the optimizer)
