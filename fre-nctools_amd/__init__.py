@@ -8,7 +8,8 @@ mirrors the reference's call signatures:
 * ``create_xgrid_2dx2d_order1/2``, ``get_grid_area``, ``get_maxxgrid``, ``conserve_interp``
   -- tools/libfrencutils/create_xgrid.c:45,66,621,893 and interp.c:262
 * ``setup_conserve_interp`` / ``do_scalar_conserve_interp``
-  -- tools/fregrid/conserve_interp.c:42,507 (compute branch, plain scalar branch)
+  -- tools/fregrid/conserve_interp.c:42,507 (compute / READ / WRITE branches; every branch of the sweep: missing values,
+     weight field, cell_methods = sum, cell_measures, --target_grid, the monotone limiter)
 
 There is NO CPU fallback: if the shared library is missing, or no HIP device is visible
 when a compute entry point is called, an exception is raised.

@@ -1020,6 +1020,24 @@ extern "C" int fg_plan_set_stream(fg_plan *pl, void *stream)
   return 0;
 }
 
+// Internal (sweep.hip): run the plan's launches on `stream` for the duration of one call and hand the previous stream back
+// afterwards.  borrow: waits for the plan's own stream, then points it at `stream`; *saved / *saved_own receive what it had.
+// give back: the caller has synchronised `stream`.  The plan never owns a borrowed stream.
+int fg_plan_borrow_stream(fg_plan *pl, void *stream, void **saved, int *saved_own)
+{
+  if (!pl) return fail(FG_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(pl->device));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  *saved = (void *)pl->stream; *saved_own = pl->own_stream ? 1 : 0;
+  pl->stream = (hipStream_t)stream; pl->own_stream = false;
+  return 0;
+}
+void fg_plan_return_stream(fg_plan *pl, void *saved, int saved_own)
+{
+  if (!pl) return;
+  pl->stream = (hipStream_t)saved; pl->own_stream = saved_own != 0;
+}
+
 // a plan without a search: exchange cells are supplied later by fg_plan_set_xgrid
 extern "C" int fg_plan_create_empty(int order, int ntiles_in, const int *nx_in, const int *ny_in,
                                     int nx_out, int ny_out, int device, fg_plan **plan_out)
@@ -2243,6 +2261,20 @@ extern "C" int fg_c2l_set_stream(fg_c2l *h, void *stream)
   if (h->own_stream) g_handles.put_stream(h->device, h->stream);
   h->stream = (hipStream_t)stream; h->own_stream = false;
   return 0;
+}
+int fg_c2l_borrow_stream(fg_c2l *h, void *stream, void **saved, int *saved_own)      // (see fg_plan_borrow_stream)
+{
+  if (!h) return fail(FG_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *saved = (void *)h->stream; *saved_own = h->own_stream ? 1 : 0;
+  h->stream = (hipStream_t)stream; h->own_stream = false;
+  return 0;
+}
+void fg_c2l_return_stream(fg_c2l *h, void *saved, int saved_own)
+{
+  if (!h) return;
+  h->stream = (hipStream_t)saved; h->own_stream = saved_own != 0;
 }
 extern "C" int fg_c2l_sync(fg_c2l *h)
 {

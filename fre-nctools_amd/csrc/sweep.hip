@@ -21,6 +21,11 @@ extern "C" int fg_plan_order(const fg_plan *pl);
 extern "C" long fg_plan_ncells_out(const fg_plan *pl);
 extern "C" int fg_plan_device(const fg_plan *pl);
 void fg_set_last_error(const char *msg);         // plan.hip
+// run-scoped use of our compute stream by the plans and the gradient object (plan.hip)
+int fg_plan_borrow_stream(fg_plan *pl, void *stream, void **saved, int *saved_own);
+void fg_plan_return_stream(fg_plan *pl, void *saved, int saved_own);
+int fg_c2l_borrow_stream(fg_c2l *h, void *stream, void **saved, int *saved_own);
+void fg_c2l_return_stream(fg_c2l *h, void *saved, int saved_own);
 
 static int sw_fail(int code, const char *msg) { fg_set_last_error(msg); return code; }
 #define SWCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { char b_[256]; \
@@ -97,9 +102,7 @@ extern "C" void fg_sweep_destroy(fg_sweep *sw)
   if (!sw) return;
   (void)hipSetDevice(sw->device);
   for (hipStream_t s : {sw->s_in, sw->s_comp, sw->s_out}) if (s) (void)hipStreamSynchronize(s);
-  // the plans and the gradient object go back to streams of their own before ours disappear
-  for (fg_plan *p : sw->plans) (void)fg_plan_set_stream(p, nullptr);
-  if (sw->c2l) (void)fg_c2l_set_stream(sw->c2l, nullptr);
+  // (the plans and the gradient object are not touched: they use our compute stream only inside fg_sweep_run)
   for (auto &sl : sw->slot) {
     if (sl.d_raw) (void)hipFree(sl.d_raw);
     if (sl.d_fin) (void)hipFree(sl.d_fin);
@@ -144,8 +147,6 @@ extern "C" int fg_sweep_create(int nplans, fg_plan *const *plans, fg_c2l *c2l, i
   }
   ok = ok && hipMalloc((void **)&sw->d_f64, nin * 8) == hipSuccess && hipMalloc((void **)&sw->d_tmp, nout * 8) == hipSuccess;
   if (sw->order == 2) ok = ok && hipMalloc((void **)&sw->d_rec, (size_t)sw->ncin * 3 * 8 * 8) == hipSuccess;
-  if (ok) for (fg_plan *p : sw->plans) ok = ok && fg_plan_set_stream(p, sw->s_comp) == 0;
-  if (ok && sw->c2l) ok = fg_c2l_set_stream(sw->c2l, sw->s_comp) == 0;
   if (!ok) { (void)hipGetLastError(); fg_sweep_destroy(sw); return sw_fail(FG_ERR_HIP, "fg_sweep_create: out of device memory (or stream / event creation failed)"); }
   *out = sw;
   return 0;
@@ -170,6 +171,26 @@ extern "C" int fg_sweep_run(fg_sweep *sw, const void *host_in, long nlev, double
   if (!sw || !host_in || !host_out || nlev < 1) return sw_fail(FG_ERR_ARG, "fg_sweep_run: null argument");
   for (size_t p = 0; p < sw->plans.size(); p++) if (!host_out[p]) return sw_fail(FG_ERR_ARG, "fg_sweep_run: null output array");
   SWCHK(hipSetDevice(sw->device));
+  // The plans and the gradient object launch on OUR compute stream for the duration of this call only: several fg_sweep objects
+  // (one per pair of file types) may share the same plans, a plan may be used directly between two runs, and either may be
+  // destroyed before the other.  On every way out -- errors included -- the three streams are drained, the borrowed streams
+  // handed back and the slots cleared, so that a later run never copies a failed run's staged outputs.
+  struct Borrow {
+    fg_sweep *sw; std::vector<void *> saved; std::vector<int> own; void *c_saved = nullptr; int c_own = 0; bool c_on = false;
+    ~Borrow()
+    {
+      for (hipStream_t s : {sw->s_in, sw->s_comp, sw->s_out}) (void)hipStreamSynchronize(s);
+      for (size_t p = 0; p < saved.size(); p++) fg_plan_return_stream(sw->plans[p], saved[p], own[p]);
+      if (c_on) fg_c2l_return_stream(sw->c2l, c_saved, c_own);
+      for (auto &sl : sw->slot) { sl.busy = false; sl.staged_out = false; }
+    }
+  } borrow{sw};
+  for (fg_plan *p : sw->plans) {
+    void *sv = nullptr; int ow = 0;
+    if (fg_plan_borrow_stream(p, sw->s_comp, &sv, &ow)) return FG_ERR_HIP;
+    borrow.saved.push_back(sv); borrow.own.push_back(ow);
+  }
+  if (sw->c2l) { if (fg_c2l_borrow_stream(sw->c2l, sw->s_comp, &borrow.c_saved, &borrow.c_own)) return FG_ERR_HIP; borrow.c_on = true; }
   const bool in_pinned = is_pinned(host_in);
   bool out_pinned = true;
   for (size_t p = 0; p < sw->plans.size(); p++) out_pinned = out_pinned && is_pinned(host_out[p]);

@@ -855,10 +855,14 @@ __device__ __forceinline__ int d_rect_ncols(const RectQuery &q)
   for (int w = 0; w < q.nw; w++) n += q.wb[w] - q.wa[w] + 1;
   return n;
 }
-__device__ __forceinline__ bool d_rect_heavy(const RectQuery &q)
+// "Heavy" = the candidates are made by a whole wave instead of one lane.  Decided from the cell's box and the MEAN axis spacings
+// alone (no axis search), by the record kernel that lists such cells and by the candidate kernel that skips them: the two must
+// agree, nothing else depends on the estimate (the lane path handles any count, only slowly).
+__device__ __forceinline__ bool d_rect_heavy(const FgRect &R, double lat_in_min, double lat_in_max, double lon_in_min, double lon_in_max)
 {
-  const int nr = q.j1 - q.j0 + 1, nc = d_rect_ncols(q);
-  return nr > 0 && nc > 0 && (nc > 64 || (long)nr * nc > RECT_HEAVY);
+  const double nr = (lat_in_max - lat_in_min) * R.hdr[3] + 2.0;
+  const double nc = (lon_in_max - lon_in_min > G_PI) ? (double)R.nx : (lon_in_max - lon_in_min) * R.hdr[1] + 2.0;
+  return nr * nc > (double)RECT_HEAVY;
 }
 // column k of the query's concatenated windows
 __device__ __forceinline__ int d_rect_col(const RectQuery &q, int k)
@@ -940,7 +944,7 @@ __global__ __launch_bounds__(256) void k_cell_struct2r(FgTileSet ts, const FgTil
       }
     }
     bool heavy = false;
-    if (s < nsrc && nv > 0 && (!mask || mask[s] > 0.5)) heavy = d_rect_heavy(d_rect_query(R, box[0], box[1], box[2], box[3]));
+    if (s < nsrc && nv > 0 && (!mask || mask[s] > 0.5)) heavy = d_rect_heavy(R, box[0], box[1], box[2], box[3]);
     const unsigned long long m = __ballot(heavy);
     if (m) {
       int base = 0;
@@ -1026,20 +1030,27 @@ __global__ __launch_bounds__(64) void k_candidates_rect(int nsrc, int H, FgCells
   }
   const int bR = (int)blockIdx.x - H;
   const int s = bR * 64 + lane;
-  int cnt = 0, nr = 0;
+  int cnt = 0, nr = 0, nwc = 0;
   unsigned long long cmask = 0ull;
   RectQuery q{};
   bool heavy = false;
+  double lon_in_min = 0, lon_in_max = 0, lon_in_avg = 0;
   if (s < nsrc && d_src_active(S, mask, s)) {
-    const double lon_in_min = S.lon_min[s], lon_in_max = S.lon_max[s], lon_in_avg = S.lon_avg[s];
-    q = d_rect_query(R, S.lat_min[s], S.lat_max[s], lon_in_min, lon_in_max);
-    heavy = d_rect_heavy(q);                             // listed by k_cell_struct2r; a whole wave writes its pairs
-    nr = q.j1 - q.j0 + 1;
-    if (!heavy && nr > 0) {
-      const int nwc = d_rect_ncols(q);                   // <= 64
-      for (int k = 0; k < nwc; k++)
-        if (d_rect_col_pass(R.col + (size_t)d_rect_col(q, k) * RECT_COLW, lon_in_min, lon_in_max, lon_in_avg)) cmask |= 1ull << k;
-      cnt = nr * __popcll(cmask);
+    const double lat_in_min = S.lat_min[s], lat_in_max = S.lat_max[s];
+    lon_in_min = S.lon_min[s]; lon_in_max = S.lon_max[s]; lon_in_avg = S.lon_avg[s];
+    heavy = d_rect_heavy(R, lat_in_min, lat_in_max, lon_in_min, lon_in_max);   // listed by k_cell_struct2r; a whole wave writes its pairs
+    if (!heavy) {
+      q = d_rect_query(R, lat_in_min, lat_in_max, lon_in_min, lon_in_max);
+      nr = max(q.j1 - q.j0 + 1, 0);
+      nwc = d_rect_ncols(q);
+      int nc = 0;
+      if (nr > 0) {
+        // the columns that pass, as a bit mask when the windows are narrow enough (the usual case), else only counted here and
+        // re-tested row by row below
+        for (int k = 0; k < nwc; k++)
+          if (d_rect_col_pass(R.col + (size_t)d_rect_col(q, k) * RECT_COLW, lon_in_min, lon_in_max, lon_in_avg)) { nc++; if (k < 64) cmask |= 1ull << k; }
+      }
+      cnt = (int)min((long)nr * nc, 0x3fffffffL);
     }
   }
   const unsigned incl = wave_incl_scan((unsigned)cnt, lane);
@@ -1071,12 +1082,18 @@ __global__ __launch_bounds__(64) void k_candidates_rect(int nsrc, int H, FgCells
   int *psrc = ps.src + (size_t)r * ps.regcap + first, *pdst = ps.dst + (size_t)r * ps.regcap + first;
   int w = 0;
   for (int j = q.j0; j <= q.j1 && w < n_ok; j++) {
-    unsigned long long m = cmask;
-    while (m && w < n_ok) {
-      const int k = __ffsll((long long)m) - 1; m &= m - 1ull;
-      psrc[w] = s; pdst[w] = j * R.nx + d_rect_col(q, k);
-      w++;
-    }
+    if (nwc <= 64) {
+      unsigned long long m = cmask;
+      while (m && w < n_ok) {
+        const int k = __ffsll((long long)m) - 1; m &= m - 1ull;
+        psrc[w] = s; pdst[w] = j * R.nx + d_rect_col(q, k);
+        w++;
+      }
+    } else
+      for (int k = 0; k < nwc && w < n_ok; k++) {
+        const int i = d_rect_col(q, k);
+        if (d_rect_col_pass(R.col + (size_t)i * RECT_COLW, lon_in_min, lon_in_max, lon_in_avg)) { psrc[w] = s; pdst[w] = j * R.nx + i; w++; }
+      }
   }
 }
 

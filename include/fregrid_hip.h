@@ -463,7 +463,14 @@ const char *fg_nc_last_error(void);
  *   scale / offset: the variable's scale_factor / add_offset (0 = absent, as the reference treats them); applied to values
  *   != missing.  Levels carry no missing values (conserve_interp.c:544 requires nz == 1 for those: use fg_plan_apply_ex).
  * Buffers from fg_host_alloc are page-locked: copies go straight from / to them; other host memory is staged through the
- * object's own pinned buffers with one extra host copy. */
+ * object's own pinned buffers with one extra host copy.
+ * Streams and lifetimes: the plans and the gradient object run on the sweep's compute stream only INSIDE fg_sweep_run (they get
+ * their own streams back before it returns, on errors too), so several fg_sweep objects -- fregrid needs one per pair of
+ * file types -- may share plans, and plans / sweeps may be destroyed in any order.  A plan serves one call at a time: do not
+ * call fg_sweep_run on two host threads with a plan in common.  After an error return the object is clean and may be run again.
+ * Out-of-range narrowing (NC_SHORT / NC_INT outputs beyond the type's range, e.g. a missing value of -1e20): the device cast
+ * saturates, the reference's host cast (fregrid_util.c:2395-2406) is undefined behaviour that yields INT_MIN on x86 --
+ * parity unpinned, no fixture in the reference covers it. */
 typedef struct fg_sweep fg_sweep;
 int  fg_sweep_create(int nplans, fg_plan *const *plans, fg_c2l *c2l, int in_type, int out_type, fg_sweep **out);
 int  fg_sweep_run(fg_sweep *sw, const void *host_in, long nlev, double scale, double offset, double missing,

@@ -68,7 +68,27 @@ def test_setup_conserve_interp_vs_oracle(fg, gpu_ok, order, ni, nlon, nlat):
         assert interp[0].nxgrid == 256864                 # BASELINE.md §2 (reference count)
         earth = 4 * np.pi * 6371000.0 ** 2
         assert abs(np.sum(interp[0].area) / earth - 0.999999998703791) < 1e-12   # reference closure, BASELINE.md §2
-        return                                            # full-list comparison: C48 cases (oracle brute force is O(N^2))
+        # BASELINE config 2 in full: every exchange cell of C96 -> 360x180 against the reference's own code compiled in place
+        # (oracle/_ref: six create_xgrid_2dx2d_order2 calls, ~4.5 s of CPU; the bit-identical port when _ref is absent)
+        p = fg.XgridPlan.create(2, grid_in, grid_out[0])
+        x = p.get_xgrid()                                 # before finalize: c1 / c2 are the reference's xgrid_clon / xgrid_clat
+        p.destroy()
+        create = orc.ref_create_xgrid if orc.ref_available() else orc.orc_create_xgrid
+        off = 0
+        for t in range(6):
+            r = create(2, ni, ni, nlon, nlat, lon[t], lat[t], lo, la)
+            sel = slice(off, off + r["n"])
+            assert np.all(x["t_in"][sel] == t)
+            for k in ("i_in", "j_in", "i_out", "j_out"):
+                assert np.array_equal(x[k][sel], r[k]), (t, k)
+                assert np.array_equal(getattr(interp[0], k)[sel], r[k]), (t, k)
+            assert np.max(np.abs(x["area"][sel] - r["area"]) / r["area"]) < RTOL
+            if orc.host_has_fma():
+                for a, b in ((x["area"][sel], r["area"]), (x["c1"][sel], r["clon"]), (x["c2"][sel], r["clat"]), (interp[0].area[sel], r["area"])):
+                    assert np.array_equal(_bits(a), _bits(b)), t
+            off += r["n"]
+        assert off == 256864
+        return
     o = orc.orc_setup(order, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
     x = dict(t_in=interp[0].t_in, i_in=interp[0].i_in, j_in=interp[0].j_in, i_out=interp[0].i_out,
              j_out=interp[0].j_out, area=interp[0].area, c1=interp[0].di_in, c2=interp[0].dj_in)

@@ -106,3 +106,39 @@ def test_streamed_order1_two_output_tiles_short_input(fg, gpu_ok):
     sw.destroy()
     for p in plans:
         p.destroy()
+
+
+def test_two_sweeps_share_plans_and_any_destruction_order(fg, gpu_ok):
+    """fregrid needs one fg_sweep per pair of file types.  Two live sweeps over the same plan and gradient object,
+    runs interleaved with a direct use of the plan, the plan destroyed BEFORE the sweeps: each run borrows the compute stream
+    for its own duration only, results stay bit-identical and nothing touches a freed plan."""
+    ni, nlon, nlat, nlev = 24, 72, 36, 10
+    lon, lat, lont, latt = fg.gnomonic_ed_grid(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    plan = fg.XgridPlan.create(2, [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)], fg.GridConfig(nlon, nlat, lo, la))
+    plan.finalize()
+    prep = fg.C2lPrep([ni] * 6, [ni] * 6, lon, lat, lont, latt, fg.find_contacts([ni] * 6, [ni] * 6, lon, lat))
+    ncell = 6 * ni * ni
+    rng = np.random.default_rng(3)
+    src32 = (280.0 + 20.0 * rng.standard_normal((nlev, ncell))).astype(np.float32)
+    src64 = src32.astype(np.float64)
+    sw_f = fg.Sweep([plan], prep, np.float32, np.float32)
+    sw_d = fg.Sweep([plan], prep, np.float64, np.float64)
+    out_f = [np.empty((nlev, nlon * nlat), dtype=np.float32) for _ in range(2)]
+    out_d = [np.empty((nlev, nlon * nlat), dtype=np.float64) for _ in range(2)]
+    sw_f.run(src32, [out_f[0]])
+    sw_d.run(src64, [out_d[0]])
+    # the plan used directly in between (its own stream again)
+    dev = "cuda:0"
+    rec = torch.empty(ncell, 3, fg.C2lPrep.records_nb(8), dtype=torch.float64, device=dev)
+    o8 = torch.empty(8, nlon * nlat, dtype=torch.float64, device=dev)
+    prep.records(torch.from_numpy(src64[:8].copy()).to(dev), 8, rec); prep.sync()
+    plan.apply_records(8, rec, o8); plan.sync()
+    assert np.array_equal(o8.cpu().numpy().view(np.uint64), out_d[0][:8].view(np.uint64))
+    sw_d.run(src64, [out_d[1]])
+    sw_f.run(src32, [out_f[1]])
+    assert np.array_equal(out_d[0].view(np.uint64), out_d[1].view(np.uint64))
+    assert np.array_equal(out_f[0].view(np.uint32), out_f[1].view(np.uint32))
+    assert np.array_equal(out_d[0].astype(np.float32).view(np.uint32), out_f[0].view(np.uint32))     # float levels are exact in double
+    plan.destroy()                                              # before its sweeps
+    sw_f.destroy(); sw_d.destroy()
