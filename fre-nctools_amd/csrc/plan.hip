@@ -149,6 +149,133 @@ static int dev_gather(double *dst_dev, const double *src_dev, const int *idx_dev
 extern "C" int fg_dev_gather_f64(double *dst_dev, const double *src_dev, const int *idx_dev, long n) { return dev_gather(dst_dev, src_dev, idx_dev, n, 0); }
 extern "C" int fg_dev_scatter_f64(double *dst_dev, const double *src_dev, const int *idx_dev, long n) { return dev_gather(dst_dev, src_dev, idx_dev, n, 1); }
 
+// ----------------------------------------------------------------------------- host <-> device transfers of large arrays
+// The host-pointer entry points (B1: create_xgrid_*, B2: fg_plan_create / fg_plan_get_xgrid) move corner arrays up and 166 MB of
+// exchange cells (C384 -> 0.25 deg) down, to and from the caller's PAGEABLE memory (the reference's malloc'ed Interp_config
+// arrays).  A plain hipMemcpy does that at ~14 GB/s -- one thread staging through a bounce buffer and taking the page faults of
+// freshly allocated destination arrays -- which was 12 of the 14 ms of the whole call.  XferPool splits a batch of copies into
+// 2 MB chunks taken by a few persistent worker threads; each has a stream and two page-locked slots, so that the DMA of one chunk
+// runs beside the host memcpy (and page faults) of another and the workers add up to the link's rate.
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+namespace {
+struct XferJob { void *host; void *dev; size_t bytes; bool d2h; };
+class XferPool {
+  const size_t CHUNK = [] { const char *e = getenv("FREGRID_HIP_XFER_CHUNK_MB"); const int m = e ? atoi(e) : 0; return (size_t)(m > 0 && m <= 64 ? m : 2) << 20; }();   // 2 MB x 8 workers measured best (scripts/pcie_time.py)
+  std::mutex batch_mu;                        // one batch at a time
+  std::mutex mu; std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> threads;
+  const std::vector<XferJob> *jobs = nullptr;
+  std::vector<std::pair<int, size_t>> chunks; // (job, offset)
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  int device = 0, active = 0;
+  unsigned long long gen = 0;
+  struct Slot { void *pin = nullptr; hipEvent_t ev = nullptr; int pending = 0; void *host = nullptr; size_t bytes = 0; };   // pending: 1 h2d, 2 d2h
+  struct Worker { int dev = -1; hipStream_t st = nullptr; Slot slot[2]; };
+
+  bool retire(Slot &sl)
+  {
+    if (!sl.pending) return true;
+    const bool ok = hipEventSynchronize(sl.ev) == hipSuccess;
+    if (ok && sl.pending == 2) memcpy(sl.host, sl.pin, sl.bytes);
+    sl.pending = 0;
+    return ok;
+  }
+  bool prepare(Worker &w)
+  {
+    if (w.dev == device && w.st) return true;
+    if (hipSetDevice(device) != hipSuccess) return false;
+    if (w.st) {                                            // another device than last time: start over
+      for (Slot &sl : w.slot) { if (sl.pin) (void)hipHostFree(sl.pin); if (sl.ev) (void)hipEventDestroy(sl.ev); sl = Slot{}; }
+      (void)hipStreamDestroy(w.st); w.st = nullptr;
+    }
+    if (hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking) != hipSuccess) return false;
+    for (Slot &sl : w.slot)
+      if (hipHostMalloc(&sl.pin, CHUNK, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return false;
+    w.dev = device;
+    return true;
+  }
+  void work(Worker &w)
+  {
+    bool ok = prepare(w);
+    int s = 0;
+    for (;;) {
+      const size_t c = next.fetch_add(1);
+      if (c >= chunks.size() || !ok) break;
+      const XferJob &j = (*jobs)[chunks[c].first];
+      const size_t off = chunks[c].second, n = std::min(CHUNK, j.bytes - off);
+      Slot &sl = w.slot[s]; s ^= 1;
+      ok = retire(sl);
+      if (!ok) break;
+      if (j.d2h) {
+        ok = hipMemcpyAsync(sl.pin, (const char *)j.dev + off, n, hipMemcpyDeviceToHost, w.st) == hipSuccess && hipEventRecord(sl.ev, w.st) == hipSuccess;
+        sl.pending = 2; sl.host = (char *)j.host + off; sl.bytes = n;
+      } else {
+        memcpy(sl.pin, (const char *)j.host + off, n);
+        ok = hipMemcpyAsync((char *)j.dev + off, sl.pin, n, hipMemcpyHostToDevice, w.st) == hipSuccess && hipEventRecord(sl.ev, w.st) == hipSuccess;
+        sl.pending = 1;
+      }
+    }
+    for (Slot &sl : w.slot) ok = retire(sl) && ok;
+    if (!ok) { (void)hipGetLastError(); failed.store(1); }
+  }
+  void loop()
+  {
+    Worker w;
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [&] { return gen != seen; });
+        seen = gen;
+      }
+      work(w);
+      std::lock_guard<std::mutex> lk(mu);
+      if (--active == 0) cv_done.notify_all();
+    }
+  }
+
+ public:
+  // false: a copy failed (the caller reports it)
+  bool run(int dev, const std::vector<XferJob> &batch)
+  {
+    size_t total = 0;
+    for (const XferJob &j : batch) total += j.bytes;
+    if (total == 0) return true;
+    static const int nthreads = [] {
+      const char *e = getenv("FREGRID_HIP_XFER_THREADS");
+      int n = e ? atoi(e) : 0;
+      if (n <= 0) { const unsigned hc = std::thread::hardware_concurrency(); n = hc >= 16 ? 8 : (hc >= 8 ? 4 : 2); }
+      return std::min(n, 16);
+    }();
+    if (total < 2 * CHUNK) {                               // small: not worth waking anybody
+      if (hipSetDevice(dev) != hipSuccess) return false;
+      for (const XferJob &j : batch)
+        if (j.bytes && hipMemcpy(j.d2h ? j.host : j.dev, j.d2h ? j.dev : j.host, j.bytes, j.d2h ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice) != hipSuccess) return false;
+      return true;
+    }
+    std::lock_guard<std::mutex> bl(batch_mu);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (threads.empty())
+        for (int t = 0; t < nthreads; t++) { threads.emplace_back([this] { loop(); }); threads.back().detach(); }
+      jobs = &batch; chunks.clear();
+      for (size_t k = 0; k < batch.size(); k++)
+        for (size_t off = 0; off < batch[k].bytes; off += CHUNK) chunks.push_back({(int)k, off});
+      next.store(0); failed.store(0); device = dev; active = (int)threads.size(); gen++;
+    }
+    cv_work.notify_all();
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return active == 0; });
+    jobs = nullptr;
+    return failed.load() == 0;
+  }
+};
+XferPool &xfer_pool() { static XferPool *p = new XferPool(); return *p; }     // (never destroyed: its threads outlive main's statics)
+}  // namespace
+
 // ----------------------------------------------------------------------------- phase timing
 // Optional HIP-event timing of the phases of a search / sweep, recorded on the plan's own
 // stream (bench.py reads these for the roofline object; torch.cuda.Event would only see
@@ -837,13 +964,13 @@ extern "C" long fg_plan_create(int order, int ntiles_in, const int *nx_in, const
   fg_plan *pl = nullptr;
   int rc = plan_base(order, ntiles_in, nx_in, ny_in, nx_out, ny_out, device, &pl);
   if (rc) return rc;
-  hipStream_t st = pl->stream;
   std::vector<const double *> dlon(ntiles_in), dlat(ntiles_in), dmask(ntiles_in, nullptr);
   std::vector<void *> staged;
+  std::vector<XferJob> up_jobs;
   auto up = [&](const double *h, size_t n) -> const double * {
     double *d = pl->alloc<double>(n);
     if (!d) return nullptr;
-    if (hipMemcpyAsync(d, h, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
+    up_jobs.push_back(XferJob{(void *)h, d, n * sizeof(double), false});
     staged.push_back(d);
     return d;
   };
@@ -856,7 +983,7 @@ extern "C" long fg_plan_create(int order, int ntiles_in, const int *nx_in, const
   }
   size_t npo = (size_t)(nx_out + 1) * (ny_out + 1);
   const double *dlo = ok ? up(lon_out, npo) : nullptr, *dla = ok ? up(lat_out, npo) : nullptr;
-  if (!ok || !dlo || !dla) { fg_plan_destroy(pl); return fail(FG_ERR_HIP, "grid upload failed (out of device memory?)"); }
+  if (!ok || !dlo || !dla || !xfer_pool().run(device, up_jobs)) { fg_plan_destroy(pl); return fail(FG_ERR_HIP, "grid upload failed (out of device memory?)"); }
   double mdlat, mdlon;
   sample_extents(nx_out, ny_out, lon_out, lat_out, &mdlat, &mdlon);
   long nx = plan_search(pl, dlon.data(), dlat.data(), mask_in ? dmask.data() : nullptr, dlo, dla, mdlat, mdlon, nullptr, nullptr, nullptr,
@@ -1235,25 +1362,25 @@ extern "C" int fg_plan_get_xgrid(const fg_plan *pl, int *t_in, int *i_in, int *j
     HIPCHK(hipStreamSynchronize(pl->stream));
     m->dist_pending = false;
   }
+  std::vector<XferJob> jobs;
+  int *idx = nullptr;
+  struct PutBack { int *&p; ~PutBack() { g_pool.put(p); } } put_back{idx};
   if (t_in || i_in || j_in || i_out || j_out) {
-    // index decomposition on the device, then plain copies (the host loop with two divisions per exchange cell took longer
-    // than the transfer)
-    int *idx = (int *)g_pool.get(pl->device, 5 * (size_t)nx * sizeof(int));
+    // index decomposition on the device (the host loop with two divisions per exchange cell took longer than the transfer)
+    idx = (int *)g_pool.get(pl->device, 5 * (size_t)nx * sizeof(int));
     if (!idx) return fail(FG_ERR_HIP, "out of device memory");
     fgd_xgrid_indices(nx, pl->x_src, pl->x_dst, pl->tiles_dev, pl->ntiles, pl->nx_out, idx, idx + nx, idx + 2 * nx, idx + 3 * nx,
                       idx + 4 * nx, pl->stream);
-    hipError_t e = hipStreamSynchronize(pl->stream);
+    HIPCHK(hipStreamSynchronize(pl->stream));
     int *dst[5] = {t_in, i_in, j_in, i_out, j_out};
-    for (int q = 0; q < 5 && e == hipSuccess; q++)
-      if (dst[q]) e = hipMemcpy(dst[q], idx + (size_t)q * nx, nx * sizeof(int), hipMemcpyDeviceToHost);
-    g_pool.put(idx);
-    if (e != hipSuccess) return fail(FG_ERR_HIP, "fg_plan_get_xgrid: %s", hipGetErrorString(e));
+    for (int q = 0; q < 5; q++) if (dst[q]) jobs.push_back(XferJob{dst[q], idx + (size_t)q * nx, (size_t)nx * sizeof(int), true});
   }
-  if (area) HIPCHK(hipMemcpy(area, pl->x_area, nx * sizeof(double), hipMemcpyDeviceToHost));
+  if (area) jobs.push_back(XferJob{area, pl->x_area, (size_t)nx * sizeof(double), true});
   if (pl->order == 2) {
-    if (c1) HIPCHK(hipMemcpy(c1, pl->x_c1, nx * sizeof(double), hipMemcpyDeviceToHost));
-    if (c2) HIPCHK(hipMemcpy(c2, pl->x_c2, nx * sizeof(double), hipMemcpyDeviceToHost));
+    if (c1) jobs.push_back(XferJob{c1, pl->x_c1, (size_t)nx * sizeof(double), true});
+    if (c2) jobs.push_back(XferJob{c2, pl->x_c2, (size_t)nx * sizeof(double), true});
   }
+  if (!xfer_pool().run(pl->device, jobs)) return fail(FG_ERR_HIP, "fg_plan_get_xgrid: device -> host copy failed");
   return 0;
 }
 
