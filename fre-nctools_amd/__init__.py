@@ -26,6 +26,7 @@ from .c2l import C2lPrep, find_contacts, c2l_grid_info, halo_map  # noqa: F401
 from .remap_file import write_remap_file, read_remap_file  # noqa: F401
 from .field_io import NcFile, Sweep, HostBuffer, read_field_levels  # noqa: F401
 from . import field_io  # noqa: F401
+from .coupler import coupler_xgrid  # noqa: F401
 from .parallel import (band_rows, row_cost, allreduce_cell_sums, allreduce_scalar_sum, allreduce_minmax,  # noqa: F401
                        boundary_source_cells, allreduce_cell_sums_sparse, ordered_cell_sums, CellSumExchange)
 from .conserve_interp import (  # noqa: F401

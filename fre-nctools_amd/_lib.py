@@ -29,7 +29,7 @@ EXPORTS = [
     "get_maxxgrid_", "get_grid_area_", "create_xgrid_2dx2d_order1_", "create_xgrid_2dx2d_order2_",
     "fg_last_error", "fg_device_count", "fg_plan_create", "fg_plan_create_dev", "fg_plan_create_empty",
     "fg_plan_destroy", "fg_plan_set_stream", "fg_pool_release", "fg_plan_nxgrid", "fg_plan_ncells_in",
-    "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_accumulate_cell_sums", "fg_plan_accumulate_cell_sums_async", "fg_dev_gather_f64", "fg_dev_scatter_f64", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_cell_struct",
+    "fg_plan_cell_sums_dev", "fg_plan_copy_cell_sums", "fg_plan_accumulate_cell_sums", "fg_plan_accumulate_cell_sums_async", "fg_dev_gather_f64", "fg_dev_scatter_f64", "fg_plan_finalize", "fg_plan_get_xgrid", "fg_plan_get_polygons", "fg_plan_create_polylist", "fg_plan_get_cell_struct",
     "fg_plan_get_cell_area", "fg_plan_set_xgrid", "fg_plan_apply", "fg_plan_apply_interleaved", "fg_plan_apply_records", "fg_plan_apply_ex", "fg_plan_mono_begin",
     "fg_plan_mono_minmax_dev", "fg_plan_mono_copy_minmax", "fg_plan_mono_end",
     "fg_plan_create_great_circle", "fg_plan_create_great_circle_dev", "fg_latlon2xyz", "create_xgrid_great_circle",
@@ -46,7 +46,7 @@ EXPORTS = [
     "fg_nc_inq_ndims", "fg_nc_inq_nvars", "fg_nc_inq_numrecs", "fg_nc_inq_dimid", "fg_nc_inq_dim", "fg_nc_inq_varid", "fg_nc_inq_var",
     "fg_nc_get_att_double", "fg_nc_get_att_text", "fg_nc_get_vara", "fg_nc_get_vara_double", "fg_nc_put_vara", "fg_nc_put_vara_double",
     "fg_nc_close", "fg_nc_last_error", "fg_sweep_create", "fg_sweep_run", "fg_sweep_destroy", "fg_host_alloc", "fg_host_free",
-    "fg_plan_stats", "fg_set_search_mode", "fg_set_search_chunks", "fg_set_search_cull", "fg_set_search_rect", "fg_set_apply_xcd", "fg_set_apply_vec", "fg_set_apply_ep", "fg_set_gc_split", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
+    "fg_plan_stats", "fg_set_search_mode", "fg_set_search_chunks", "fg_set_search_cull", "fg_set_search_rect", "fg_set_search_frame", "fg_set_apply_xcd", "fg_set_apply_vec", "fg_set_apply_ep", "fg_set_gc_split", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
 
 
@@ -147,6 +147,10 @@ def lib():
     L.fg_plan_finalize.restype = C.c_int
     L.fg_plan_get_xgrid.argtypes = [vp] + [ip] * 5 + [dp] * 3
     L.fg_plan_get_xgrid.restype = C.c_int
+    L.fg_plan_get_polygons.argtypes = [vp, C.c_int, ip, dp, dp, dp]
+    L.fg_plan_get_polygons.restype = C.c_int
+    L.fg_plan_create_polylist.argtypes = [C.c_int, C.c_int, ip, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp, C.c_int, C.POINTER(vp)]
+    L.fg_plan_create_polylist.restype = C.c_long
     L.fg_plan_get_cell_struct.argtypes = [vp, C.c_int] + [dp] * 5 + [ip] + [dp] * 2
     L.fg_plan_get_cell_struct.restype = C.c_int
     L.fg_plan_get_cell_area.argtypes = [vp, dp, dp]

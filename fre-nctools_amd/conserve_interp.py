@@ -97,10 +97,11 @@ class FieldConfig:
 class XgridPlan:
     """RAII wrapper of an ``fg_plan`` (include/fregrid_hip.h)."""
 
-    def __init__(self, handle, order, device):
+    def __init__(self, handle, order, device, great_circle=False):
         self._h = C.c_void_p(handle)
         self.order = order
         self.device = device
+        self.great_circle = great_circle
 
     # -- construction -------------------------------------------------------------------
     @classmethod
@@ -179,7 +180,7 @@ class XgridPlan:
         la = arr(grid_out.latc, (grid_out.nx + 1) * (grid_out.ny + 1))
         h = C.c_void_p()
         check(L.fg_plan_create_great_circle(nt, nx, ny, lon, lat, msk, grid_out.nx, grid_out.ny, lo, la, device, C.byref(h)))
-        return cls(h.value, 1, device)
+        return cls(h.value, 1, device, True)
 
     @classmethod
     def create_great_circle_dev(cls, nx_in, ny_in, xyz_in_t, nx_out, ny_out, xyz_out_t, mean_dlat=0.0, mean_dlon=0.0,
@@ -202,7 +203,7 @@ class XgridPlan:
                                                 C.c_void_p(xyz_out_t[0].data_ptr()), C.c_void_p(xyz_out_t[1].data_ptr()),
                                                 C.c_void_p(xyz_out_t[2].data_ptr()), float(mean_dlat), float(mean_dlon),
                                                 device, sptr, use, C.byref(h)))
-        return cls(h.value, 1, device)
+        return cls(h.value, 1, device, True)
 
     @classmethod
     def create_empty(cls, order, nx_in, ny_in, nx_out, ny_out, device=0):
@@ -298,6 +299,32 @@ class XgridPlan:
         if self.order == 2:
             out["c1"], out["c2"] = c1, c2
         return out
+
+    def get_polygons(self, maxv=16):
+        """The clipped polygon of every exchange cell (fg_plan_get_polygons): dict n [nxgrid] and, for a legacy plan, lon / lat
+        [nxgrid, maxv]; for a great-circle plan x / y / z."""
+        nx = self.nxgrid
+        n = np.zeros(nx, dtype=np.int32)
+        v = [np.zeros((nx, maxv)) for _ in range(3)]
+        check(lib().fg_plan_get_polygons(self._h, maxv, _ip(n), _dp(v[0]), _dp(v[1]), _dp(v[2])))
+        if self.great_circle:
+            return {"n": n, "x": v[0], "y": v[1], "z": v[2]}
+        return {"n": n, "lon": v[0], "lat": v[1]}
+
+    @classmethod
+    def create_polylist(cls, order, n, lon, lat, lon_avg, area_ref, grid_out, device=0):
+        """A search whose source cells are polygons of <= 8 vertices (fg_plan_create_polylist): n [npoly], lon / lat [npoly, 8],
+        lon_avg / area_ref [npoly]."""
+        _lib.require_gpu()
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        lon, lat = _f64(lon), _f64(lat)
+        assert lon.shape == (n.size, 8) == lat.shape
+        lon_avg, area_ref = _f64(lon_avg), _f64(area_ref)
+        lo, la = _f64(grid_out.lonc).reshape(-1), _f64(grid_out.latc).reshape(-1)
+        h = C.c_void_p()
+        check(lib().fg_plan_create_polylist(order, n.size, _ip(n), _dp(lon), _dp(lat), _dp(lon_avg), _dp(area_ref), grid_out.nx, grid_out.ny,
+                                            _dp(lo), _dp(la), device, C.byref(h)))
+        return cls(h.value, order, device)
 
     def get_cell_area(self, ncells_out):
         a_in = np.empty(self.ncells_in, dtype=np.float64)

@@ -400,6 +400,7 @@ struct fg_plan {
   FgCells S{}, D{};
   bool rect = false;            // searched on the rectilinear path: D holds areas only, the cells are in rect_tab (FgRect)
   FgRect rect_tab{};
+  FgPolyList polys{};           // npoly > 0: the source "cells" are this list of polygons (fg_plan_create_polylist)
   // exchange cells
   long nx = 0;
   int *x_src = nullptr, *x_dst = nullptr;
@@ -561,6 +562,14 @@ static int choose_chunks(int nsrc, int nreg)
 // a look at a few corners (host_says_not_rect).
 static int g_search_rect = 1;
 extern "C" void fg_set_search_rect(int on) { g_search_rect = on ? 1 : 0; }
+// Longitude frame of the DESTINATION cells of a legacy search.  0 (default) = create_xgrid's: fix_lon(cell, pi), then per pair a
+// shift of +-2pi towards the source cell's mean longitude (create_xgrid.c:1004,1062-1079).  1 = make_coupler_mosaic's: the cell is
+// only unwrapped and then moved ONCE per pair, fix_lon(cell, mean longitude of the other cell) (make_coupler_mosaic.c:1452,1598).
+// The two agree unless the first recentring moved the cell and the second moved it back -- (x + 2pi) - 2pi is not x in floating
+// point -- as for an ocean grid given on -280..80 degrees.  Implementation: the recentring target of the destination records is
+// NaN (every comparison of fix_lon's last step is then false), the per-pair shift is the same code.
+static int g_dst_frame = 0;
+extern "C" void fg_set_search_frame(int coupler) { g_dst_frame = coupler ? 1 : 0; }
 static bool host_says_not_rect(int nx, int ny, const double *lon, const double *lat)
 {
   const long nxp = nx + 1;
@@ -630,6 +639,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   // --- sizes known up front
   const bool rect = caps->rect && !gc && !boxm;
   pl->rect = rect;
+  const double dst_tlon = g_dst_frame ? (double)NAN : 3.14159265358979323846;
   FgBins bins;
   choose_bins(pl, mean_dlat, mean_dlon, &bins);
   if (rect) { bins.nblat = 0; bins.nblon = 0; }       // no bins on the rectilinear path
@@ -721,16 +731,20 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     R.bad = &dc->rect_bad; R.nx = pl->nx_out; R.ny = pl->ny_out;
     if (g_search_cull) fgd_band_keys(d_lat_out, (long)(pl->nx_out + 1) * (pl->ny_out + 1), dc->band_keys, st);
     fgd_rect_tables(d_lon_out, d_lat_out, pl->nx_out, pl->ny_out, rect_blk, rect_blk + 8, rect_blk + 8 + (pl->ny_out + 1),
-                    rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1), &dc->rect_bad, dc->err, st);
-    fgd_cell_struct2r(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D.area, R, pl->mask_dev, order, pl->src_idx_f, pl->sums,
-                      dc->err, st, dc->band_keys, g_search_cull ? 2 : 0, heavy_list, &dc->heavy_cnt);
-  } else if (g_search_cull && !boxm) {
+                    rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1), &dc->rect_bad, dc->err, st, dst_tlon);
+    if (pl->polys.npoly) fgd_polylist_records(pl->polys, pl->S, pl->src_idx_f, pl->sums, &R, heavy_list, &dc->heavy_cnt, dc->err, st);
+    fgd_cell_struct2r(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, pl->polys.npoly ? 0 : nsrc, ndst, pl->S, pl->D.area, R, pl->mask_dev, order,
+                      pl->src_idx_f, pl->sums, dc->err, st, dc->band_keys, (g_search_cull && !pl->polys.npoly) ? 2 : 0, heavy_list, &dc->heavy_cnt);
+  } else if (g_search_cull && !boxm && !pl->polys.npoly) {
     // the destination grid's latitude range from its corners (a 5 us reduction), then ONE record launch in which the source
     // blocks that cannot meet it leave early (round 2 first ran a destination launch, then a source launch: two latency floors)
     fgd_band_keys(d_lat_out, (long)(pl->nx_out + 1) * (pl->ny_out + 1), dc->band_keys, st);
-    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st, dc->band_keys, 2);
+    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st, dc->band_keys, 2, dst_tlon);
+  } else if (pl->polys.npoly) {
+    fgd_polylist_records(pl->polys, pl->S, pl->src_idx_f, pl->sums, nullptr, nullptr, nullptr, dc->err, st);
+    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, 0, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st, nullptr, 0, dst_tlon);
   } else
-    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st);
+    fgd_cell_struct2(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, nsrc, ndst, pl->S, pl->D, bins, bin_cnt, order, pl->src_idx_f, pl->sums, dc->err, st, nullptr, 0, dst_tlon);
   if (boxm) fgd_box_cell_boxes(boxm->box, pl->S, st);
   if (boxm && boxm->no_adjust) fgd_box_area_no_adjust(boxm->box, pl->S.area, st);      // create_xgrid.c:239-242
   pt.end();
@@ -1137,6 +1151,43 @@ extern "C" long fg_plan_create_great_circle(int ntiles_in, const int *nx_in, con
   return nx;
 }
 
+// A search whose SOURCE cells are a list of polygons (<= 8 vertices each), e.g. the atmosphere x land cells of a coupler mosaic
+// against the ocean grid (make_coupler_mosaic.c:1659-1692: clip_2dx2d(atmxlnd polygon, ocean cell)).  Host arrays: n[npoly],
+// lon / lat [npoly][8] in the longitude frame of the polygon's parent cell, lon_avg[npoly] = that cell's mean longitude (decides
+// the +-2pi shift of a destination cell and is poly_ctrlon's reference longitude), area_ref[npoly] = the area the 1e-6 ratio
+// test compares with (together with the destination cell's).  Exchange cells: i_in = polygon index, j_in = t_in = 0.
+extern "C" long fg_plan_create_polylist(int order, int npoly, const int *n, const double *lon, const double *lat, const double *lon_avg,
+                                        const double *area_ref, int nx_out, int ny_out, const double *lon_out, const double *lat_out,
+                                        int device, fg_plan **plan_out)
+{
+  if (npoly < 1 || !n || !lon || !lat || !lon_avg || !area_ref || !lon_out || !lat_out) return fail(FG_ERR_ARG, "null argument");
+  fg_plan *pl = nullptr;
+  const int one = 1;
+  int rc = plan_base(order, 1, &npoly, &one, nx_out, ny_out, device, &pl);
+  if (rc) return rc;
+  if (order == 2) pl->f_stride = npoly;                  // (no halo: the "field" of a polygon list is one value per polygon)
+  const size_t npo = (size_t)(nx_out + 1) * (ny_out + 1);
+  int *d_n = pl->alloc<int>(npoly);
+  double *d_lon = pl->alloc<double>((size_t)npoly * 8), *d_lat = pl->alloc<double>((size_t)npoly * 8);
+  double *d_avg = pl->alloc<double>(npoly), *d_area = pl->alloc<double>(npoly), *d_lo = pl->alloc<double>(npo), *d_la = pl->alloc<double>(npo);
+  std::vector<XferJob> jobs = {{(void *)n, d_n, (size_t)npoly * sizeof(int), false}, {(void *)lon, d_lon, (size_t)npoly * 64, false},
+                               {(void *)lat, d_lat, (size_t)npoly * 64, false}, {(void *)lon_avg, d_avg, (size_t)npoly * 8, false},
+                               {(void *)area_ref, d_area, (size_t)npoly * 8, false}, {(void *)lon_out, d_lo, npo * 8, false}, {(void *)lat_out, d_la, npo * 8, false}};
+  if (!d_n || !d_lon || !d_lat || !d_avg || !d_area || !d_lo || !d_la || !xfer_pool().run(device, jobs)) {
+    fg_plan_destroy(pl); return fail(FG_ERR_HIP, "polygon upload failed (out of device memory?)");
+  }
+  pl->polys = FgPolyList{d_n, d_lon, d_lat, d_avg, d_area, npoly};
+  double mdlat, mdlon;
+  sample_extents(nx_out, ny_out, lon_out, lat_out, &mdlat, &mdlon);
+  const double *none[1] = {nullptr};
+  long nx = plan_search(pl, none, none, nullptr, d_lo, d_la, mdlat, mdlon, nullptr, nullptr, nullptr,
+                        host_says_not_rect(nx_out, ny_out, lon_out, lat_out) ? 0 : 1);
+  if (nx < 0) { fg_plan_destroy(pl); return nx; }
+  pl->release(d_lo); pl->release(d_la);
+  *plan_out = pl;
+  return nx;
+}
+
 extern "C" int fg_plan_set_stream(fg_plan *pl, void *stream)
 {
   if (!pl) return fail(FG_ERR_ARG, "null plan");
@@ -1381,6 +1432,50 @@ extern "C" int fg_plan_get_xgrid(const fg_plan *pl, int *t_in, int *i_in, int *j
     if (c2) jobs.push_back(XferJob{c2, pl->x_c2, (size_t)nx * sizeof(double), true});
   }
   if (!xfer_pool().run(pl->device, jobs)) return fail(FG_ERR_HIP, "fg_plan_get_xgrid: device -> host copy failed");
+  return 0;
+}
+
+// The clipped polygon of every exchange cell (canonical order): n_out[nx] vertex counts and [nx][maxv] vertex arrays -- legacy
+// plans: v0 = lon, v1 = lat (v2 unused, may be null); great-circle plans: v0, v1, v2 = x, y, z.  Host arrays.  What clip_2dx2d /
+// clip_2dx2d_great_circle returned for the pair inside create_xgrid (make_coupler_mosaic.c:1560-1577 keeps exactly these).
+extern "C" int fg_plan_get_polygons(const fg_plan *pl, int maxv, int *n_out, double *v0, double *v1, double *v2)
+{
+  if (!pl || !n_out || !v0 || !v1) return fail(FG_ERR_ARG, "null argument");
+  if (!pl->searched || !pl->have_geom || !pl->x_src) return fail(FG_ERR_STATE, "fg_plan_get_polygons: needs a plan from a search (cell records)");
+  if (pl->great_circle && !v2) return fail(FG_ERR_ARG, "fg_plan_get_polygons: a great-circle plan returns x, y, z");
+  if (maxv < 3 || maxv > 64) return fail(FG_ERR_ARG, "fg_plan_get_polygons: maxv must be 3..64");
+  HIPCHK(hipSetDevice(pl->device));
+  HIPCHK(hipStreamSynchronize(pl->stream));
+  const long nx = pl->nx, CH = 1L << 20;
+  const int dev = pl->device;
+  for (long k0 = 0; k0 < nx; k0 += CH) {
+    const long n = std::min(CH, nx - k0);
+    const size_t nv = (size_t)n * maxv;
+    int *d_n = (int *)g_pool.get(dev, n * sizeof(int));
+    double *d_v = (double *)g_pool.get(dev, 3 * nv * sizeof(double));
+    struct Put { void *a, *b; ~Put() { g_pool.put(a); g_pool.put(b); } } put{d_n, d_v};
+    if (!d_n || !d_v) return fail(FG_ERR_HIP, "out of device memory");
+    std::vector<XferJob> jobs;
+    if (pl->great_circle) {
+      double *a = (double *)g_pool.get(dev, (size_t)n * 12 * 8), *b = (double *)g_pool.get(dev, (size_t)n * 12 * 8);
+      double *o = (double *)g_pool.get(dev, (size_t)n * FG_GC_POLY_CAP * 3 * 8), *ar = (double *)g_pool.get(dev, (size_t)n * 8);
+      struct Put4 { void *p[4]; ~Put4() { for (void *q : p) g_pool.put(q); } } put4{{a, b, o, ar}};
+      if (!a || !b || !o || !ar) return fail(FG_ERR_HIP, "out of device memory");
+      fgd_xgrid_gather_gc(n, pl->x_src + k0, pl->x_dst + k0, pl->S, pl->D, a, b, pl->stream);
+      fgd_gc_clip_batch((int)n, a, b, o, d_n, ar, pl->stream);
+      fgd_split_xyz(n, maxv, o, d_v, d_v + nv, d_v + 2 * nv, pl->stream);
+      HIPCHK(hipStreamSynchronize(pl->stream));
+      jobs.push_back(XferJob{v2 + (size_t)k0 * maxv, d_v + 2 * nv, nv * sizeof(double), true});
+    } else {
+      fgd_xgrid_polygons(n, pl->x_src + k0, pl->x_dst + k0, pl->S, pl->D, pl->rect ? &pl->rect_tab : nullptr, maxv, d_n, d_v, d_v + nv, pl->stream);
+      HIPCHK(hipStreamSynchronize(pl->stream));
+    }
+    HIPCHK(hipGetLastError());
+    jobs.push_back(XferJob{n_out + k0, d_n, (size_t)n * sizeof(int), true});
+    jobs.push_back(XferJob{v0 + (size_t)k0 * maxv, d_v, nv * sizeof(double), true});
+    jobs.push_back(XferJob{v1 + (size_t)k0 * maxv, d_v + nv, nv * sizeof(double), true});
+    if (!xfer_pool().run(dev, jobs)) return fail(FG_ERR_HIP, "fg_plan_get_polygons: device -> host copy failed");
+  }
   return 0;
 }
 

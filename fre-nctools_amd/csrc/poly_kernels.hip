@@ -124,3 +124,76 @@ void fgd_sincos_probe(long n, const double *x, double *s, double *c, hipStream_t
 {
   if (n > 0) k_sincos_probe<<<(int)((n + 255) / 256), 256, 0, st>>>(n, x, s, c);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The clipped polygon of every exchange cell of a plan (fg_plan_get_polygons): what clip_2dx2d returned inside create_xgrid for the
+// pair -- source cell after fix_lon(pi), destination cell after fix_lon(pi) and the +-2pi shift towards the source cell's mean
+// longitude (create_xgrid.c:1062-1079), clip_2dx2d's own wrap (:1282-1290).  make_coupler_mosaic keeps these vertices
+// (atmxlnd_x / _y, make_coupler_mosaic.c:1560-1577) to clip them against the ocean grid.  One lane per exchange cell.
+__global__ __launch_bounds__(64) void k_xgrid_polygons(long n, const int *x_src, const int *x_dst, FgCells S, FgCells D, FgRect R, int rect,
+                                                        int maxv, int *n_out, double *lon_out, double *lat_out)
+{
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int s = x_src[k], d = x_dst[k];
+  double a[PB_IN], b[PB_IN], c[PB_IN], e[PB_IN], xo[PB_CAP], yo[PB_CAP];
+  const int n1 = S.nv[s];
+  int n2;
+  const double *sv = S.verts + (size_t)s * 16;
+  for (int q = 0; q < 8; q++) { a[q] = sv[q]; b[q] = sv[8 + q]; }
+  double lon_out_avg;
+  if (rect) {
+    const int j = d / R.nx, i = d - j * R.nx;
+    const double *cr = R.col + (size_t)i * RECT_COLW;
+    const double ya = R.lat_ax[j], yb = R.lat_ax[j + 1];
+    c[0] = cr[0]; c[1] = cr[1]; c[2] = cr[2]; c[3] = cr[3]; lon_out_avg = cr[6];
+    e[0] = ya; e[1] = ya; e[2] = yb; e[3] = yb;
+    n2 = 4;
+  } else {
+    const double *dv = D.verts + (size_t)d * 16;
+    for (int q = 0; q < 8; q++) { c[q] = dv[q]; e[q] = dv[8 + q]; }
+    lon_out_avg = D.lon_avg[d];
+    n2 = D.nv[d];
+  }
+  const double dx = lon_out_avg - S.lon_avg[s];
+  const double shift = (dx < -G_PI) ? G_TPI : ((dx > G_PI) ? -G_TPI : 0.0);
+  if (shift != 0.0) for (int q = 0; q < n2; q++) c[q] += shift;
+  int m = (n1 < 1 || n2 < 1) ? 0 : d_clip_private(a, b, n1, c, e, n2, xo, yo);
+  n_out[k] = m;
+  for (int q = 0; q < maxv; q++) {
+    lon_out[(size_t)k * maxv + q] = (q < m && q < PB_CAP) ? xo[q] : 0.0;
+    lat_out[(size_t)k * maxv + q] = (q < m && q < PB_CAP) ? yo[q] : 0.0;
+  }
+}
+void fgd_xgrid_polygons(long n, const int *x_src, const int *x_dst, FgCells S, FgCells D, const FgRect *rect, int maxv,
+                        int *n_out, double *lon_out, double *lat_out, hipStream_t st)
+{
+  if (n > 0) k_xgrid_polygons<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(n, x_src, x_dst, S, D, rect ? *rect : FgRect{}, rect ? 1 : 0, maxv,
+                                                                      n_out, lon_out, lat_out);
+}
+__global__ __launch_bounds__(256) void k_xgrid_gather_gc(long n, const int *x_src, const int *x_dst, FgCells S, FgCells D, double *a, double *b)
+{
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 12) return;
+  const long k = t / 12; const int q = (int)(t - k * 12);
+  a[t] = S.verts[(size_t)x_src[k] * 16 + q];
+  b[t] = D.verts[(size_t)x_dst[k] * 16 + q];
+}
+void fgd_xgrid_gather_gc(long n, const int *x_src, const int *x_dst, FgCells S, FgCells D, double *a, double *b, hipStream_t st)
+{
+  if (n > 0) k_xgrid_gather_gc<<<(unsigned)((n * 12 + 255) / 256), 256, 0, st>>>(n, x_src, x_dst, S, D, a, b);
+}
+__global__ __launch_bounds__(256) void k_split_xyz(long n, int maxv, const double *xyz, double *x, double *y, double *z)
+{
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * maxv) return;
+  const long k = t / maxv; const int q = (int)(t - k * maxv);
+  const bool in = q < FG_GC_POLY_CAP;
+  x[t] = in ? xyz[((size_t)k * FG_GC_POLY_CAP + q) * 3] : 0.0;
+  y[t] = in ? xyz[((size_t)k * FG_GC_POLY_CAP + q) * 3 + 1] : 0.0;
+  z[t] = in ? xyz[((size_t)k * FG_GC_POLY_CAP + q) * 3 + 2] : 0.0;
+}
+void fgd_split_xyz(long n, int maxv, const double *xyz, double *x, double *y, double *z, hipStream_t st)
+{
+  if (n > 0) k_split_xyz<<<(unsigned)((n * maxv + 255) / 256), 256, 0, st>>>(n, maxv, xyz, x, y, z);
+}

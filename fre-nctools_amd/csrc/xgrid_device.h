@@ -125,7 +125,7 @@ void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *st
 // their bins (slot_cnt), fills src_idx_f, zeroes sums[3][nsrc] (may be null) and stores the tile descriptors at tiles_out
 void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, FgCells D,
                       FgBins b, int *slot_cnt, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
-                      unsigned long long *band_keys = nullptr, int cull = 0);
+                      unsigned long long *band_keys = nullptr, int cull = 0, double dst_tlon = 3.14159265358979323846);
 void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c, unsigned *err, hipStream_t st);
 // band_keys[0] / [1] = ordered keys of max / ~min of lat[0..n) (the destination grid's corner latitudes); cull = 2 in fgd_cell_struct2
 // then means: keys already there, cull the source blocks in the same launch as the destination blocks
@@ -140,6 +140,7 @@ void fgd_candidates1(int c0, int c1, FgCells S, const double *mask, FgBins b, co
                      hipStream_t st);
 // A rectilinear destination grid (lon_out a function of the column, lat_out of the row, bit for bit): see k_rect_tables.
 // All pointers are device pointers; bad != 0 after the check kernel = the grid is NOT rectilinear (the tables are then junk).
+#define RECT_COLW 8
 struct FgRect {
   const double *lon_ax;   // [nx+1] raw longitude axis (copy of row 0 of lon_out)
   const double *lat_ax;   // [ny+1] compact copy of lat_out[j][0]
@@ -149,11 +150,17 @@ struct FgRect {
   int nx, ny;
 };
 void fgd_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax, double *lon_ax, double *col,
-                     unsigned *bad, unsigned *err, hipStream_t st);
+                     unsigned *bad, unsigned *err, hipStream_t st, double dst_tlon = 3.14159265358979323846);
 void fgd_cell_struct2r(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, double *area_out,
                        FgRect R, const double *mask, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
                        unsigned long long *band_keys, int cull, int *heavy_list, int *heavy_cnt);
 void fgd_rect_materialize(int ndst, FgRect R, FgCells D, hipStream_t st);
+// Source "cells" given as a list of polygons (<= 8 vertices each, already in the longitude frame they are to be clipped in):
+// fills the source records a search needs (box, vertices, the caller's lon_avg and reference area), the field index, zeroes the
+// sums, and -- rect != null -- lists the heavy ones.  make_coupler_mosaic's atmosphere x land cells against the ocean grid.
+struct FgPolyList { const int *n; const double *lon, *lat; const double *lon_avg, *area; int npoly; };
+void fgd_polylist_records(FgPolyList P, FgCells S, int *src_idx_f, double *sums, const FgRect *rect, int *heavy_list, int *heavy_cnt,
+                          unsigned *err, hipStream_t st);
 void fgd_candidates_rect(int nsrc, FgCells S, const double *mask, FgRect R, FgPairSpace ps, int *pair_beg, int *pair_cnt,
                          const int *heavy_list, const int *heavy_cnt, int *big_list, int *big_cnt, hipStream_t st);
 // rect != null: the destination cells come from the rectilinear tables (D holds areas only)
@@ -293,6 +300,13 @@ void fgd_gc_area_batch(int npoly, int stride_pts, const double *xyz, const int *
 void fgd_poly_clip(int npoly, const double *lon1, const double *lat1, const int *n1, const double *lon2, const double *lat2,
                    const int *n2, double *lon_out, double *lat_out, int *n_out, hipStream_t st);
 void fgd_poly_op(int op, int npoly, double *lon, double *lat, int *n, const double *clon, double *result, hipStream_t st);
+// the clipped polygons of exchange cells [k0, k0 + n) of a legacy plan: n_out[n], lon / lat [n][maxv] (rect != null: destination
+// cells from the rectilinear tables)
+void fgd_xgrid_polygons(long n, const int *x_src, const int *x_dst, FgCells S, FgCells D, const FgRect *rect, int maxv,
+                        int *n_out, double *lon_out, double *lat_out, hipStream_t st);
+// great-circle plans: the two cells of each exchange cell as [n][12] xyz (for fgd_gc_clip_batch), and [n][16][3] -> three [n][maxv]
+void fgd_xgrid_gather_gc(long n, const int *x_src, const int *x_dst, FgCells S, FgCells D, double *a, double *b, hipStream_t st);
+void fgd_split_xyz(long n, int maxv, const double *xyz, double *x, double *y, double *z, hipStream_t st);
 void fgd_sincos_probe(long n, const double *x, double *s, double *c, hipStream_t st);
 
 // ---- order-2 input preparation (c2l_kernels.hip)

@@ -193,7 +193,7 @@ void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *st
 // nv = 0 and area 0 and nothing else; a block without a live cell skips its vertex records altogether.
 __device__ __forceinline__ int d_cell_record(const FgTile *tiles, int ntiles, int ncells, const FgCells &c, unsigned *err, int s0,
                                              double *vtile, double *box /* lat_min, lat_max, lon_min, lon_max */, int *tile_of,
-                                             const unsigned long long *cull = nullptr)
+                                             const unsigned long long *cull = nullptr, double tlon = G_PI)
 {
   const int s = s0 + threadIdx.x;
   double *row = vtile + threadIdx.x * 17;
@@ -225,8 +225,8 @@ __device__ __forceinline__ int d_cell_record(const FgTile *tiles, int ntiles, in
       const double bmax = d_ord_val(cull[0]), bmin = d_ord_val(~cull[1]);
       out_of_band = (lmax <= bmin) || (lmin >= bmax);
     }
-    int n = out_of_band ? 0 : d_fix_lon_quad_fast(x, y, G_PI);
-    if (n < 0) n = d_fix_lon(x, y, 4, G_PI);             // cells with a pole vertex / a half-turn edge: the general routine
+    int n = out_of_band ? 0 : d_fix_lon_quad_fast(x, y, tlon);
+    if (n < 0) n = d_fix_lon(x, y, 4, tlon);             // cells with a pole vertex / a half-turn edge: the general routine
     if (out_of_band) { c.nv[s] = 0; c.area[s] = 0; }
     else if (n < 0 || n > G_MAXV) {
       atomicOr(err, G_ERRBIT_MAXV);
@@ -350,7 +350,7 @@ __device__ __forceinline__ void d_bin_insert(bool live, int d, double lat_min, d
 // fregrid_util.c:2137-2145); destination blocks count their cells into the bins; block 0 stores the tile descriptors.
 __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst,
                                                        int nbS, FgCells S, FgCells D, FgBins b, int *slot_cnt, int order, int *src_idx_f,
-                                                       double *sums, unsigned *err, unsigned long long *band_keys, int cull)
+                                                       double *sums, unsigned *err, unsigned long long *band_keys, int cull, double dst_tlon)
 {
   __shared__ double vtile[256 * 17];
   __shared__ FgTile sh_tiles[FG_TILESET_MAX];
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_cell_struct2(FgTileSet ts, const FgTile
     }
   } else {
     const int d0 = ((int)blockIdx.x - nbS) * 256, d = d0 + threadIdx.x;
-    const int nv = d_cell_record(tiles + ntiles, 1, ndst, D, err, d0, vtile, box, &tl);
+    const int nv = d_cell_record(tiles + ntiles, 1, ndst, D, err, d0, vtile, box, &tl, nullptr, dst_tlon);
     d_bin_insert<false>(d < ndst && nv != 0, d, box[0], box[1], box[2], box[3], box[4], b, slot_cnt, nullptr, nullptr, 0);
     if (band_keys && cull != 2) {                       // latitude range of the destination cells, for the culling of a later launch
       // one pair of atomics per BLOCK, and only when it would change the value: thousands of same-address atomics serialise
@@ -759,13 +759,13 @@ __global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCel
 // k_rect_tables VERIFIES the property on the device (every corner against its axis value, bitwise) in the same stream; every
 // later kernel of the rectilinear path leaves at once when the check failed, and the host repeats the search with the generic
 // path (plan.hip).  Results are the generic path's, bit for bit (tests/test_gpu_rect.py, scripts/legacy_fuzz.py).
-#define RECT_COLW 8           // doubles per column record: x'[0..3] after fix_lon (SW, SE, NE, NW), lon_min, lon_max, lon_avg, spare
+// (RECT_COLW = 8 doubles per column record, xgrid_device.h: x'[0..3] after fix_lon (SW, SE, NE, NW), lon_min, lon_max, lon_avg, width)
 #define RECT_HDR 8            // header of the tables: lon[0], nx / (lon[nx] - lon[0]), lat[0], ny / (lat[ny] - lat[0])
 #define RECT_EPS 1.e-9
 #define RECT_HEAVY 48         // rows x window columns above which a source cell's candidates are made by a whole wave
 
 __global__ __launch_bounds__(256) void k_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax,
-                                                      double *lon_ax, double *col, unsigned *bad, unsigned *err)
+                                                      double *lon_ax, double *col, unsigned *bad, unsigned *err, double dst_tlon)
 {
   const long np = (long)(nx + 1) * (ny + 1);
   const long gid = (long)blockIdx.x * 256 + threadIdx.x, gsz = (long)gridDim.x * 256;
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void k_rect_tables(const double *lon, const do
     double x[G_FIXCAP], y[G_FIXCAP];
     x[0] = x0; x[1] = x1; x[2] = x1; x[3] = x0;
     y[0] = 0.0; y[1] = 0.0; y[2] = 0.1; y[3] = 0.1;
-    const int n = d_fix_lon(x, y, 4, G_PI);
+    const int n = d_fix_lon(x, y, 4, dst_tlon);
     double *c = col + (size_t)gid * RECT_COLW;
     if (n != 4) { b = true; for (int k = 0; k < RECT_COLW; k++) c[k] = 0.0; }
     else {
@@ -960,6 +960,46 @@ __global__ __launch_bounds__(256) void k_cell_struct2r(FgTileSet ts, const FgTil
       const double ya = R.lat_ax[j], yb = R.lat_ax[j + 1];
       double x[4] = {c[0], c[1], c[2], c[3]}, y[4] = {ya, ya, yb, yb};
       area_out[d] = d_poly_area<1>(x, y, 4);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_polylist_records(FgPolyList P, FgCells S, int *src_idx_f, double *sums, FgRect R, int rect,
+                                                           int *heavy_list, int *heavy_cnt, unsigned *err)
+{
+  if (rect && *R.bad) return;
+  const int s = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  bool heavy = false;
+  if (s < P.npoly) {
+    const int n = P.n[s];
+    double *v = S.verts + (size_t)s * 16;
+    if (n < 3 || n > G_MAXV) {
+      if (n > G_MAXV) atomicOr(err, G_ERRBIT_MAXV);
+      S.nv[s] = 0; S.area[s] = 0; S.lat_min[s] = 0; S.lat_max[s] = 0; S.lon_min[s] = 0; S.lon_max[s] = 0; S.lon_avg[s] = 0;
+      for (int k = 0; k < 16; k++) v[k] = 0.0;
+    } else {
+      double xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+      for (int k = 0; k < G_MAXV; k++) {
+        const double x = (k < n) ? P.lon[(size_t)s * G_MAXV + k] : 0.0, y = (k < n) ? P.lat[(size_t)s * G_MAXV + k] : 0.0;
+        v[k] = x; v[8 + k] = y;
+        if (k == 0) { xmin = xmax = x; ymin = ymax = y; }
+        else if (k < n) { xmin = fmin(xmin, x); xmax = fmax(xmax, x); ymin = fmin(ymin, y); ymax = fmax(ymax, y); }
+      }
+      if (!(ymin >= -G_HPI - 1.e-6) || !(ymax <= G_HPI + 1.e-6)) atomicOr(err, G_ERRBIT_BADLAT);
+      S.nv[s] = n; S.area[s] = P.area[s]; S.lon_avg[s] = P.lon_avg[s];
+      S.lat_min[s] = ymin; S.lat_max[s] = ymax; S.lon_min[s] = xmin; S.lon_max[s] = xmax;
+      if (rect) heavy = d_rect_heavy(R, ymin, ymax, xmin, xmax);
+    }
+    if (src_idx_f) src_idx_f[s] = s;
+    if (sums) { sums[s] = 0.0; sums[P.npoly + s] = 0.0; sums[2 * (size_t)P.npoly + s] = 0.0; }
+  }
+  if (rect) {
+    const unsigned long long m = __ballot(heavy);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(heavy_cnt, __popcll(m));
+      base = __shfl(base, 0);
+      if (heavy) heavy_list[base + __popcll(m & ((1ull << lane) - 1ull))] = s;
     }
   }
 }
@@ -1677,12 +1717,12 @@ void fgd_cell_struct(const FgTile *tiles_dev, int ntiles, int ncells, FgCells c,
 
 void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, FgCells D,
                       FgBins b, int *slot_cnt, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
-                      unsigned long long *band_keys, int cull)
+                      unsigned long long *band_keys, int cull, double dst_tlon)
 {
   const int nbS = nblk(nsrc, 256), nbD = nblk(ndst, 256);
   if (nbS + nbD > 0)
     k_cell_struct2<<<nbS + nbD, 256, 0, st>>>(ts, tiles_in, tiles_out, ntiles, nsrc, ndst, nbS, S, D, b, slot_cnt, order, src_idx_f, sums, err,
-                                              band_keys, cull);
+                                              band_keys, cull, dst_tlon);
 }
 
 void fgd_bin_count(int ncells, FgCells c, FgBins b, int *slot_cnt, hipStream_t st)
@@ -1738,11 +1778,11 @@ void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, 
 
 // ---- rectilinear destination grid
 void fgd_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax, double *lon_ax, double *col, unsigned *bad,
-                     unsigned *err, hipStream_t st)
+                     unsigned *err, hipStream_t st, double dst_tlon)
 {
   const long np = (long)(nx + 1) * (ny + 1);
   const int g = (int)std::min<long>(1024, std::max<long>((np + 255) / 256, (std::max(nx, ny) + 1 + 255) / 256));
-  k_rect_tables<<<std::max(g, 1), 256, 0, st>>>(lon, lat, nx, ny, hdr, lat_ax, lon_ax, col, bad, err);
+  k_rect_tables<<<std::max(g, 1), 256, 0, st>>>(lon, lat, nx, ny, hdr, lat_ax, lon_ax, col, bad, err, dst_tlon);
 }
 void fgd_cell_struct2r(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, double *area_out,
                        FgRect R, const double *mask, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
@@ -1752,6 +1792,12 @@ void fgd_cell_struct2r(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tile
   if (nbS + nbD > 0)
     k_cell_struct2r<<<nbS + nbD, 256, 0, st>>>(ts, tiles_in, tiles_out, ntiles, nsrc, ndst, nbS, S, area_out, R, mask, order, src_idx_f, sums, err,
                                                band_keys, cull, heavy_list, heavy_cnt);
+}
+void fgd_polylist_records(FgPolyList P, FgCells S, int *src_idx_f, double *sums, const FgRect *rect, int *heavy_list, int *heavy_cnt,
+                          unsigned *err, hipStream_t st)
+{
+  if (P.npoly > 0)
+    k_polylist_records<<<nblk(P.npoly, 256), 256, 0, st>>>(P, S, src_idx_f, sums, rect ? *rect : FgRect{}, rect ? 1 : 0, heavy_list, heavy_cnt, err);
 }
 void fgd_rect_materialize(int ndst, FgRect R, FgCells D, hipStream_t st)
 {

@@ -207,6 +207,22 @@ int fg_plan_get_xgrid(const fg_plan *plan, int *t_in, int *i_in, int *j_in, int 
 int fg_plan_get_cell_struct(const fg_plan *plan, int which, double *lat_min, double *lat_max, double *lon_min,
                             double *lon_max, double *lon_avg, int *nvert, double *vlon, double *vlat);
 
+/* The clipped polygon of every exchange cell of a searched plan, in canonical order: n_out[nxgrid] vertex counts and
+ * [nxgrid][maxv] vertex arrays (host).  Legacy plans: v0 = longitudes, v1 = latitudes as clip_2dx2d returned them for the pair
+ * inside create_xgrid (source cell after fix_lon(pi); destination cell after fix_lon(pi) and the +-2pi shift of
+ * create_xgrid.c:1062-1079); v2 unused.  Great-circle plans: v0, v1, v2 = x, y, z as clip_2dx2d_great_circle returned them.
+ * make_coupler_mosaic keeps these vertices of its atmosphere x land cells to clip them against the ocean grid
+ * (make_coupler_mosaic.c:1560-1577, 1659-1692); see coupler.py. */
+int fg_plan_get_polygons(const fg_plan *plan, int maxv, int *n_out, double *v0, double *v1, double *v2);
+/* A legacy search whose SOURCE cells are a list of polygons of at most 8 vertices: n[npoly], lon / lat [npoly][8] (host) in the
+ * longitude frame of each polygon's parent cell; lon_avg[npoly] = the parent's mean longitude (it decides the +-2pi shift of a
+ * destination cell, create_xgrid.c:1062-1079, and is poly_ctrlon's reference); area_ref[npoly] = the area the 1e-6 ratio test
+ * uses for the polygon.  Everything downstream is the ordinary plan (exchange cells with i_in = polygon index, j_in = t_in = 0,
+ * fg_plan_get_xgrid / _polygons / accumulate / finalize / apply).  make_coupler_mosaic.c:1659-1692 clips its remembered
+ * atmosphere x land polygons against the ocean grid this way; fre-nctools_amd/coupler.py is that loop over two plans and this. */
+long fg_plan_create_polylist(int order, int npoly, const int *n, const double *lon, const double *lat, const double *lon_avg,
+                             const double *area_ref, int nx_out, int ny_out, const double *lon_out, const double *lat_out,
+                             int device, fg_plan **plan_out);
 /* cell areas computed during the search (get_grid_area semantics): source cells
  * concatenated over tiles / destination cells.  Host arrays, may be NULL. */
 int fg_plan_get_cell_area(const fg_plan *plan, double *area_in, double *area_out);
@@ -326,6 +342,11 @@ void fg_set_search_cull(int on);
  * (no bins, no per-cell records); the property is verified on the device inside the search, and a grid that fails it is searched
  * by the generic path in the same call.  0: always the generic path.  Results do not depend on it (tests/test_gpu_rect.py). */
 void fg_set_search_rect(int on);
+/* Longitude frame of the destination cells of a legacy search: 0 (default) create_xgrid's -- fix_lon(cell, pi), then the +-2pi shift
+ * towards the source cell per pair (create_xgrid.c:1004,1062-1079); 1 make_coupler_mosaic's -- the cell is moved once per pair,
+ * fix_lon(cell, mean longitude of the other cell) (make_coupler_mosaic.c:1452,1598).  Same exchange cells; the vertices (and so
+ * the last bits of the areas) differ only for grids whose raw longitudes lie outside [0, 2pi).  coupler.py uses 1. */
+void fg_set_search_frame(int coupler);
 /* Sweep tuning hook: 1 (default) = 8-level order-2 sweeps on merged records use the entry-parallel kernel when rows are short
  * (nxgrid <= 6 x destination cells), 0 = always the row-serial kernel.  Results do not depend on it. */
 void fg_set_apply_ep(int on);
