@@ -70,6 +70,39 @@ bool is_pinned(const void *p)
 }
 }  // namespace
 
+// get_input_data's / write_field_data's conversions on device buffers, for callers that run the field loop themselves
+// (integration/field_io_hip.c).  Synchronous (null stream + device sync).
+extern "C" int fg_dev_widen(int nc_type, long n, const void *raw_dev, double scale, double offset, double missing, double *out_dev)
+{
+  if (n < 0 || (n > 0 && (!raw_dev || !out_dev)) || !type_size(nc_type)) return sw_fail(FG_ERR_ARG, "fg_dev_widen: bad argument");
+  if (n == 0) return 0;
+  const int grid = (int)((n + 255) / 256);
+  switch (nc_type) {
+    case FG_NC_SHORT: k_widen<int16_t><<<grid, 256>>>(n, (const int16_t *)raw_dev, scale, offset, missing, out_dev); break;
+    case FG_NC_INT: k_widen<int32_t><<<grid, 256>>>(n, (const int32_t *)raw_dev, scale, offset, missing, out_dev); break;
+    case FG_NC_FLOAT: k_widen<float><<<grid, 256>>>(n, (const float *)raw_dev, scale, offset, missing, out_dev); break;
+    default: k_widen<double><<<grid, 256>>>(n, (const double *)raw_dev, scale, offset, missing, out_dev); break;
+  }
+  SWCHK(hipGetLastError());
+  SWCHK(hipDeviceSynchronize());
+  return 0;
+}
+extern "C" int fg_dev_narrow(int nc_type, long n, const double *in_dev, double scale, double offset, double missing, void *out_dev)
+{
+  if (n < 0 || (n > 0 && (!in_dev || !out_dev)) || !type_size(nc_type)) return sw_fail(FG_ERR_ARG, "fg_dev_narrow: bad argument");
+  if (n == 0) return 0;
+  const int grid = (int)((n + 255) / 256);
+  switch (nc_type) {
+    case FG_NC_SHORT: k_narrow<int16_t><<<grid, 256>>>(n, in_dev, scale, offset, missing, (int16_t *)out_dev); break;
+    case FG_NC_INT: k_narrow<int32_t><<<grid, 256>>>(n, in_dev, scale, offset, missing, (int32_t *)out_dev); break;
+    case FG_NC_FLOAT: k_narrow<float><<<grid, 256>>>(n, in_dev, scale, offset, missing, (float *)out_dev); break;
+    default: k_narrow<double><<<grid, 256>>>(n, in_dev, scale, offset, missing, (double *)out_dev); break;
+  }
+  SWCHK(hipGetLastError());
+  SWCHK(hipDeviceSynchronize());
+  return 0;
+}
+
 struct fg_sweep {
   int device = 0, order = 1, in_type = FG_NC_DOUBLE, out_type = FG_NC_DOUBLE;
   size_t in_sz = 8, out_sz = 8;

@@ -492,6 +492,11 @@ const char *fg_nc_last_error(void);
  * Out-of-range narrowing (NC_SHORT / NC_INT outputs beyond the type's range, e.g. a missing value of -1e20): the device cast
  * saturates, the reference's host cast (fregrid_util.c:2395-2406) is undefined behaviour that yields INT_MIN on x86 --
  * parity unpinned, no fixture in the reference covers it. */
+/* The two conversions alone, on device buffers (synchronous): out[i] = (double)raw[i], `*= scale` / `+= offset` where != missing
+ * (get_input_data, fregrid_util.c:2097-2123); and the inverse with the C cast to the file type (write_field_data, :2376-2406).
+ * nc_type: FG_NC_SHORT / _INT / _FLOAT / _DOUBLE.  integration/field_io_hip.c builds fregrid's per-level loop from them. */
+int fg_dev_widen(int nc_type, long n, const void *raw_dev, double scale, double offset, double missing, double *out_dev);
+int fg_dev_narrow(int nc_type, long n, const double *in_dev, double scale, double offset, double missing, void *out_dev);
 typedef struct fg_sweep fg_sweep;
 int  fg_sweep_create(int nplans, fg_plan *const *plans, fg_c2l *c2l, int in_type, int out_type, fg_sweep **out);
 int  fg_sweep_run(fg_sweep *sw, const void *host_in, long nlev, double scale, double offset, double missing,

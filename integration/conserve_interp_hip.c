@@ -28,6 +28,10 @@
 #include "mpp.h"
 #include "mpp_domain.h"
 #include "fregrid_hip.h"
+#include "fregrid_hip_glue.h"
+/* device-resident fields handed over by integration/field_io_hip.c; weak: this object also links and runs without it */
+const FgDevField *fg_glue_input(const Field_config *field, int varid) __attribute__((weak));
+int fg_glue_output_put(const Field_config *field_out_n, double *d_out, long n, int nz) __attribute__((weak));
 
 #define MAXVAL (1.e20)
 
@@ -314,11 +318,25 @@ void do_scalar_conserve_interp(Interp_config *interp, int varid, int ntiles_in, 
     e_data[n] = (size_t)(grid_in[n].nx + 2 * halo) * (grid_in[n].ny + 2 * halo);
     ncell += e_cell[n];
   }
+  /* get_input_data of field_io_hip.c leaves the level(s) on the device: halo filled, gradients and gradient mask made there */
+  const FgDevField *devf = fg_glue_input ? fg_glue_input(field_in, varid) : NULL;
+  if (devf && (devf->nz != nz || devf->order != order || devf->ncell != (long)ncell)) devf = NULL;
   for (n = 0; n < ntiles_in; n++) p[n] = field_in[n].data;
-  double *d_data = stage_tiles(ntiles_in, nz, e_data, p, dev, NULL);
+  double *d_data = devf ? devf->d_data : stage_tiles(ntiles_in, nz, e_data, p, dev, NULL);
   double *d_gx = NULL, *d_gy = NULL, *d_w = NULL, *d_fa = NULL, *d_ca = NULL;
   int *d_gm = NULL;
-  if (order == 2) {
+  if (devf) {
+    d_gx = devf->d_gx; d_gy = devf->d_gy; d_gm = devf->d_gm;
+    if (opcode & CHECK_CONSERVE) {                       /* the flux sum below reads the host arrays */
+      size_t off = 0;
+      int k;
+      for (n = 0; n < ntiles_in; n++) {
+        for (k = 0; k < nz; k++)
+          if (fg_dev_download(field_in[n].data + (size_t)k * e_data[n], d_data + (size_t)k * devf->f_stride + off, e_data[n] * sizeof(double))) hip_fatal("do_scalar_conserve_interp");
+        off += e_data[n];
+      }
+    }
+  } else if (order == 2) {
     for (n = 0; n < ntiles_in; n++) p[n] = field_in[n].grad_x;
     d_gx = stage_tiles(ntiles_in, nz, e_cell, p, dev, NULL);
     for (n = 0; n < ntiles_in; n++) p[n] = field_in[n].grad_y;
@@ -369,9 +387,12 @@ void do_scalar_conserve_interp(Interp_config *interp, int varid, int ntiles_in, 
     }
     if (fg_plan_sync(pl) || fg_dev_download(field_out[m].data, d_out, nout * (size_t)nz * sizeof(double))) hip_fatal("do_scalar_conserve_interp");
     gsum_out += g;
-    fg_dev_free(d_out); fg_dev_free(d_cao);
+    /* write_field_data of field_io_hip.c narrows the level on the device and downloads it in the file's type */
+    if (!(fg_glue_output_put && fg_glue_output_put(&field_out[m], d_out, (long)nout, nz))) fg_dev_free(d_out);
+    fg_dev_free(d_cao);
   }
-  fg_dev_free(d_data); fg_dev_free(d_gx); fg_dev_free(d_gy); fg_dev_free(d_gm); fg_dev_free(d_w); fg_dev_free(d_fa); fg_dev_free(d_ca);
+  if (!devf) { fg_dev_free(d_data); fg_dev_free(d_gx); fg_dev_free(d_gy); fg_dev_free(d_gm); }
+  fg_dev_free(d_w); fg_dev_free(d_fa); fg_dev_free(d_ca);
   free(e_data); free(e_cell); free(p);
 
   /* conservation check if needed (:874-907) */

@@ -60,7 +60,11 @@ def test_fregrid_replacement_object_type_checks_against_the_reference(tmp_path):
     typedef only; tests/capi/typecheck_shim supplies that one typedef -- syntax check only, nothing is linked or run.)"""
     _run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(CAPI, "typecheck_shim"),
           "-I", os.path.join(REF, "fregrid"), "-I", os.path.join(REF, "libfrencutils"), "-I", os.path.join(ROOT, "include"),
-          os.path.join(ROOT, "integration", "conserve_interp_hip.c")])
+          "-I", os.path.join(ROOT, "integration"), os.path.join(ROOT, "integration", "conserve_interp_hip.c")])
+    # ... and integration/field_io_hip.c against fregrid_util.h / mpp_io.h (get_input_data / write_field_data, Var_config, Field_config)
+    _run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(CAPI, "typecheck_shim"),
+          "-I", os.path.join(REF, "fregrid"), "-I", os.path.join(REF, "libfrencutils"), "-I", os.path.join(ROOT, "include"),
+          "-I", os.path.join(ROOT, "integration"), os.path.join(ROOT, "integration", "field_io_hip.c")])
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
