@@ -92,6 +92,32 @@ def cpu_baseline(fg, lon, lat, lo, la, ni, nlon, nlat, rows):
             "seconds": dt}, r, j0
 
 
+def gc_roofline(clip_ms, scale=1.0):
+    """The great-circle clip (k_gc_screen + k_gc_solve + k_gc_walk [+ k_gc_clip_list beside it]) against the vector issue rate: the
+    solve is integer arithmetic (a software x87 for the reference's long double), the walk FP64 + the exact acosl.  Instruction
+    counts from the committed PMC passes (profiles/pmc_traffic.json, C384 -> 1440x720; `scale` = this job's exchange cells over that
+    launch's 4 160 160 for the C768 job), time = this run's HIP-event span of the clip."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not clip_ms or not os.path.exists(pmc):
+        return None
+    try:
+        tr = json.load(open(pmc))
+    except Exception:
+        return None
+    ks = [k for k in ("k_gc_screen", "k_gc_solve", "k_gc_walk") if tr.get(k + "_valu_insts")]
+    if not ks:
+        return None
+    valu_peak = 1024 * 2.4e9
+    insts = scale * sum(tr[k + "_valu_insts"] for k in ks)
+    out = {"kernels": ks, "instruction_scale": scale, "dominant": "k_gc_walk", "bound": "valu", "unit": "SIMD issue cycles/s", "peak": valu_peak, "clip_ms": clip_ms,
+           "achieved": 4.0 * insts / (clip_ms * 1e-3), "traffic": sum(tr.get(k, 0) for k in ks) or None,
+           "per_kernel": {k: {"valu_insts": tr[k + "_valu_insts"], "fp64_share": tr.get(k + "_fp64_insts", 0) / tr[k + "_valu_insts"],
+                              "int_share": tr.get(k + "_int_insts", 0) / tr[k + "_valu_insts"], "lanes_active_per_valu_inst": tr.get(k + "_lanes_active")} for k in ks},
+           "source": f"profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of {tr.get('round', 'an earlier round')}, not collected in this run)"}
+    out["frac"] = out["achieved"] / valu_peak
+    return out
+
+
 def pcie_leg(fg, ni, nlon, nlat, lon, lat, lo, la, device):
     """The same job through the HOST-pointer API (what a B1 / B2 caller with host arrays pays): corner arrays up, search,
     finalize, and the exchange cells (8 arrays, indices decomposed on the device) back into host memory."""
@@ -143,9 +169,11 @@ def config4_leg(fg, torch, dev, device):
         p = fg.XgridPlan.create_great_circle_dev([ni] * 6, [ni] * 6, xin, nlon, nlat, xout, np.pi / nlat, 2 * np.pi / nlon, device=device)
         p.finalize(); p.sync()
         ts.append(time.perf_counter() - t0); n = p.nxgrid
+        clip_ms = p.phase_ms().get("clip_general")
         p.destroy()
     out["4a_great_circle_order1"] = {"nxgrid": n, "ms_per_step": min(ts[1:]) * 1e3, "exchange_cells_per_s": n / min(ts[1:]),
-                                     "host_latlon2xyz_and_upload_ms": t_xyz * 1e3}
+                                     "host_latlon2xyz_and_upload_ms": t_xyz * 1e3, "clip_kernel_ms": clip_ms,
+                                     "roofline_gc": gc_roofline(clip_ms, n / 4160160.0)}
     del lon_t, lat_t, lo_t, la_t, xin, xout
     fg.lib().fg_pool_release()
     return out
@@ -645,13 +673,15 @@ def main():
         # The dominant kernel of the search is FP64-VALU bound (SURVEY.md §8d predicted it): its roofline is the vector issue
         # rate -- a wave64 FP64 instruction occupies its SIMD for 4 cycles, 1024 SIMDs at 2.4 GHz -- and the HBM view is secondary.
         valu_peak = 1024 * 2.4e9
-        roof = {"kernel": "k_clip_quad<2>", "bound": "valu", "achieved": None, "peak": valu_peak, "unit": "SIMD issue cycles/s",
+        fp64_peak = 78.6e12           # vector FP64, MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+        roof = {"kernel": "k_clip_quad<2, true>", "bound": "valu", "achieved": None, "peak": valu_peak, "unit": "SIMD issue cycles/s",
                 "frac": None, "traffic": None,
                 "kernel_ms": clip_ms, "algorithmic_bytes_per_launch": alg_search,
                 "hbm": {"achieved": (alg_search / 1e9) / (clip_ms / 1e3) if clip_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
-                "note": "achieved = 4 issue cycles x wave VALU instructions of one launch (SQ_INSTS_VALU, PMC pass) / live kernel time; "
-                        "hbm.achieved = algorithmic bytes of the whole search / this kernel's time (the figure SURVEY.md 8d asks for); "
-                        "the HBM-bound kernel of the path is the sweep: roofline_apply"}
+                "note": "achieved = 4 issue cycles x wave VALU instructions of one launch (SQ_INSTS_VALU, PMC pass) / live kernel time = how busy the "
+                        "vector pipes are, NOT how much of that is useful FP64 work: see fp64 (flop/s against the 78.6 TF vector peak, FP64 share of the "
+                        "instructions, lanes live per instruction); hbm.achieved = algorithmic bytes of the whole search / this kernel's time (the figure "
+                        "SURVEY.md 8d asks for); the HBM-bound kernel of the path is the sweep: roofline_apply"}
         roof["hbm"]["frac"] = roof["hbm"]["achieved"] / HBM_PEAK_GBS if roof["hbm"]["achieved"] else None
         # sweep: weights streamed once per launch of nz levels + per level the source fields and the output
         alg_apply = 32.0 * nx_rank0 + nb * (24.0 * ncell_in + 8.0 * nlon * ny_band)
@@ -663,29 +693,35 @@ def main():
                   "kernel_ms_separate_arrays": apply_kernel_ms}
         roof_a["frac"] = roof_a["achieved"] / HBM_PEAK_GBS if roof_a["achieved"] else None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and world > 1:       # a band's launch: the per-pair instruction count of the single-GPU PMC pass, scaled
+        tr = {}
+        if os.path.exists(pmc):
             try:
                 tr = json.load(open(pmc))
-                if tr.get("k_clip_quad_valu_insts") and tr.get("k_clip_quad_pairs") and clip_ms > 0:
-                    insts = tr["k_clip_quad_valu_insts"] * stats["pairs"] / tr["k_clip_quad_pairs"]
-                    roof["achieved"] = 4.0 * insts / (clip_ms * 1e-3)
-                    roof["frac"] = roof["achieved"] / valu_peak
-                    roof["valu_insts_source"] = ("profiles/pmc_traffic.json (static: SQ_INSTS_VALU of the single-GPU launch, scaled by this "
-                                                 "rank's candidate pairs / the profiled launch's)")
             except Exception:
-                pass
-        if os.path.exists(pmc) and world == 1:      # the PMC passes were taken on the single-GPU launch sizes
-            try:
-                tr = json.load(open(pmc))
-                src = f"profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of {tr.get('round', 'an earlier round')}, not collected in this run)"
+                tr = {}
+        if tr.get("k_clip_quad_valu_insts") and tr.get("k_clip_quad_pairs") and clip_ms > 0:
+            # a band's launch (world > 1): the per-pair counts of the single-GPU PMC pass, scaled by this rank's candidate pairs
+            scale = 1.0 if world == 1 else stats["pairs"] / tr["k_clip_quad_pairs"]
+            src = (f"profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of {tr.get('round', 'an earlier round')} on the single-GPU launch, not collected "
+                   "in this run" + ("" if world == 1 else "; scaled by this rank's candidate pairs / the profiled launch's") + ")")
+            roof["achieved"] = 4.0 * tr["k_clip_quad_valu_insts"] * scale / (clip_ms * 1e-3)
+            roof["frac"] = roof["achieved"] / valu_peak
+            roof["valu_insts_source"] = src
+            if tr.get("k_clip_quad_fp64_wave_flops"):
+                lanes = tr.get("k_clip_quad_lanes_active")
+                fl_all = 64.0 * tr["k_clip_quad_fp64_wave_flops"] * scale / (clip_ms * 1e-3)
+                roof["fp64"] = {"flops_per_s_all_lanes": fl_all, "frac_of_78.6TF_all_lanes": fl_all / fp64_peak,
+                                "flops_per_s_live_lanes": (fl_all * lanes / 64.0) if lanes else None,
+                                "frac_of_78.6TF_live_lanes": (fl_all * lanes / 64.0 / fp64_peak) if lanes else None,
+                                "fp64_share_of_valu_insts": tr.get("k_clip_quad_fp64_insts", 0) / tr["k_clip_quad_valu_insts"],
+                                "int32_share_of_valu_insts": tr.get("k_clip_quad_int32_insts", 0) / tr["k_clip_quad_valu_insts"],
+                                "lanes_active_per_valu_inst": lanes,
+                                "note": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 (FMA = 2 flops) x 64 lanes / live kernel time; live lanes = "
+                                        "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of 64: the gap between pipe-busy and useful work is divergence "
+                                        "(polygons of 3..8 vertices in one wave, flat / general edges) plus moves, selects and compares"}
+            if world == 1:
                 roof["traffic"] = tr.get("k_clip_quad"); roof["traffic_source"] = src
                 roof_a["traffic"] = tr.get("k_apply"); roof_a["traffic_source"] = src
-                if tr.get("k_clip_quad_valu_insts") and clip_ms > 0:
-                    roof["achieved"] = 4.0 * tr["k_clip_quad_valu_insts"] / (clip_ms * 1e-3)
-                    roof["frac"] = roof["achieved"] / valu_peak
-                    roof["valu_insts_source"] = src
-            except Exception:
-                pass
         # mass conservation (conserve_interp.c:874-907): input flux uses get_grid_area cell areas
         a_in = a_in_full if a_in_full is not None else np.asarray(p.get_cell_area(nlon * ny_band)[0])
         gsum_in = float(np.sum(src_h[0] * a_in))
@@ -766,7 +802,8 @@ def main():
             line["great_circle"] = {"workload": f"C{ni} -> {nlon}x{nlat}, create_xgrid_great_circle semantics, first order",
                                     "nxgrid": gp.nxgrid, "ms_per_step": dtg * 1e3, "exchange_cells_per_s": gp.nxgrid / dtg,
                                     "clip_kernel_ms": gc_ph.get("clip_general"), "search_device_ms": gc_ph.get("search_total"),
-                                    "host_latlon2xyz_ms": t_xyz * 1e3, "search_stats": gp.stats()}
+                                    "host_latlon2xyz_ms": t_xyz * 1e3, "search_stats": gp.stats(),
+                                    "roofline_gc": gc_roofline(gc_ph.get("clip_general"))}
             gp.destroy()
         if world == 1 and "pcie" in legs:
             line["pcie_inclusive"] = pcie_leg(fg, ni, nlon, nlat, lon, lat, lo, la, local_rank)
