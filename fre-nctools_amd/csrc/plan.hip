@@ -682,6 +682,11 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   double *tmp_clon = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
   double *tmp_clat = (order == 2) ? pl->alloc<double>(npairs + 1) : nullptr;
   int *defer_list = pl->alloc<int>(npairs + 1);
+  // legacy clip on one chunk: the clip kernels take the destination-row slots, the row scan runs before the compaction and the
+  // compaction stores the row lists itself (no k_csr_fill_pos, no returning atomics in the compaction)
+  const bool early_rows = !gc && !boxm && K == 1;
+  int *tmp_rowpos = early_rows ? pl->alloc<int>(npairs + 1) : nullptr;
+  if (early_rows && !tmp_rowpos) return fail(FG_ERR_HIP, "out of device memory");
   // great-circle path, three-pass clip: per-pair words, and 3 tasks (edge pairs to solve) per pair of capacity -- 3.0 per LIVE
   // pair were counted at C384 -> 0.25 deg; pairs whose tasks do not fit go through the one-kernel clip instead
   const bool gc_split = gc && g_gc_split && npairs < (1L << 28);
@@ -816,10 +821,12 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
       ptb.end();
     } else {
       ptb.begin(PH_CLIP_QUAD);
-      fgd_clip_quad(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb, rect ? &pl->rect_tab : nullptr);
+      fgd_clip_quad(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb, rect ? &pl->rect_tab : nullptr,
+                    early_rows ? row_cnt : nullptr, tmp_rowpos);
       ptb.end();
       ptb.begin(PH_CLIP_GENERAL);
-      fgd_clip_general(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb, rect ? &pl->rect_tab : nullptr);
+      fgd_clip_general(order, q, pl->S, pl->mask_dev, pl->D, ta, tl, tt, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb, rect ? &pl->rect_tab : nullptr,
+                       early_rows ? row_cnt : nullptr, tmp_rowpos);
       ptb.end();
     }
     if (K > 1) { ev_q[k] = g_handles.get_sync_event(); HIPCHK(hipEventRecord(ev_q[k], sb)); }
@@ -835,18 +842,22 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     io.tmp_area = tmp_area + k * pcap_k; io.tmp_clon = tmp_clon ? tmp_clon + k * pcap_k : nullptr; io.tmp_clat = tmp_clat ? tmp_clat + k * pcap_k : nullptr;
     io.xoff = pl->xoff; io.x_src = pl->x_src; io.x_dst = pl->x_dst; io.x_area = pl->x_area; io.x_c1 = pl->x_c1; io.x_c2 = pl->x_c2;
     io.row_cnt = row_cnt; io.x_rowpos = pl->x_rowpos; io.sums = pl->sums; io.big_list = big_list + cb[k]; io.big_cnt = &dc->big_cnt[k];
+    io.tmp_rowpos = tmp_rowpos; io.row_ptr = pl->csr.row_ptr; io.perm = pl->perm;
     io.fill_all = (k == K - 1) ? ps.fill : nullptr; io.nreg_all = nreg_k * K;
     io.dc = dc; io.xcap = nx_alloc;
     const int nk = cb[k + 1] - cb[k];
     fgd_exclusive_scan1(nacc + cb[k], nk, pl->xoff + cb[k], lb_comp + tile0, &tickets[2 + k], &dc->xtot[k], dc->err, st, k ? &dc->xtot[k - 1] : nullptr);
+    if (early_rows) fgd_exclusive_scan1(row_cnt, ndst, pl->csr.row_ptr, lb_rows, &tickets[1], &dc->rows_total, dc->err, st);
     tile0 += fgd_scan_tiles(nk);
     fgd_compact(order, nsrc, q, io, st);
     pt.end();
   }
-  pt.begin(PH_ROWS);
-  fgd_exclusive_scan1(row_cnt, ndst, pl->csr.row_ptr, lb_rows, &tickets[1], &dc->rows_total, dc->err, st);
-  fgd_csr_fill_pos(nx_alloc, &dc->xtot[K - 1], pl->x_dst, pl->csr.row_ptr, pl->x_rowpos, pl->perm, st);
-  pt.end();
+  if (!early_rows) {
+    pt.begin(PH_ROWS);
+    fgd_exclusive_scan1(row_cnt, ndst, pl->csr.row_ptr, lb_rows, &tickets[1], &dc->rows_total, dc->err, st);
+    fgd_csr_fill_pos(nx_alloc, &dc->xtot[K - 1], pl->x_dst, pl->csr.row_ptr, pl->x_rowpos, pl->perm, st);
+    pt.end();
+  }
   ptot.end();
   HIPCHK(hipMemcpyAsync(hc, dc, sizeof(FgCounters), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));                              // the one synchronisation of a search (stream B's work is ordered before it)
@@ -886,7 +897,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pl->rect_tab.bad = nullptr;                          // (lives in the scratch block released below; nothing reads it after the search)
   // scratch no longer needed
   void *scratch[] = {zero_blk, bin_start, bin_entries, heavy_list, big_list, pair_beg, pair_cnt, ps.src, ps.dst,
-                     tmp_area, tmp_clon, tmp_clat, defer_list, gc_meta, gc_tbase, gc_task, gc_res};
+                     tmp_area, tmp_clon, tmp_clat, defer_list, gc_meta, gc_tbase, gc_task, gc_res, tmp_rowpos};
   for (void *p : scratch) pl->release(p);
   pl->release(pl->x_rowpos); pl->x_rowpos = nullptr;
   pl->rows_built = true;

@@ -166,10 +166,13 @@ void fgd_candidates_rect(int nsrc, FgCells S, const double *mask, FgRect R, FgPa
 // rect != null: the destination cells come from the rectilinear tables (D holds areas only)
 void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-              unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect = nullptr);
+              unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect = nullptr, int *row_cnt = nullptr,
+              int *tmp_rowpos = nullptr);
+// row_cnt / tmp_rowpos != null: accepted pairs take their destination-row slot in the clip kernel (tmp_rowpos[pair])
 void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-              unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect = nullptr);
+              unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect = nullptr, int *row_cnt = nullptr,
+              int *tmp_rowpos = nullptr);
 // accepted pairs -> exchange cells in canonical order (xoff = scan of the clip kernels' nacc), per-source-cell sums,
 // destination-row sizes and slots
 struct FgCompactIo {
@@ -179,6 +182,8 @@ struct FgCompactIo {
   int *x_src, *x_dst;
   double *x_area, *x_c1, *x_c2;
   int *row_cnt, *x_rowpos;
+  const int *tmp_rowpos;             // != null: row slots per PAIR from the clip kernels; row_ptr is final and perm is stored here
+  const int *row_ptr; int *perm;
   double *sums;                      // [3][nsrc] (order 2, zeroed: cells without exchange cells are not visited) or null
   const int *big_list;               // the chunk's cells with more than CP_SMALL pairs (from the candidate kernel)
   const int *big_cnt;

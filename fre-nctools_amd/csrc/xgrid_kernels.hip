@@ -1307,11 +1307,14 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
 // (The integrals loop over the polygon's edges and a wave runs as many iterations as its largest polygon has.  Re-binning the
 // block's 256 polygons by vertex count through LDS before the integrals, so that a wave sees polygons of equal size, was
 // measured: 502 us against 482 -- the extra barriers and the scattered LDS columns cost more than the divergence.)
+// row_cnt / tmp_rowpos (may be null): an accepted pair takes its slot in its destination row HERE -- a value-returning atomic whose
+// latency hides behind the clip arithmetic -- instead of in the compaction, a kernel that does little else than wait on memory; the
+// destination-row scan can then run before the compaction, which stores the row lists (perm) itself.
 template <int ORDER, bool RECT>
 __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D, FgRect R,
                                                             double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
                                                             int *defer_list, int *defer_cnt,
-                                                            unsigned long long *stats, unsigned *err)
+                                                            unsigned long long *stats, unsigned *err, int *row_cnt, int *tmp_rowpos)
 {
   __shared__ double2 sh_poly[8][CLIP_THREADS];
   if (RECT && *R.bad) return;
@@ -1333,6 +1336,7 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCe
       acc = true;
       tmp_area[p] = o.area;
       if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
+      if (row_cnt) tmp_rowpos[p] = atomicAdd(&row_cnt[d], 1);
     } else {
       ps.dst[p] = -1;
       below = (o.area == -2.0);                                  // rare (slivers below the 1e-6 ratio)
@@ -1371,7 +1375,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
                                                               const int *pair_src, int *pair_dst,
                                                               FgCells S, const double *mask, FgCells D, FgRect R,
                                                               double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
-                                                              unsigned long long *stats, unsigned *err)
+                                                              unsigned long long *stats, unsigned *err, int *row_cnt, int *tmp_rowpos)
 {
   __shared__ double2 sh_a[GEN_CAP][GEN_THREADS];
   __shared__ double2 sh_b[GEN_CAP][GEN_THREADS];
@@ -1471,6 +1475,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
       tmp_area[p] = o.area;
       if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
       atomicAdd(&nacc[s], 1);
+      if (row_cnt) tmp_rowpos[p] = atomicAdd(&row_cnt[d], 1);
     } else {
       pair_dst[p] = -1;
       if (o.area == -2.0) atomicAdd(&stats[FG_STAT_BELOW], 1ull);
@@ -1499,13 +1504,13 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
 // hide behind five blocks per CU; a lane-per-pair version that left the cells cut by a block boundary to one lane: 245 us.)
 #define CP_SPAN (256 + CP_SMALL)
 
-struct CpPair { int s, d, beg, cnt, li; long x0; int na; double a, l, t; bool mine; };
+struct CpPair { int s, d, beg, cnt, li, p; long x0; int na; double a, l, t; bool mine; };
 
 template <int ORDER>
 __device__ __forceinline__ CpPair d_cp_load(const FgPairSpace &ps, const FgCompactIo &io, int p, int p0, unsigned live_end, bool halo)
 {
   CpPair c;
-  c.s = 0; c.d = -1; c.beg = 0; c.cnt = 0; c.x0 = 0; c.na = 0; c.a = 0; c.l = 0; c.t = 0; c.mine = false; c.li = p - p0;
+  c.s = 0; c.d = -1; c.beg = 0; c.cnt = 0; c.x0 = 0; c.na = 0; c.a = 0; c.l = 0; c.t = 0; c.mine = false; c.li = p - p0; c.p = p;
   if ((unsigned)p < live_end) {
     c.s = ps.src[p]; c.d = ps.dst[p];
     c.beg = io.pair_beg[c.s]; c.cnt = io.pair_cnt[c.s];
@@ -1530,7 +1535,8 @@ __device__ __forceinline__ void d_cp_place(const FgCompactIo &io, const CpPair &
   const long pos = c.x0 + rank;
   io.x_src[pos] = c.s; io.x_dst[pos] = c.d; io.x_area[pos] = c.a;
   if (ORDER == 2) { io.x_c1[pos] = c.l; io.x_c2[pos] = c.t; sh_v[0][lb + rank] = c.a; sh_v[1][lb + rank] = c.l; sh_v[2][lb + rank] = c.t; }
-  io.x_rowpos[pos] = atomicAdd(&io.row_cnt[c.d], 1);
+  if (io.tmp_rowpos) io.perm[io.row_ptr[c.d] + io.tmp_rowpos[c.p]] = (int)pos;        // the row slot was taken by the clip kernel
+  else io.x_rowpos[pos] = atomicAdd(&io.row_cnt[c.d], 1);
 }
 
 #define RANK_WORDS 1024      // 65536 destination indices: 45 rows of a 1440-column grid
@@ -1611,7 +1617,8 @@ __device__ __forceinline__ void d_compact_big(int nsrc, const FgPairSpace &ps, c
           io.x_c1[pos] = l; io.x_c2[pos] = t;
           sval[0][rank - c0] = a; sval[1][rank - c0] = l; sval[2][rank - c0] = t;
         }
-        io.x_rowpos[pos] = atomicAdd(&io.row_cnt[d], 1);
+        if (io.tmp_rowpos) io.perm[io.row_ptr[d] + io.tmp_rowpos[p]] = (int)pos;
+        else io.x_rowpos[pos] = atomicAdd(&io.row_cnt[d], 1);
       }
       __syncthreads();
       if (ORDER == 2 && threadIdx.x < 3 && x0 + na <= io.xcap) {
@@ -1750,13 +1757,13 @@ void fgd_candidates1(int c0, int c1, FgCells S, const double *mask, FgBins b, co
 
 void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
                    double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-                   unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect)
+                   unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect, int *row_cnt, int *tmp_rowpos)
 {
   const long np = fgd_pairs_total(ps);
   if (np <= 0) return;
   const FgRect R = rect ? *rect : FgRect{};
   const int g = nblk(np, CLIP_THREADS);
-#define FG_LAUNCH_QUAD(O, RC) k_clip_quad<O, RC><<<g, CLIP_THREADS, 0, st>>>(ps, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err)
+#define FG_LAUNCH_QUAD(O, RC) k_clip_quad<O, RC><<<g, CLIP_THREADS, 0, st>>>(ps, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err, row_cnt, tmp_rowpos)
   if (order == 2) { if (rect) FG_LAUNCH_QUAD(2, true); else FG_LAUNCH_QUAD(2, false); }
   else            { if (rect) FG_LAUNCH_QUAD(1, true); else FG_LAUNCH_QUAD(1, false); }
 #undef FG_LAUNCH_QUAD
@@ -1764,13 +1771,13 @@ void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgC
 
 void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, FgCells D,
                       double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc, int *defer_list, int *defer_cnt,
-                      unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect)
+                      unsigned long long *stats, unsigned *err, hipStream_t st, const FgRect *rect, int *row_cnt, int *tmp_rowpos)
 {
   const long np = fgd_pairs_total(ps);
   if (np <= 0) return;
   int grid = nblk(np, GEN_THREADS); if (grid > 1024) grid = 1024;
   const FgRect R = rect ? *rect : FgRect{};
-#define FG_LAUNCH_GEN(O, RC) k_clip_general<O, RC><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, stats, err)
+#define FG_LAUNCH_GEN(O, RC) k_clip_general<O, RC><<<grid, GEN_THREADS, 0, st>>>(defer_list, defer_cnt, ps.src, ps.dst, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, stats, err, row_cnt, tmp_rowpos)
   if (order == 2) { if (rect) FG_LAUNCH_GEN(2, true); else FG_LAUNCH_GEN(2, false); }
   else            { if (rect) FG_LAUNCH_GEN(1, true); else FG_LAUNCH_GEN(1, false); }
 #undef FG_LAUNCH_GEN
