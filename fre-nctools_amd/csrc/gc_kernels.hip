@@ -977,6 +977,7 @@ __device__ __forceinline__ bool gc_plain_quad(const double *v, double *len2)
   return ok;
 }
 
+__device__ __forceinline__ void d_gc_order_append(const FgPairSpace &ps, const GcSplit &g, unsigned reg, int lane, int p, bool valid, int cnt);
 __global__ __launch_bounds__(64) void k_gc_screen(FgPairSpace ps, FgCells S, FgCells D, GcSplit g, unsigned *err)
 {
   const unsigned first = blockIdx.x * 64u, reg = first / (unsigned)ps.regcap;
@@ -1021,14 +1022,32 @@ __global__ __launch_bounds__(64) void k_gc_screen(FgPairSpace ps, FgCells S, FgC
   if (lane == 0 && total) wbase = atomicAdd(&g.ntask[treg * FG_FILL_STRIDE], (unsigned)total);
   wbase = __shfl(wbase, 0);
   const unsigned local = wbase + (unsigned)(incl - cnt), base = treg * g.tcap + local;
-  if (!live) return;
-  // every slot below min(ntask[r], tcap) of a region holds a well-formed task, also those of a pair that did not fit and goes to the list
-  unsigned need = meta & 0xffffu, t = local;
-  while (need) { const int bit = __ffs((int)need) - 1; need &= need - 1; if (t < g.tcap) g.task[treg * g.tcap + t] = ((unsigned)p << 4) | (unsigned)bit; t++; }
-  if (cnt && local + (unsigned)cnt > g.tcap) { defer = true; valid = false; }
-  if (defer) g.list[atomicAdd(g.list_cnt, 1)] = p;
-  g.meta[p] = meta;
-  g.tbase[p] = valid ? (int)base : -1;                     // -1: rejected, or on the list
+  if (live) {
+    // every slot below min(ntask[r], tcap) of a region holds a well-formed task, also those of a pair that did not fit and goes to the list
+    unsigned need = meta & 0xffffu, t = local;
+    while (need) { const int bit = __ffs((int)need) - 1; need &= need - 1; if (t < g.tcap) g.task[treg * g.tcap + t] = ((unsigned)p << 4) | (unsigned)bit; t++; }
+    if (cnt && local + (unsigned)cnt > g.tcap) { defer = true; valid = false; }
+    if (defer) g.list[atomicAdd(g.list_cnt, 1)] = p;
+    g.meta[p] = meta;
+    g.tbase[p] = valid ? (int)base : -1;                   // -1: rejected, or on the list
+  }
+  d_gc_order_append(ps, g, reg, lane, p, live && valid, cnt);
+}
+// the second half of k_gc_screen (every lane of the wave arrives here): the pairs for k_gc_walk, in their region's list
+__device__ __forceinline__ void d_gc_order_append(const FgPairSpace &ps, const GcSplit &g, unsigned reg, int lane, int p, bool valid, int cnt)
+{
+  const bool few = valid && cnt <= 2, many = valid && cnt > 2;
+  const unsigned long long mf = __ballot(few), mm = __ballot(many);
+  unsigned bf = 0, bm = 0;
+  if (lane == 0) {
+    if (mf) bf = atomicAdd(&g.ocnt[reg * FG_FILL_STRIDE], (unsigned)__popcll(mf));
+    if (mm) bm = atomicAdd(&g.ocnt[reg * FG_FILL_STRIDE + 1], (unsigned)__popcll(mm));
+  }
+  bf = __shfl(bf, 0); bm = __shfl(bm, 0);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int *o = g.order + (size_t)reg * ps.regcap;
+  if (few) o[bf + __popcll(mf & below)] = p;
+  if (many) o[(unsigned)ps.regcap - 1u - (bm + __popcll(mm & below))] = p;
 }
 
 __global__ __launch_bounds__(256) void k_gc_solve(FgPairSpace ps, FgCells S, FgCells D, GcSplit g)
@@ -1058,12 +1077,14 @@ __global__ __launch_bounds__(256) void k_gc_solve(FgPairSpace ps, FgCells S, FgC
   }
 }
 
+// a[k] for a run-time k without an indexed access: bit masks, not a ?: chain -- the optimizer turns the chain back into a table in
+// scratch memory (k_gc_walk then moved 2.9 GB per launch through it, profiles/r03_summary.md, and waited on every dependent load)
 __device__ __forceinline__ double gcw_sel8(const double *a, int k)
 {
-  double v = a[0];
+  long long v = 0;
 #pragma unroll
-  for (int m = 1; m < 8; m++) v = (k == m) ? a[m] : v;
-  return v;
+  for (int m = 0; m < 8; m++) v |= __double_as_longlong(a[m]) & -(long long)(k == m);
+  return __longlong_as_double(v);
 }
 // node lists of k_gc_walk: 4-bit refs in one 64-bit word, the intersect (0 / 1) and isInside flags as bit masks -- the 128-bit
 // byte codes of GcPacked cost three times the instructions per access; gl_get returns the same code (ref | intersect << 4 | inside << 6)
@@ -1134,142 +1155,175 @@ __device__ __forceinline__ int gcw_poly_add(double *lds, int lane, int &n, bool 
   return 0;
 }
 
+// The area of the output polygon -- n_out spherical angles, each through the exact acosl (~1300 instructions) -- is NOT computed by
+// the pair's own lane: a wave's 64 pairs hold 0 (rejected by the screen, empty, listed) to 8 vertices, and a per-lane loop ran
+// max-over-lanes iterations with 25.7 of 64 lanes live (PMC, profiles/r03_summary.md).  The (pair, vertex) items of the wave are
+// dealt round-robin to its lanes through LDS instead: every lane computes angles of whichever pairs have them, the owning lane
+// then adds its polygon's angles up in vertex order (great_circle_area's order, mosaic_util.c:763-787: the same sum).
 __global__ __launch_bounds__(64) void k_gc_walk(FgPairSpace ps, FgCells S, const double *mask, FgCells D, GcSplit g,
                                                 double *tmp_area, int *nacc, unsigned long long *stats, unsigned *err)
 {
   __shared__ double lds[GC_WALK_PTS * 3 * 64];
-  const unsigned first = blockIdx.x * 64u, reg = first / (unsigned)ps.regcap;
-  if (first - reg * (unsigned)ps.regcap >= ps.fill[reg * FG_FILL_STRIDE]) return;
-  const int lane = threadIdx.x, p = (int)first + lane;
-  if (!d_pair_live(ps, p)) return;
-  const int d = ps.dst[p];
-  if (d < 0) return;
-  const int t0 = g.tbase[p];
-  if (t0 < 0) return;                                      // on the list
-  unsigned meta = g.meta[p];
-  const int s = ps.src[p];
-  const double *A = S.verts + (size_t)s * 16, *B = D.verts + (size_t)d * 16;
-  bool bad = false;
-  for (unsigned edge = meta >> 24; edge; edge &= edge - 1) {             // corners near an edge plane of the other cell
-    const int bit = __ffs((int)edge) - 1;
-    const int in = (bit < 4) ? gc_inside4(A + bit * 3, B) : gc_inside4(B + (bit - 4) * 3, A);
-    if (in < 0) bad = true;
-    if (in > 0) meta |= 1u << (16 + bit);
-  }
-
-  GcL64 gl0, gl1;                                          // (two named values: a list indexed by L would live in scratch)
-  gl0.refs = gl1.refs = 0x3210ull; gl0.inter = gl1.inter = 0; gl0.n = gl1.n = 4;
-  gl0.inside = (meta >> 16) & 15u; gl1.inside = (meta >> 20) & 15u;
-  double iu0[8], iu1[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) { iu0[k] = -1.0; iu1[k] = -1.0; }
-  unsigned long long imeta = 0;                            // per intersection: i1 | i2 << 2 | inbound << 4
-  int nil = 0;
-  {
-    unsigned need = meta & 0xffffu;
-    // the first four results (a pair has 3.0 on average) in one round trip; the rest one by one
-    const int ntask = __popc(need);
-    double2 rpre[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) rpre[i] = ((const double2 *)g.res)[t0 + min(i, max(ntask - 1, 0))];
-    int ti = 0;
-    while (need && !bad) {
-      const int bit = __ffs((int)need) - 1;
-      need &= need - 1;
-      double2 r = rpre[0];
-#pragma unroll
-      for (int i = 1; i < 4; i++) r = (ti == i) ? rpre[i] : r;
-      if (ti >= 4) r = ((const double2 *)g.res)[t0 + ti];
-      ti++;
-      if (r.x < 0) continue;
-      const double u1 = r.x, u2 = fabs(r.y);
-      if (u1 > 1.5 || u1 < 1.e-6 || u1 > 1.0 - 1.e-6 || u2 < 1.e-6 || u2 > 1.0 - 1.e-6) { bad = true; break; }
-      const int inbound = (r.y < 0) ? 2 : 1, i1 = bit >> 2, i2 = bit & 3;
-      bool dup = false;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int m = (int)(imeta >> (6 * k));
-        if (k < nil && ((iu0[k] == u1 && (m & 3) == i1) || (iu1[k] == u2 && ((m >> 2) & 3) == i2))) dup = true;
-      }
-      if (dup) continue;
-      if (nil >= 8) { bad = true; break; }
-      const int iref = nil++;
-#pragma unroll
-      for (int k = 0; k < 8; k++) { if (k == iref) { iu0[k] = u1; iu1[k] = u2; } }
-      imeta |= (unsigned long long)(i1 | (i2 << 2) | (inbound << 4)) << (6 * iref);
-      if (gcw_insert(gl0, i1, u1, inbound, iu0, iref) || gcw_insert(gl1, i2, u2, 0, iu1, iref)) bad = true;
-    }
-  }
-
+  __shared__ double sh_ang[GC_WALK_PTS * 64];
+  __shared__ unsigned short sh_own[GC_WALK_PTS * 64];      // item -> lane | vertex << 6 | n_out << 9
+  // slot q of the region's list (k_gc_screen): the pairs with few tasks from the front, the others from the back
+  const unsigned first = blockIdx.x * 64u, reg = first / (unsigned)ps.regcap, qa0 = first - reg * (unsigned)ps.regcap;
+  const unsigned cnt_f = g.ocnt[reg * FG_FILL_STRIDE], cnt_b = g.ocnt[reg * FG_FILL_STRIDE + 1];
+  if (qa0 >= cnt_f && qa0 + 64u <= (unsigned)ps.regcap - cnt_b) return;                  // (block-uniform) no pair in these slots
+  const int lane = threadIdx.x;
+  const unsigned qa = qa0 + (unsigned)lane;
+  int p = -1, d = -1, t0 = -1, s = 0;
+  if (qa < cnt_f || qa >= (unsigned)ps.regcap - cnt_b) p = g.order[(size_t)reg * ps.regcap + qa];
+  if (p >= 0) { d = ps.dst[p]; if (d >= 0) { t0 = g.tbase[p]; s = ps.src[p]; } }
+  const bool live = d >= 0 && t0 >= 0;                     // else: rejected by the screen, or on the list
   int n_out = 0;
-  if (!bad) {
-    int nintersect = nil, firstx = -1;
-    if (nintersect > 1) for (int k = 0; k < nil; k++) if (((imeta >> (6 * k + 4)) & 3u) == 2u) { firstx = k; break; }
-    if (firstx >= 0) {
-      const int maxiter1 = nintersect;
-      int np = 0;
-      gcw_poly_add(lds, lane, np, false, 0, (unsigned)(4 + firstx) | (1u << 4), A, B, iu0, imeta);
-      nintersect--;
-      int L = 0, iter1 = 0, found1 = 0, found2 = 0, cur = firstx;
-      unsigned ccode = 0;
-      while (iter1 < maxiter1 && !bad) {
-        const GcL64 lw = L ? gl1 : gl0;                 // the walk only reads the lists
-        int k1 = -1;
-        for (int k = 0; k < lw.n; k++) { const unsigned c = gl_get(lw, k); if (GCN_INTER(c) == 1 && (int)GCN_REF(c) - 4 == cur) { k1 = k; break; } }
-        if (k1 < 0) { bad = true; break; }
-        int k2 = (k1 + 1 < lw.n) ? k1 + 1 : 0;
-        const int maxiter2 = lw.n;
-        int iter2 = 0;
-        found2 = 0;
-        while (iter2 < maxiter2) {
-          int t2_is_inter = 0;
-          const unsigned c2 = gl_get(lw, k2);
-          if (GCN_INTER(c2)) {
-            if ((int)GCN_REF(c2) - 4 == firstx) { found1 = 1; break; }
-            const unsigned c3 = gl_get(lw, (k2 + 1 < lw.n) ? k2 + 1 : 0);
-            found2 = 1;
-            t2_is_inter = 1;
-            if (GCN_INTER(c3) || GCN_INSIDE(c3) == 1) found2 = 0;
-          }
-          if (found2) { cur = (int)GCN_REF(c2) - 4; ccode = c2; break; }
-          if (gcw_poly_add(lds, lane, np, true, L, c2, A, B, iu0, imeta)) { bad = true; break; }
-          if (t2_is_inter) nintersect--;
-          k2 = (k2 + 1 < lw.n) ? k2 + 1 : 0;
-          iter2++;
-        }
-        if (bad || found1) break;
-        if (!found2) { bad = true; break; }
-        if (gcw_poly_add(lds, lane, np, true, L, ccode, A, B, iu0, imeta)) { bad = true; break; }
-        nintersect--;
-        L = 1 - L;
-        iter1++;
-      }
-      if (!found1 || nintersect > 0) bad = true;
-      n_out = (np < 3) ? 0 : np;
+  if (live) {
+    unsigned meta = g.meta[p];
+    const double *A = S.verts + (size_t)s * 16, *B = D.verts + (size_t)d * 16;
+    bool bad = false;
+    for (unsigned edge = meta >> 24; edge; edge &= edge - 1) {             // corners near an edge plane of the other cell
+      const int bit = __ffs((int)edge) - 1;
+      const int in = (bit < 4) ? gc_inside4(A + bit * 3, B) : gc_inside4(B + (bit - 4) * 3, A);
+      if (in < 0) bad = true;
+      if (in > 0) meta |= 1u << (16 + bit);
     }
-    if (!bad && n_out == 0) {
+
+    GcL64 gl0, gl1;                                          // (two named values: a list indexed by L would live in scratch)
+    gl0.refs = gl1.refs = 0x3210ull; gl0.inter = gl1.inter = 0; gl0.n = gl1.n = 4;
+    gl0.inside = (meta >> 16) & 15u; gl1.inside = (meta >> 20) & 15u;
+    double iu0[8], iu1[8];
 #pragma unroll
-      for (int L = 0; L < 2; L++) {                        // grid1 inside grid2 (:1839-1870), then grid2 inside grid1 (:1873-1904)
-        const GcL64 lw = L ? gl1 : gl0;
-        int nin = 0;
-        for (int k = 0; k < lw.n; k++) { const unsigned c = gl_get(lw, k); if (GCN_INTER(c) != 1 && GCN_INSIDE(c) == 1) nin++; }
-        if (n_out == 0 && nin == 4) {
-          int np = 0;
-          for (int k = 0; k < 4; k++) gcw_poly_add(lds, lane, np, false, L, gl_get(lw, k), A, B, iu0, imeta);
-          n_out = 4;
+    for (int k = 0; k < 8; k++) { iu0[k] = -1.0; iu1[k] = -1.0; }
+    unsigned long long imeta = 0;                            // per intersection: i1 | i2 << 2 | inbound << 4
+    int nil = 0;
+    {
+      unsigned need = meta & 0xffffu;
+      // the first four results (a pair has 3.0 on average) in one round trip; the rest one by one
+      const int ntask = __popc(need);
+      double2 rpre[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) rpre[i] = ((const double2 *)g.res)[t0 + min(i, max(ntask - 1, 0))];
+      int ti = 0;
+      while (need && !bad) {
+        const int bit = __ffs((int)need) - 1;
+        need &= need - 1;
+        double2 r;
+        {
+          long long rx = 0, ry = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) { const long long mk = -(long long)(ti == i); rx |= __double_as_longlong(rpre[i].x) & mk; ry |= __double_as_longlong(rpre[i].y) & mk; }
+          r.x = __longlong_as_double(rx); r.y = __longlong_as_double(ry);
+        }
+        if (ti >= 4) r = ((const double2 *)g.res)[t0 + ti];
+        ti++;
+        if (r.x < 0) continue;
+        const double u1 = r.x, u2 = fabs(r.y);
+        if (u1 > 1.5 || u1 < 1.e-6 || u1 > 1.0 - 1.e-6 || u2 < 1.e-6 || u2 > 1.0 - 1.e-6) { bad = true; break; }
+        const int inbound = (r.y < 0) ? 2 : 1, i1 = bit >> 2, i2 = bit & 3;
+        bool dup = false;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int m = (int)(imeta >> (6 * k));
+          if (k < nil && ((iu0[k] == u1 && (m & 3) == i1) || (iu1[k] == u2 && ((m >> 2) & 3) == i2))) dup = true;
+        }
+        if (dup) continue;
+        if (nil >= 8) { bad = true; break; }
+        const int iref = nil++;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { if (k == iref) { iu0[k] = u1; iu1[k] = u2; } }
+        imeta |= (unsigned long long)(i1 | (i2 << 2) | (inbound << 4)) << (6 * iref);
+        if (gcw_insert(gl0, i1, u1, inbound, iu0, iref) || gcw_insert(gl1, i2, u2, 0, iu1, iref)) bad = true;
+      }
+    }
+
+    if (!bad) {
+      int nintersect = nil, firstx = -1;
+      if (nintersect > 1) for (int k = 0; k < nil; k++) if (((imeta >> (6 * k + 4)) & 3u) == 2u) { firstx = k; break; }
+      if (firstx >= 0) {
+        const int maxiter1 = nintersect;
+        int np = 0;
+        gcw_poly_add(lds, lane, np, false, 0, (unsigned)(4 + firstx) | (1u << 4), A, B, iu0, imeta);
+        nintersect--;
+        int L = 0, iter1 = 0, found1 = 0, found2 = 0, cur = firstx;
+        unsigned ccode = 0;
+        while (iter1 < maxiter1 && !bad) {
+          const GcL64 lw = L ? gl1 : gl0;                 // the walk only reads the lists
+          int k1 = -1;
+          for (int k = 0; k < lw.n; k++) { const unsigned c = gl_get(lw, k); if (GCN_INTER(c) == 1 && (int)GCN_REF(c) - 4 == cur) { k1 = k; break; } }
+          if (k1 < 0) { bad = true; break; }
+          int k2 = (k1 + 1 < lw.n) ? k1 + 1 : 0;
+          const int maxiter2 = lw.n;
+          int iter2 = 0;
+          found2 = 0;
+          while (iter2 < maxiter2) {
+            int t2_is_inter = 0;
+            const unsigned c2 = gl_get(lw, k2);
+            if (GCN_INTER(c2)) {
+              if ((int)GCN_REF(c2) - 4 == firstx) { found1 = 1; break; }
+              const unsigned c3 = gl_get(lw, (k2 + 1 < lw.n) ? k2 + 1 : 0);
+              found2 = 1;
+              t2_is_inter = 1;
+              if (GCN_INTER(c3) || GCN_INSIDE(c3) == 1) found2 = 0;
+            }
+            if (found2) { cur = (int)GCN_REF(c2) - 4; ccode = c2; break; }
+            if (gcw_poly_add(lds, lane, np, true, L, c2, A, B, iu0, imeta)) { bad = true; break; }
+            if (t2_is_inter) nintersect--;
+            k2 = (k2 + 1 < lw.n) ? k2 + 1 : 0;
+            iter2++;
+          }
+          if (bad || found1) break;
+          if (!found2) { bad = true; break; }
+          if (gcw_poly_add(lds, lane, np, true, L, ccode, A, B, iu0, imeta)) { bad = true; break; }
+          nintersect--;
+          L = 1 - L;
+          iter1++;
+        }
+        if (!found1 || nintersect > 0) bad = true;
+        n_out = (np < 3) ? 0 : np;
+      }
+      if (!bad && n_out == 0) {
+#pragma unroll
+        for (int L = 0; L < 2; L++) {                        // grid1 inside grid2 (:1839-1870), then grid2 inside grid1 (:1873-1904)
+          const GcL64 lw = L ? gl1 : gl0;
+          int nin = 0;
+          for (int k = 0; k < lw.n; k++) { const unsigned c = gl_get(lw, k); if (GCN_INTER(c) != 1 && GCN_INSIDE(c) == 1) nin++; }
+          if (n_out == 0 && nin == 4) {
+            int np = 0;
+            for (int k = 0; k < 4; k++) gcw_poly_add(lds, lane, np, false, L, gl_get(lw, k), A, B, iu0, imeta);
+            n_out = 4;
+          }
         }
       }
     }
+    if (bad) { g.list[g.list_cap - 1 - atomicAdd(g.list2_cnt, 1)] = p; n_out = 0; }
+    else if (n_out == 0) ps.dst[p] = -1;
   }
-  if (bad) { g.list[g.list_cap - 1 - atomicAdd(g.list2_cnt, 1)] = p; return; }
-  if (n_out == 0) { ps.dst[p] = -1; return; }
+  // --- the wave's (pair, vertex) items, dealt to its lanes
+  const unsigned incl = (unsigned)n_out + 0u;
+  unsigned pre = incl;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(pre, o, 64); if (lane >= o) pre += v; }
+  const int T = (int)__shfl(pre, 63), off = (int)pre - n_out;
+  for (int i = 0; i < n_out; i++) sh_own[off + i] = (unsigned short)(lane | (i << 6) | (n_out << 9));
+  __syncthreads();
+  for (int t = lane; t < T; t += 64) {
+    const unsigned w = sh_own[t];
+    const int l = (int)(w & 63u), i = (int)(w >> 6) & 7, n = (int)(w >> 9);
+    const int i1 = (i + 1 < n) ? i + 1 : 0, i2 = (i1 + 1 < n) ? i1 + 1 : 0;
+#define GCW_PL(k, c) lds[((k) * 3 + (c)) * 64 + l]
+    const double p0[3] = {GCW_PL(i, 0), GCW_PL(i, 1), GCW_PL(i, 2)}, p1[3] = {GCW_PL(i1, 0), GCW_PL(i1, 1), GCW_PL(i1, 2)},
+                 p2[3] = {GCW_PL(i2, 0), GCW_PL(i2, 1), GCW_PL(i2, 2)};
+#undef GCW_PL
+#if defined(FG_EXP) && FG_EXP == 3
+    sh_ang[t] = p0[0] + p1[1] + p2[2];               // (timing experiment: no angles)
+#else
+    sh_ang[t] = gc_spherical_angle<true>(p1, p2, p0);
+#endif
+  }
+  __syncthreads();
+  if (n_out == 0) return;
   double sum = 0.0;                                        // great_circle_area, mosaic_util.c:763-787
-  for (int i = 0; i < n_out; i++) {
-    const int i1 = (i + 1 < n_out) ? i + 1 : 0, i2 = (i1 + 1 < n_out) ? i1 + 1 : 0;
-    const double p0[3] = {GCW_P(i, 0), GCW_P(i, 1), GCW_P(i, 2)}, p1[3] = {GCW_P(i1, 0), GCW_P(i1, 1), GCW_P(i1, 2)},
-                 p2[3] = {GCW_P(i2, 0), GCW_P(i2, 1), GCW_P(i2, 2)};
-    sum += gc_spherical_angle<true>(p1, p2, p0);
-  }
+  for (int i = 0; i < n_out; i++) sum += sh_ang[off + i];
   const double area1 = S.area[s], area2 = D.area[d];
   const double xarea = (sum - (n_out - 2.) * GC_PI) * GC_RADIUS * GC_RADIUS * (mask ? mask[s] : 1.0);
   const double min_area = (area1 < area2) ? area1 : area2;

@@ -669,7 +669,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   const size_t ztick = 128;
   const size_t zlb = (size_t)(t_bins + t_rows + t_comp) * sizeof(unsigned long long);
   const size_t zints = ((size_t)(2 * (nslots + 1) + ndst + 1 + nsrc + 1) * sizeof(int) + 15) / 16 * 16;
-  const size_t zgc = gc ? (size_t)K * FG_NREG * FG_FILL_STRIDE * sizeof(unsigned) : 0;        // task counters of the great-circle clip
+  const size_t zgc = gc ? 2 * (size_t)K * FG_NREG * FG_FILL_STRIDE * sizeof(unsigned) : 0;    // great-circle clip: task counters, then the counters of the walk's pair lists
   const size_t zbytes = zc + zfill + ztick + zlb + zints + zgc;
   char *zero_blk = pl->alloc<char>(zbytes);
   int *bin_start = pl->alloc<int>(nslots + 1);
@@ -695,9 +695,10 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   const long tcap_all = tcap_reg * K * FG_NREG;
   unsigned *gc_meta = gc_split ? pl->alloc<unsigned>(npairs + 1) : nullptr;
   int *gc_tbase = gc_split ? pl->alloc<int>(npairs + 1) : nullptr;
+  int *gc_order = gc_split ? pl->alloc<int>(npairs + 1) : nullptr;
   unsigned *gc_task = gc_split ? pl->alloc<unsigned>(tcap_all + 1) : nullptr;
   double *gc_res = gc_split ? pl->alloc<double>(2 * (size_t)tcap_all + 2) : nullptr;
-  if (gc_split && (!gc_meta || !gc_tbase || !gc_task || !gc_res)) return fail(FG_ERR_HIP, "out of device memory");
+  if (gc_split && (!gc_meta || !gc_tbase || !gc_order || !gc_task || !gc_res)) return fail(FG_ERR_HIP, "out of device memory");
   pl->xoff = pl->alloc<int>(nsrc + 1);
   pl->x_src = pl->alloc<int>(nx_alloc + 1); pl->x_dst = pl->alloc<int>(nx_alloc + 1);
   pl->x_area = pl->alloc<double>(nx_alloc + 1);
@@ -814,7 +815,8 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
         const long tcap_k = tcap_reg * FG_NREG;
         unsigned *ntask = (unsigned *)(zero_blk + zbytes - zgc) + (size_t)k * FG_NREG * FG_FILL_STRIDE;
         GcSplit g{gc_meta + k * pcap_k, gc_tbase + k * pcap_k, gc_task + k * tcap_k, gc_res + 2 * k * tcap_k, (unsigned)tcap_reg,
-                  ntask, dl, &dc->defer_cnt[k], &dc->gc_list2_cnt[k], pcap_k};
+                  ntask, dl, &dc->defer_cnt[k], &dc->gc_list2_cnt[k], pcap_k,
+                  gc_order + k * pcap_k, ntask + (size_t)K * FG_NREG * FG_FILL_STRIDE};
         fgd_gc_clip_split(q, pl->S, pl->mask_dev, pl->D, ta, nacc, g, dc->stats, dc->err, sb, K == 1 ? pl->stream_b : nullptr, gc_e1, gc_e2);
       } else
         fgd_gc_clip(q, pl->S, pl->mask_dev, pl->D, ta, nacc, dl, &dc->defer_cnt[k], dc->stats, dc->err, sb);
@@ -897,7 +899,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pl->rect_tab.bad = nullptr;                          // (lives in the scratch block released below; nothing reads it after the search)
   // scratch no longer needed
   void *scratch[] = {zero_blk, bin_start, bin_entries, heavy_list, big_list, pair_beg, pair_cnt, ps.src, ps.dst,
-                     tmp_area, tmp_clon, tmp_clat, defer_list, gc_meta, gc_tbase, gc_task, gc_res, tmp_rowpos};
+                     tmp_area, tmp_clon, tmp_clat, defer_list, gc_meta, gc_tbase, gc_order, gc_task, gc_res, tmp_rowpos};
   for (void *p : scratch) pl->release(p);
   pl->release(pl->x_rowpos); pl->x_rowpos = nullptr;
   pl->rows_built = true;

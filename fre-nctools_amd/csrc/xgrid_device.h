@@ -293,6 +293,11 @@ struct GcSplit {
   int *list, *list_cnt;    // pairs for the one-kernel version (k_gc_clip_list): from k_gc_screen and k_gc_solve, upwards from list[0]
   int *list2_cnt;          // ... from k_gc_walk, downwards from list[list_cap - 1]
   long list_cap;
+  // the pairs k_gc_walk works on, listed by k_gc_screen region by region (a pair's own region of the pair list, so a region's list
+  // cannot outgrow regcap): pairs with at most two edge-pair tasks from the front of the region, the others from its back -- no lane
+  // is spent on a pair the screen rejected (a third of the candidates) and a wave sees pairs of one kind
+  int *order;              // [nreg * regcap]
+  unsigned *ocnt;          // ocnt[r * FG_FILL_STRIDE] front count, [r * FG_FILL_STRIDE + 1] back count
 };
 void fgd_gc_clip_split(FgPairSpace ps, FgCells S, const double *mask, FgCells D, double *tmp_area, int *nacc, GcSplit g,
                        unsigned long long *stats, unsigned *err, hipStream_t st, hipStream_t st2, hipEvent_t e1, hipEvent_t e2);
