@@ -735,7 +735,6 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     FgRect &R = pl->rect_tab;
     R.hdr = rect_blk; R.lat_ax = rect_blk + 8; R.lon_ax = rect_blk + 8 + (pl->ny_out + 1); R.col = rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1);
     R.bad = &dc->rect_bad; R.nx = pl->nx_out; R.ny = pl->ny_out;
-    if (g_search_cull) fgd_band_keys(d_lat_out, (long)(pl->nx_out + 1) * (pl->ny_out + 1), dc->band_keys, st);
     fgd_rect_tables(d_lon_out, d_lat_out, pl->nx_out, pl->ny_out, rect_blk, rect_blk + 8, rect_blk + 8 + (pl->ny_out + 1),
                     rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1), &dc->rect_bad, dc->err, st, dst_tlon);
     if (pl->polys.npoly) fgd_polylist_records(pl->polys, pl->S, pl->src_idx_f, pl->sums, &R, heavy_list, &dc->heavy_cnt, dc->err, st);
@@ -848,8 +847,10 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     io.fill_all = (k == K - 1) ? ps.fill : nullptr; io.nreg_all = nreg_k * K;
     io.dc = dc; io.xcap = nx_alloc;
     const int nk = cb[k + 1] - cb[k];
-    fgd_exclusive_scan1(nacc + cb[k], nk, pl->xoff + cb[k], lb_comp + tile0, &tickets[2 + k], &dc->xtot[k], dc->err, st, k ? &dc->xtot[k - 1] : nullptr);
-    if (early_rows) fgd_exclusive_scan1(row_cnt, ndst, pl->csr.row_ptr, lb_rows, &tickets[1], &dc->rows_total, dc->err, st);
+    if (early_rows)       // accepted pairs per source cell -> xoff, destination-row counts -> row_ptr: one launch
+      fgd_exclusive_scan2(nacc, nk, pl->xoff, lb_comp, &tickets[2], &dc->xtot[0], row_cnt, ndst, pl->csr.row_ptr, lb_rows, &tickets[1], &dc->rows_total, dc->err, st);
+    else
+      fgd_exclusive_scan1(nacc + cb[k], nk, pl->xoff + cb[k], lb_comp + tile0, &tickets[2 + k], &dc->xtot[k], dc->err, st, k ? &dc->xtot[k - 1] : nullptr);
     tile0 += fgd_scan_tiles(nk);
     fgd_compact(order, nsrc, q, io, st);
     pt.end();

@@ -121,6 +121,10 @@ long fgd_scan_tiles(long n);
 void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *status, unsigned *ticket,
                          unsigned long long *total_dev, unsigned *err, hipStream_t st, const unsigned long long *base_dev = nullptr);
 
+void fgd_exclusive_scan2(const int *in_a, long n_a, int *out_a, unsigned long long *status_a, unsigned *ticket_a, unsigned long long *total_a,
+                         const int *in_b, long n_b, int *out_b, unsigned long long *status_b, unsigned *ticket_b, unsigned long long *total_b,
+                         unsigned *err, hipStream_t st);
+
 // per-cell records of the source tiles and of the destination tile in ONE launch; also counts the destination cells into
 // their bins (slot_cnt), fills src_idx_f, zeroes sums[3][nsrc] (may be null) and stores the tile descriptors at tiles_out
 void fgd_cell_struct2(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, FgCells D,

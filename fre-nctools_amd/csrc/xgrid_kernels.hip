@@ -170,7 +170,64 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan1(const int *in, long n, i
   if (threadIdx.x == 0 && n >= base && n < base + SCAN_CHUNK) *total_out = excl + tot;      // the tile holding out[n]
 }
 
+// two independent scans in one launch (blockIdx.y picks the job): the accept-count scan and the destination-row scan of a search
+// depend on the same kernel and feed the same one -- a launch boundary less on a path that is launch bound for small bands
+struct FgScanJob { const int *in; long n; int *out; unsigned long long *status; unsigned *ticket; unsigned long long *total; };
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan2(FgScanJob a, FgScanJob b, unsigned *err, int by_ticket)
+{
+  const FgScanJob j = blockIdx.y ? b : a;
+  const long nt = (j.n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  if ((long)blockIdx.x >= nt) return;
+  __shared__ unsigned tile[SCAN_CHUNK];
+  __shared__ int sh_t;
+  __shared__ unsigned long long sh_excl;
+  // by_ticket == 0: the whole grid is resident at once, no tile can wait for one that has not started
+  if (by_ticket) { if (threadIdx.x == 0) sh_t = (int)atomicAdd(j.ticket, 1u); __syncthreads(); }
+  const int t = by_ticket ? sh_t : (int)blockIdx.x;
+  const long base = (long)t * SCAN_CHUNK;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    const int li = k * SCAN_THREADS + threadIdx.x;
+    const long idx = base + li;
+    tile[li] = (idx < j.n) ? (unsigned)j.in[idx] : 0u;
+  }
+  __syncthreads();
+  unsigned loc[SCAN_ITEMS];
+  unsigned s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { loc[k] = tile[threadIdx.x * SCAN_ITEMS + k]; s += loc[k]; }
+  unsigned tot;
+  const unsigned inc = block_incl_scan(s, &tot);
+  if (threadIdx.x < 64) {
+    const unsigned long long e = d_lookback_wave(j.status, t, (unsigned long long)tot, err);
+    if (threadIdx.x == 0) sh_excl = e;
+  }
+  __syncthreads();
+  const unsigned long long excl = sh_excl;
+  unsigned run = (unsigned)excl + inc - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { tile[threadIdx.x * SCAN_ITEMS + k] = run; run += loc[k]; }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    const int li = k * SCAN_THREADS + threadIdx.x;
+    const long idx = base + li;
+    if (idx <= j.n) j.out[idx] = (int)tile[li];
+  }
+  if (threadIdx.x == 0 && j.n >= base && j.n < base + SCAN_CHUNK) *j.total = excl + tot;
+}
+
 long fgd_scan_tiles(long n) { if (n < 0) n = 0; return (n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK; }
+void fgd_exclusive_scan2(const int *in_a, long n_a, int *out_a, unsigned long long *status_a, unsigned *ticket_a, unsigned long long *total_a,
+                         const int *in_b, long n_b, int *out_b, unsigned long long *status_b, unsigned *ticket_b, unsigned long long *total_b,
+                         unsigned *err, hipStream_t st)
+{
+  if (n_a < 0) n_a = 0;
+  if (n_b < 0) n_b = 0;
+  const long nt = std::max(fgd_scan_tiles(n_a), fgd_scan_tiles(n_b));
+  k_scan2<<<dim3((unsigned)nt, 2), SCAN_THREADS, 0, st>>>(FgScanJob{in_a, n_a, out_a, status_a, ticket_a, total_a},
+                                                         FgScanJob{in_b, n_b, out_b, status_b, ticket_b, total_b}, err, 2 * nt > 1024 ? 1 : 0);
+}
 
 void fgd_exclusive_scan1(const int *in, long n, int *out, unsigned long long *status, unsigned *ticket,
                          unsigned long long *total_dev, unsigned *err, hipStream_t st, const unsigned long long *base_dev)
@@ -894,6 +951,13 @@ __global__ __launch_bounds__(256) void k_cell_struct2r(FgTileSet ts, const FgTil
   if (*R.bad) return;
   if (ts.n && (int)threadIdx.x < ts.n) sh_tiles[threadIdx.x] = ts.t[threadIdx.x];
   const bool isD = (int)blockIdx.x >= nbS;
+  // the band of a culling search: the latitude axis gives it (rows ascend) -- no reduction over the corner array, no launch for it
+  __shared__ unsigned long long sh_band[2];
+  if (cull) {
+    if (threadIdx.x == 0) { sh_band[0] = d_ord_key(R.lat_ax[R.ny]); sh_band[1] = ~d_ord_key(R.lat_ax[0]); }
+    __syncthreads();
+    band_keys = sh_band;
+  }
   if (cull && !isD && band_keys[0]) {                      // (as in k_cell_struct2: blocks wholly outside the band leave early)
     __syncthreads();
     const FgTile *tl0 = ts.n ? sh_tiles : tiles_in;
