@@ -104,8 +104,10 @@ static int rd_atts(Rd *r, int *natt, NcAtt **out)
     a[k].name = rd_name(r);
     a[k].type = (int)rd_u32(r);
     a[k].n = rd_size(r);
-    size_t w = tsize(a[k].type), bytes = w * a[k].n;
-    if (!w || r->pos + bytes > r->n) { r->bad = 1; break; }
+    size_t w = tsize(a[k].type);
+    /* (a 64-bit CDF-5 count: compare before multiplying, or w * n wraps and the copy below runs past a small buffer) */
+    if (!w || r->pos > r->n || a[k].n > (uint64_t)(r->n - r->pos) / w) { r->bad = 1; break; }
+    const size_t bytes = w * (size_t)a[k].n;
     a[k].val = (unsigned char *)malloc(bytes + 1);
     if (!a[k].val) { r->bad = 1; break; }
     swap_copy(a[k].val, r->p + r->pos, a[k].n, w);
@@ -194,7 +196,8 @@ int fg_nc_open(const char *path, fg_ncfile **out)
         }
       }
     }
-    const int truncated = r.bad && (size_t)got == cap;      /* ran off the end of what was read: read more and parse again */
+    /* ran off the end of what was read AND the file has more: read more and parse again (never past the file's own size) */
+    const int truncated = r.bad && (size_t)got == cap && r.pos + 8 > (size_t)got;
     free(buf);
     if (!r.bad) break;
     nc_free(f); f = NULL;
@@ -265,6 +268,11 @@ static double att_elem(const NcAtt *a, uint64_t i)
     case FG_NC_SHORT: { int16_t v; memcpy(&v, a->val + 2 * i, 2); return v; }
     case FG_NC_INT: { int32_t v; memcpy(&v, a->val + 4 * i, 4); return v; }
     case FG_NC_FLOAT: { float v; memcpy(&v, a->val + 4 * i, 4); return v; }
+    case 7 /* NC_UBYTE */: return ((unsigned char *)a->val)[i];
+    case 8 /* NC_USHORT */: { uint16_t v; memcpy(&v, a->val + 2 * i, 2); return v; }
+    case 9 /* NC_UINT */: { uint32_t v; memcpy(&v, a->val + 4 * i, 4); return v; }
+    case 10 /* NC_INT64 */: { int64_t v; memcpy(&v, a->val + 8 * i, 8); return (double)v; }
+    case 11 /* NC_UINT64 */: { uint64_t v; memcpy(&v, a->val + 8 * i, 8); return (double)v; }
     default: { double v; memcpy(&v, a->val + 8 * i, 8); return v; }
   }
 }

@@ -212,8 +212,14 @@ class Sweep:
         self.ncells_in = int(lib().fg_plan_ncells_in(self.plans[0]._h))
         self.ndst = [int(lib().fg_plan_ncells_out(p._h)) for p in self.plans]
 
-    def run(self, host_in, outs, scale=0.0, offset=0.0, missing=-1.0e20):
-        """host_in [nlev][ncells_in] of in_dtype; outs[p] [nlev][ndst_p] of out_dtype (numpy arrays, ideally HostBuffer.array)."""
+    def run(self, host_in, outs, scale=0.0, offset=0.0, missing=-1.0e20, has_missing=False):
+        """host_in [nlev][ncells_in] of in_dtype; outs[p] [nlev][ndst_p] of out_dtype (numpy arrays, ideally HostBuffer.array).
+        `missing` only steers the scale / offset conversion (values equal to it are left alone, fregrid_util.c:2114-2123): the
+        streamed remap itself treats every value as data.  A variable that HAS missing values (has_missing: its file carries
+        missing_value / _FillValue, read_field_levels' meta["missing"] is not None) must go level by level through
+        XgridPlan.apply(has_missing=True) -- conserve_interp.c:544 forbids nz > 1 for it -- so that case is refused here."""
+        if has_missing and host_in.shape[0] > 1:
+            raise ValueError("conserve_interp: has_missing should be false when nz > 1 (a variable with missing values cannot take the streamed sweep)")
         a = host_in
         assert a.dtype == self.in_dtype and a.flags.c_contiguous and a.shape[1] == self.ncells_in
         nlev = a.shape[0]

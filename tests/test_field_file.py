@@ -131,3 +131,48 @@ def test_rejects_hdf5_and_garbage(tmp_path):
     open(p, "wb").write(b"not a file")
     with pytest.raises(IOError):
         NC.NcFile(p)
+
+
+def test_malformed_cdf5_headers_are_refused_under_asan(tmp_path):
+    """a CDF-5 header is 64-bit -- an attribute count whose byte size wraps (2^61 doubles = 0 bytes mod 2^64) must be refused
+    before it is multiplied, not copied; and a header that fails to parse must not make the reader re-read ever larger pieces of
+    a file that has no more bytes.  csrc/field_file.c compiled with -fsanitize=address,undefined and run on crafted files."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "fre-nctools_amd", "csrc", "field_file.c")
+    drv = tmp_path / "drv.c"
+    drv.write_text('#include <stdio.h>\n#include "fregrid_hip.h"\n'
+                   'int main(int c, char **v) { int k, bad = 0; for (k = 1; k < c; k++) { fg_ncfile *f = 0; int rc = fg_nc_open(v[k], &f);\n'
+                   '  printf("%s -> %d %s\\n", v[k], rc, rc ? fg_nc_last_error() : "ok"); if (!rc) { fg_nc_close(f); bad = 1; } } return bad; }\n')
+    exe = str(tmp_path / "drv")
+    r = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", os.path.join(root, "include"),
+                        str(drv), src, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    u32 = lambda v: struct.pack(">I", v)
+    u64 = lambda v: struct.pack(">Q", v)
+    name = lambda s: u64(len(s)) + s + b"\0" * (-len(s) % 4)
+    head = b"CDF\x05" + u64(0) + u32(0) + u64(0)                       # numrecs 0, no dimensions
+    cases = {
+        "wrap.nc": head + u32(12) + u64(1) + name(b"a") + u32(6) + u64((1 << 61) + 1) + b"\0" * 64,        # global attribute: 2^61 + 1 doubles
+        "huge.nc": head + u32(12) + u64(1) + name(b"a") + u32(6) + u64(1 << 40) + b"\0" * 64,              # 8 TiB of attribute values
+        "trunc.nc": (head + u32(12) + u64(3) + name(b"a") + u32(6) + u64(2) + b"\0" * 16)[:-9],            # cut in the middle of a value
+        "badtype.nc": head + u32(12) + u64(1) + name(b"a") + u32(99) + u64(1) + b"\0" * 16,                # unknown attribute type
+    }
+    paths = []
+    for fn, blob in cases.items():
+        p = tmp_path / fn
+        p.write_bytes(blob); paths.append(str(p))
+    r = subprocess.run([exe] + paths, capture_output=True, text=True, timeout=60, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    assert r.stdout.count("malformed header") == len(cases), r.stdout
+    # ... and the unsigned / 64-bit attribute types of CDF-5 decode to their values
+    good = tmp_path / "u.nc"
+    good.write_bytes(head + u32(12) + u64(2) + name(b"u") + u32(9) + u64(1) + struct.pack(">I", 4000000000) +
+                     name(b"q") + u32(10) + u64(1) + struct.pack(">q", -5) + u32(0) + u64(0))
+    f = NC.NcFile(str(good))
+    import ctypes as C
+    val = (C.c_double * 1)()
+    assert fg.lib().fg_nc_get_att_double(f._h, -1, b"u", val, 1) == 1 and val[0] == 4000000000.0
+    assert fg.lib().fg_nc_get_att_double(f._h, -1, b"q", val, 1) == 1 and val[0] == -5.0
+    f.close()
