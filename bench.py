@@ -405,7 +405,7 @@ def main():
     ap.add_argument("--apply-steps", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--no-phase-timing", action="store_true", help="skip the separate pass that records per-phase HIP events")
-    ap.add_argument("--legs", default="all", help="comma list of extra legs: gc,pcie,config4,config5,cpu,c768,c768gc (or all / none); "
+    ap.add_argument("--legs", default="all", help="comma list of extra legs: gc,pcie,config4,config5,cpu,c768,c768gc,config5_full (or all / none); "
                                                   "all = the first five; with --gpus N > 1 the c768 jobs always run")
     ap.add_argument("--cpu-rows", type=int, default=32, help="source rows in the CPU baseline sample (0 = skip)")
     ap.add_argument("--gc-steps", type=int, default=3, help="timed great-circle searches of the same grids (N=1 only; 0 = skip)")
@@ -811,6 +811,8 @@ def main():
             line["config4"] = config4_leg(fg, torch, dev, local_rank)
         if world == 1 and "config5" in legs:
             line["config5"] = config5_leg(fg, torch, dev, local_rank)
+        if world == 1 and "config5_full" in legs:      # BASELINE config 5 at its stated size (50 fields x 365 steps x 50 levels): ~2.5 minutes, not in `all`
+            line["config5_full"] = config5_leg(fg, torch, dev, local_rank, nz=50, nt=365, nfields=50)
         if world == 1 and args.cpu_rows > 0 and "cpu" in legs:
             cb, _, _ = cpu_baseline(fg, lon, lat, lo, la, ni, nlon, nlat, args.cpu_rows)
             line["cpu_baseline"] = cb
