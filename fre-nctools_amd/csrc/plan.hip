@@ -873,7 +873,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   if (hc->total[0] > 2000000000ull) return fail(FG_ERR_ARG, "bin table too large");
   if (hc->total[3] > (unsigned long long)ps.regcap) {
     if (hc->total[3] > 2000000000ull / (unsigned long long)ps.nreg) return fail(FG_ERR_CAPACITY, "candidate pair list exceeds 2^31 entries");
-    caps->regcap = (int)((hc->total[3] + 255) / 256 * 256);
+    caps->regcap = (int)((hc->total[3] + FG_REG_ALIGN - 1) / FG_REG_ALIGN * FG_REG_ALIGN);
     return FG_RETRY;
   }
   if (hc->err[0] & 8u) return fail(FG_ERR_ARG, "a grid corner latitude lies outside [-pi/2, pi/2] (radians expected)");
@@ -935,7 +935,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
   // regions of the pair list: a run of 256 source cells appends to one region; at least four such runs per region on average, so
   // that small grids do not pile their pairs into a few small regions
   caps.nreg = (int)std::max(1L, std::min((long)FG_NREG, ((long)pl->nsrc + 1023) / 1024));
-  caps.regcap = exact ? 0 : (int)((cap_pairs / caps.nreg + 255) / 256 * 256);
+  caps.regcap = exact ? 0 : (int)((cap_pairs / caps.nreg + FG_REG_ALIGN - 1) / FG_REG_ALIGN * FG_REG_ALIGN);
   caps.rect = g_search_rect && rect_hint && !gc_in && !boxm && pl->nx_out <= 8192 && pl->nx_out >= 2;
   const size_t keep = pl->owned.size();              // blocks the caller staged before the search stay
   long rc = FG_RETRY;

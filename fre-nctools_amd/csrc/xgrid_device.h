@@ -60,7 +60,8 @@ enum {
 // pairs of its source cells to one region with a single atomic on that region's fill counter (a counter per 128-byte
 // line: appends to different regions do not serialise), so the list is written in ONE pass -- no count pass, no scan.
 // A region may overflow (fill > regcap): writes beyond it are dropped, the host sees it at its one readback and repeats
-// the search with regions sized by the counters.  regcap is a multiple of 256, so a block of a pair kernel lies in one region.
+// the search with regions sized by the counters.  regcap is a multiple of FG_REG_ALIGN, so a block of a pair kernel lies in one region.
+#define FG_REG_ALIGN 512
 #define FG_NREG 64
 #define FG_FILL_STRIDE 32            // unsigned words per region counter (128 B)
 struct FgPairSpace {

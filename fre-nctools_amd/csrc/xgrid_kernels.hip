@@ -1223,22 +1223,32 @@ __device__ __forceinline__ void d_finish_pair(const double *px, const double *py
   else o->area = -2.0;                                         // non-empty clip, below the area threshold
 }
 
+#ifndef CLIP_THREADS
 #define CLIP_THREADS 256
+#endif
+#ifndef CLIP_SLOTS
+#define CLIP_SLOTS 8        // vertices a polygon of the quad kernel may have (more: general kernel)
+#endif
+#ifndef CLIP_WAVES
+#define CLIP_WAVES 4        // waves per SIMD the quad kernel is compiled for
+#endif
+#ifndef CLIP_PAD_LDS
+#define CLIP_PAD_LDS 0      // timing experiment: extra LDS bytes per clip block (occupancy sensitivity)
+#endif
 
-// Quad x quad fast path.  LDS: polygon [8][256] double2 (32 KiB); the cutting quad lives in registers.
-// Returns false if the pair must go to the general kernel (more than 4 vertices on a side, or more than 8
-// in an intermediate polygon); otherwise *o holds the result (area >= 0 accepted, -1 empty, -2 below threshold).
+// Quad x quad fast path, first half: the Sutherland-Hodgman pass.  LDS: polygon [8][T] double2 (32 KiB per 256 lanes); the
+// cutting quad lives in registers.  Returns -1 if the pair must go to the general kernel (more than 4 vertices on a side, or
+// more than 8 in an intermediate polygon); otherwise the vertex count of the clipped polygon left in column tid (0: empty).
 // RECT: the destination cell is four values of its column record and two of the latitude axis (FgRect) -- D holds areas only.
-template <int ORDER, bool RECT>
-__device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS], const int tid, const int s, const int d,
-                                                 const FgCells &S, const double *mask, const FgCells &D, const FgRect &R,
-                                                 ClipOut *o_out, unsigned long long *stats, unsigned *err)
+template <bool RECT, int T>
+__device__ __forceinline__ int d_clip_quad_sh(double2 (*sh_poly)[T], const int tid, const int s, const int d,
+                                              const FgCells &S, const FgCells &D, const FgRect &R, unsigned *err)
 {
   // RECT: the cutting cell is always a quad, so source cells of up to 8 vertices (the pole-fixed ones) fit this kernel too --
   // the general kernel then only sees the rare pair whose intermediate polygon outgrows 8 vertices
-  constexpr int NV1 = RECT ? 8 : 4;
+  constexpr int NV1 = RECT ? CLIP_SLOTS : 4;
   const int n1 = S.nv[s], n2 = RECT ? 4 : D.nv[d];
-  if (n1 > NV1 || n2 > 4) return false;
+  if (n1 > NV1 || n2 > 4) return -1;
 
   const double *sv = S.verts + (size_t)s * 16;
   const double lon_in_avg = S.lon_avg[s];
@@ -1307,10 +1317,10 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
 #endif
     double2 e1 = cut(e);
     const double x2_0 = e0.x, y2_0 = e0.y, x2_1 = e1.x, y2_1 = e1.y;
-    double2 c[8];
+    double2 c[CLIP_SLOTS];
     unsigned inmask = 0u;
 #pragma unroll
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < CLIP_SLOTS; k++)
       if (k < n_cur) {
         c[k] = sh_poly[k][tid];
         inmask |= (unsigned)d_inside_edge(x2_0, y2_0, x2_1, y2_1, c[k].x, c[k].y) << k;
@@ -1319,7 +1329,7 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
     const unsigned prevmask = ((inmask << 1) | (inmask >> (n_cur - 1))) & full;     // bit k: vertex k-1 (cyclic) is inside
     const unsigned tmask = inmask ^ prevmask;                                        // bit k: edge (k-1, k) crosses the line
     const int ncross = __popc(tmask);
-    if (ncross > 2 || ncross + __popc(inmask) > 8) { overflow = true; break; }
+    if (ncross > 2 || ncross + __popc(inmask) > CLIP_SLOTS) { overflow = true; break; }
     if (tmask) {
       const int ka = __ffs((int)tmask) - 1, kb = 31 - __clz((int)tmask);
       double2 I[2];
@@ -1340,7 +1350,7 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
       }
       // (all reads of the old polygon are done: c[] and I[] are registers)
 #pragma unroll
-      for (int k = 0; k < 8; k++)
+      for (int k = 0; k < CLIP_SLOTS; k++)
         if (k < n_cur && ((inmask >> k) & 1u))
           sh_poly[__popc(inmask & ((1u << k) - 1u)) + __popc(tmask & ((2u << k) - 1u))][tid] = c[k];
       sh_poly[__popc(inmask & ((1u << ka) - 1u))][tid] = I[0];                       // no crossing before the first one
@@ -1350,53 +1360,90 @@ __device__ __forceinline__ bool d_clip_quad_pair(double2 (*sh_poly)[CLIP_THREADS
     n_cur = ncross + __popc(inmask);
     e0 = e1;
   }
-  if (overflow) return false;
+  if (overflow) return -1;
   if (parallel) atomicOr(err, G_ERRBIT_PARALLEL);
-  ClipOut o; o.area = -1.0; o.clon = 0; o.clat = 0;
-  if (n_cur > 0) {
-    const double *px = (const double *)&sh_poly[0][tid];
-#if FG_EXP == 1
-    o.area = n_cur + px[0] + px[1];
-#else
-    d_finish_pair<ORDER, 2 * CLIP_THREADS>(px, px + 1, n_cur, mask ? mask[s] : 1.0, S.area[s], D.area[d],
-                                            lon_in_avg, &o, stats);
-#endif
-  }
-  *o_out = o;
-  return true;
+  return n_cur;
 }
 
 // Result encoding shared by the clip kernels and the compaction: an accepted pair keeps pair_dst[p] = d and
 // gets tmp_area/clon/clat[p]; a rejected pair gets pair_dst[p] = -1.
 // (The integrals loop over the polygon's edges and a wave runs as many iterations as its largest polygon has.  Re-binning the
 // block's 256 polygons by vertex count through LDS before the integrals, so that a wave sees polygons of equal size, was
-// measured: 502 us against 482 -- the extra barriers and the scattered LDS columns cost more than the divergence.)
+// measured in round 1: 502 us against 482 -- the extra barriers and the scattered LDS columns cost more than the divergence.
+// CLIP_COMPACT=1, round 3: the block's non-empty polygons moved to its first lanes before the integrals, order kept.  On the
+// rectilinear path 4.16 M of 4.59 M candidate pairs are accepted, so there is next to nothing to move: 0.444 ms against 0.433.)
 // row_cnt / tmp_rowpos (may be null): an accepted pair takes its slot in its destination row HERE -- a value-returning atomic whose
 // latency hides behind the clip arithmetic -- instead of in the compaction, a kernel that does little else than wait on memory; the
 // destination-row scan can then run before the compaction, which stores the row lists (perm) itself.
-template <int ORDER, bool RECT>
-__global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D, FgRect R,
-                                                            double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
-                                                            int *defer_list, int *defer_cnt,
-                                                            unsigned long long *stats, unsigned *err, int *row_cnt, int *tmp_rowpos)
+#ifndef CLIP_COMPACT
+#define CLIP_COMPACT 0
+#endif
+template <int ORDER, bool RECT, int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(CLIP_WAVES, CLIP_WAVES))) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D, FgRect R,
+                                                 double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
+                                                 int *defer_list, int *defer_cnt,
+                                                 unsigned long long *stats, unsigned *err, int *row_cnt, int *tmp_rowpos)
 {
-  __shared__ double2 sh_poly[8][CLIP_THREADS];
+  __shared__ double2 sh_poly[CLIP_SLOTS][T];
+#if CLIP_PAD_LDS
+  __shared__ char sh_pad[CLIP_PAD_LDS];
+  if (nacc == (int *)16) sh_pad[threadIdx.x * 7 % CLIP_PAD_LDS] = 1;
+#endif
+#if CLIP_COMPACT
+  __shared__ unsigned short sh_perm[T];
+  __shared__ unsigned char sh_n[T];
+  __shared__ int sh_wtot[T / 64];
+#endif
   if (RECT && *R.bad) return;
   {                                                   // the launch covers the regions' CAPACITY: blocks beyond a region's fill leave at once
-    const unsigned first = blockIdx.x * CLIP_THREADS, r = first / (unsigned)ps.regcap;
+    const unsigned first = blockIdx.x * T, r = first / (unsigned)ps.regcap;
     if (first - r * (unsigned)ps.regcap >= ps.fill[r * FG_FILL_STRIDE]) return;
   }
   d_load_trig_table();
   const int tid = threadIdx.x, lane = tid & 63;
-  const int p = blockIdx.x * CLIP_THREADS + tid;
-  bool defer = false, below = false, acc = false;
+  const int p0 = blockIdx.x * T;
+  // ---- first half: clip.  Lane = candidate pair; 4 of 10 pairs of a cubed-sphere x lat-lon job come out empty.
+  bool defer = false;
+  int n_cur = 0;
+  if (d_pair_live(ps, p0 + tid)) {
+    n_cur = d_clip_quad_sh<RECT, T>(sh_poly, tid, ps.src[p0 + tid], ps.dst[p0 + tid], S, D, R, err);
+    if (n_cur < 0) { defer = true; n_cur = 0; }        // rare; the general kernel finishes this pair
+    else if (n_cur == 0) ps.dst[p0 + tid] = -1;
+  }
+  // ---- the block's non-empty polygons move to its first lanes (order kept): the integrals below cost 2/3 of this kernel's
+  // arithmetic, and a wave of them costs the same with 38 live lanes as with 64.  The polygons stay where they are in LDS:
+  // lane l works on column sh_perm[l].
+  int src = tid;
+#if CLIP_COMPACT
+  {
+    const int wave = tid >> 6;
+    const unsigned long long hm = __ballot(n_cur > 0);
+    if (lane == 0) sh_wtot[wave] = __popcll(hm);
+    sh_n[tid] = (unsigned char)n_cur;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < T / 64; w++) { const int c = sh_wtot[w]; if (w < wave) base += c; total += c; }
+    if (n_cur > 0) sh_perm[base + __popcll(hm & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+    __syncthreads();
+    if (tid < total) { src = sh_perm[tid]; n_cur = sh_n[src]; } else n_cur = 0;
+  }
+#endif
+  // ---- second half: area (+ centroid integrals) of polygon `src`
+  bool below = false, acc = false;
   int s = -1;
-  if (d_pair_live(ps, p)) {
+  if (n_cur > 0) {
+    const int p = p0 + src;
     s = ps.src[p];
     const int d = ps.dst[p];
-    ClipOut o;
-    if (!d_clip_quad_pair<ORDER, RECT>(sh_poly, tid, s, d, S, mask, D, R, &o, stats, err)) defer = true;   // rare; the general kernel finishes this pair
-    else if (o.area >= 0) {
+    ClipOut o; o.area = -1.0; o.clon = 0; o.clat = 0;
+    const double *px = (const double *)&sh_poly[0][src];
+#if FG_EXP == 1
+    o.area = n_cur + px[0] + px[1];
+#else
+    d_finish_pair<ORDER, 2 * T>(px, px + 1, n_cur, mask ? mask[s] : 1.0, S.area[s], D.area[d], S.lon_avg[s], &o, stats);
+#endif
+    if (o.area >= 0) {
       acc = true;
       tmp_area[p] = o.area;
       if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
@@ -1406,8 +1453,9 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCe
       below = (o.area == -2.0);                                  // rare (slivers below the 1e-6 ratio)
     }
   }
-  // nacc[s]: accepted pairs of source cell s.  Lanes are pair-ordered, so one atomic per (wave, source cell) run does it.
-  {
+  // nacc[s]: accepted pairs of source cell s.  Lanes are pair-ordered (before and after the move), so one atomic per
+  // (wave, source cell) run does it.
+  if (__ballot(s >= 0)) {
     const int s_prev = __shfl_up(s, 1, 64);
     const bool head = (lane == 0) || (s != s_prev);
     const unsigned long long hm = __ballot(head), am = __ballot(acc);
@@ -1425,7 +1473,7 @@ __global__ __launch_bounds__(CLIP_THREADS) void k_clip_quad(FgPairSpace ps, FgCe
     int q = 0;
     if (lane == 0) q = atomicAdd(defer_cnt, __popcll(dm));
     q = __shfl(q, 0);
-    if (defer) defer_list[q + __popcll(dm & ((1ull << lane) - 1ull))] = p;
+    if (defer) defer_list[q + __popcll(dm & ((1ull << lane) - 1ull))] = p0 + tid;
   }
   if (bm && lane == 0) atomicAdd(&stats[FG_STAT_BELOW], (unsigned long long)__popcll(bm));
 }
@@ -1827,7 +1875,7 @@ void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgC
   if (np <= 0) return;
   const FgRect R = rect ? *rect : FgRect{};
   const int g = nblk(np, CLIP_THREADS);
-#define FG_LAUNCH_QUAD(O, RC) k_clip_quad<O, RC><<<g, CLIP_THREADS, 0, st>>>(ps, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err, row_cnt, tmp_rowpos)
+#define FG_LAUNCH_QUAD(O, RC) k_clip_quad<O, RC, CLIP_THREADS><<<g, CLIP_THREADS, 0, st>>>(ps, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err, row_cnt, tmp_rowpos)
   if (order == 2) { if (rect) FG_LAUNCH_QUAD(2, true); else FG_LAUNCH_QUAD(2, false); }
   else            { if (rect) FG_LAUNCH_QUAD(1, true); else FG_LAUNCH_QUAD(1, false); }
 #undef FG_LAUNCH_QUAD
