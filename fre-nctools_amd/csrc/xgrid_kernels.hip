@@ -1378,12 +1378,13 @@ __device__ __forceinline__ int d_clip_quad_sh(double2 (*sh_poly)[T], const int t
 #ifndef CLIP_COMPACT
 #define CLIP_COMPACT 0
 #endif
-template <int ORDER, bool RECT, int T>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(CLIP_WAVES, CLIP_WAVES))) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D, FgRect R,
+template <int ORDER, bool RECT>
+__global__ __launch_bounds__(CLIP_THREADS) __attribute__((amdgpu_waves_per_eu(CLIP_WAVES, CLIP_WAVES))) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D, FgRect R,
                                                  double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
                                                  int *defer_list, int *defer_cnt,
                                                  unsigned long long *stats, unsigned *err, int *row_cnt, int *tmp_rowpos)
 {
+  constexpr int T = CLIP_THREADS;
   __shared__ double2 sh_poly[CLIP_SLOTS][T];
 #if CLIP_PAD_LDS
   __shared__ char sh_pad[CLIP_PAD_LDS];
@@ -1875,7 +1876,7 @@ void fgd_clip_quad(int order, FgPairSpace ps, FgCells S, const double *mask, FgC
   if (np <= 0) return;
   const FgRect R = rect ? *rect : FgRect{};
   const int g = nblk(np, CLIP_THREADS);
-#define FG_LAUNCH_QUAD(O, RC) k_clip_quad<O, RC, CLIP_THREADS><<<g, CLIP_THREADS, 0, st>>>(ps, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err, row_cnt, tmp_rowpos)
+#define FG_LAUNCH_QUAD(O, RC) k_clip_quad<O, RC><<<g, CLIP_THREADS, 0, st>>>(ps, S, mask, D, R, tmp_area, tmp_clon, tmp_clat, nacc, defer_list, defer_cnt, stats, err, row_cnt, tmp_rowpos)
   if (order == 2) { if (rect) FG_LAUNCH_QUAD(2, true); else FG_LAUNCH_QUAD(2, false); }
   else            { if (rect) FG_LAUNCH_QUAD(1, true); else FG_LAUNCH_QUAD(1, false); }
 #undef FG_LAUNCH_QUAD
