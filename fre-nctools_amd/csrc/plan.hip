@@ -657,7 +657,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   if (rect) {
     pl->D = FgCells{};
     pl->D.area = pl->alloc<double>(ndst);
-    rect_blk = pl->alloc<double>(8 + (size_t)(pl->ny_out + 1) + (size_t)(pl->nx_out + 1) + 8 * (size_t)pl->nx_out);
+    rect_blk = pl->alloc<double>(8 + (size_t)(pl->ny_out + 1) + (size_t)(pl->nx_out + 1) + 8 * (size_t)pl->nx_out + 4 * (size_t)(pl->ny_out + 1));
     if (!pl->D.area || !rect_blk) return fail(FG_ERR_HIP, "out of device memory");
   } else if (!alloc_cells(pl, &pl->D, ndst)) return fail(FG_ERR_HIP, "out of device memory");
   // one zeroed block: [counters | region fill counters | tickets | look-back words of the three scans | bin counts |
@@ -734,9 +734,11 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     // tables + on-device verification of the grid, then the source records, the heavy list and the destination AREAS in one launch
     FgRect &R = pl->rect_tab;
     R.hdr = rect_blk; R.lat_ax = rect_blk + 8; R.lon_ax = rect_blk + 8 + (pl->ny_out + 1); R.col = rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1);
+    double *rect_row = rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1) + 8 * (size_t)pl->nx_out;
+    R.row = rect_row;
     R.bad = &dc->rect_bad; R.nx = pl->nx_out; R.ny = pl->ny_out;
     fgd_rect_tables(d_lon_out, d_lat_out, pl->nx_out, pl->ny_out, rect_blk, rect_blk + 8, rect_blk + 8 + (pl->ny_out + 1),
-                    rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1), &dc->rect_bad, dc->err, st, dst_tlon);
+                    rect_blk + 8 + (pl->ny_out + 1) + (pl->nx_out + 1), rect_row, &dc->rect_bad, dc->err, st, dst_tlon);
     if (pl->polys.npoly) fgd_polylist_records(pl->polys, pl->S, pl->src_idx_f, pl->sums, &R, heavy_list, &dc->heavy_cnt, dc->err, st);
     fgd_cell_struct2r(ts, pl->tiles_dev, pl->tiles_dev, pl->ntiles, pl->polys.npoly ? 0 : nsrc, ndst, pl->S, pl->D.area, R, pl->mask_dev, order,
                       pl->src_idx_f, pl->sums, dc->err, st, dc->band_keys, (g_search_cull && !pl->polys.npoly) ? 2 : 0, heavy_list, &dc->heavy_cnt);

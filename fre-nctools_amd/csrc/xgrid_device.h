@@ -151,11 +151,13 @@ struct FgRect {
   const double *lat_ax;   // [ny+1] compact copy of lat_out[j][0]
   const double *col;      // [nx][8] per column: the four longitudes after fix_lon (SW, SE, NE, NW), lon_min, lon_max, lon_avg, width
   const double *hdr;      // [8] lon[0], nx / (lon[nx] - lon[0]), lat[0], ny / (lat[ny] - lat[0])
+  const double *row;      // [ny+1][4] per latitude-axis value j: sin(lat[j]); and of row j: sin of the mid latitude, sin(dy)/dy of half the
+                          // height, 1.0 if the row is flatter than 1e-10 -- what poly_area evaluates on a cell of that row
   const unsigned *bad;
   int nx, ny;
 };
 void fgd_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax, double *lon_ax, double *col,
-                     unsigned *bad, unsigned *err, hipStream_t st, double dst_tlon = 3.14159265358979323846);
+                     double *row, unsigned *bad, unsigned *err, hipStream_t st, double dst_tlon = 3.14159265358979323846);
 void fgd_cell_struct2r(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, double *area_out,
                        FgRect R, const double *mask, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
                        unsigned long long *band_keys, int cull, int *heavy_list, int *heavy_cnt);

@@ -822,8 +822,9 @@ __global__ __launch_bounds__(64) void k_candidates1(int c0, int c1, int H, FgCel
 #define RECT_HEAVY 48         // rows x window columns above which a source cell's candidates are made by a whole wave
 
 __global__ __launch_bounds__(256) void k_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax,
-                                                      double *lon_ax, double *col, unsigned *bad, unsigned *err, double dst_tlon)
+                                                      double *lon_ax, double *col, double *row, unsigned *bad, unsigned *err, double dst_tlon)
 {
+  d_load_trig_table();                                   // (barrier inside)
   const long np = (long)(nx + 1) * (ny + 1);
   const long gid = (long)blockIdx.x * 256 + threadIdx.x, gsz = (long)gridDim.x * 256;
   bool b = false;
@@ -838,6 +839,16 @@ __global__ __launch_bounds__(256) void k_rect_tables(const double *lon, const do
     if (!(y >= -G_HPI - 1.e-6) || !(y <= G_HPI + 1.e-6)) atomicOr(err, G_ERRBIT_BADLAT);       // (also NaN)
     if (gid < ny && !(lat[(gid + 1) * (nx + 1)] > y)) b = true;                                 // strictly ascending rows
     if (gid > 0 && gid < ny && d_is_pole(y)) b = true;                                          // a pole only as the outer edge of an outer row
+    // what d_poly_area evaluates on the cells of row gid (d_rect_area below): the sines of its two flat edges (lat1 == lat2: the
+    // mid latitude 0.5 * (y + y) is y) and of its two meridian edges (mid latitude 0.5 * (yb + y), half height 0.5 * (yb - y))
+    double *r = row + (size_t)gid * 4;
+    r[0] = d_sin_lat(0.5 * (y + y));
+    if (gid < ny) {
+      const double yb = lat[(gid + 1) * (nx + 1)];
+      const bool flat = fabs(yb - y) < G_SMALL;
+      const double dy = 0.5 * (yb - y);
+      r[1] = d_sin_lat(0.5 * (yb + y)); r[2] = flat ? 1.0 : d_sin_lat(dy) / dy; r[3] = flat ? 1.0 : 0.0;
+    } else { r[1] = 0.0; r[2] = 1.0; r[3] = 1.0; }
   }
   if (gid <= nx) lon_ax[gid] = lon[gid];                                                        // (a copy: the caller's array may go away)
   if (gid < nx) {
@@ -939,6 +950,30 @@ __device__ __forceinline__ bool d_rect_col_pass(const double *c, double lon_in_m
   return !(lon_out_min >= lon_in_max || lon_out_max <= lon_in_min);
 }
 
+// poly_area (mosaic_util.c:417-459, d_poly_area) of the cell in column record c and row record r: the same terms in the same
+// order -- edge 0 flat at the row's lower latitude, edge 1 a meridian (lat1 = upper, lat2 = lower), edge 2 flat at the upper
+// latitude, edge 3 the other meridian (lat1 = lower, lat2 = upper: dy and sin(dy) change sign together, the mid latitude is the
+// same sum) -- with the four sines and the quotient taken from the row table instead of evaluated per cell.
+__device__ __forceinline__ double d_rect_area(const double *c, const double *r)
+{
+  const double s_lo = r[0], s_hi = r[4], s_mid = r[1], dat = r[2];
+  const bool flat_m = r[3] != 0.0;
+  double area = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double dx = c[(k + 1) & 3] - c[k];
+    if (dx > G_PI)  dx = dx - 2.0 * G_PI;
+    if (dx < -G_PI) dx = dx + 2.0 * G_PI;
+    if (fabs(dx + G_PI) < G_SMALL || fabs(dx - G_PI) < G_SMALL) { area += G_PI; continue; }
+    if (k == 0) area -= dx * s_lo;
+    else if (k == 2) area -= dx * s_hi;
+    else if (flat_m) area -= dx * s_mid;
+    else area -= dx * s_mid * dat;
+  }
+  if (area < 0) return -area * G_RADIUS * G_RADIUS;
+  return area * G_RADIUS * G_RADIUS;
+}
+
 // Rectilinear twin of k_cell_struct2: source blocks make the full records (and list the cells whose candidates a whole wave
 // will make), destination blocks store the cell AREA only.
 __global__ __launch_bounds__(256) void k_cell_struct2r(FgTileSet ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst,
@@ -1020,10 +1055,7 @@ __global__ __launch_bounds__(256) void k_cell_struct2r(FgTileSet ts, const FgTil
     const int d = ((int)blockIdx.x - nbS) * 256 + threadIdx.x;
     if (d < ndst) {
       const int j = d / R.nx, i = d - j * R.nx;
-      const double *c = R.col + (size_t)i * RECT_COLW;
-      const double ya = R.lat_ax[j], yb = R.lat_ax[j + 1];
-      double x[4] = {c[0], c[1], c[2], c[3]}, y[4] = {ya, ya, yb, yb};
-      area_out[d] = d_poly_area<1>(x, y, 4);
+      area_out[d] = d_rect_area(R.col + (size_t)i * RECT_COLW, R.row + (size_t)j * 4);
     }
   }
 }
@@ -1897,12 +1929,12 @@ void fgd_clip_general(int order, FgPairSpace ps, FgCells S, const double *mask, 
 }
 
 // ---- rectilinear destination grid
-void fgd_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax, double *lon_ax, double *col, unsigned *bad,
-                     unsigned *err, hipStream_t st, double dst_tlon)
+void fgd_rect_tables(const double *lon, const double *lat, int nx, int ny, double *hdr, double *lat_ax, double *lon_ax, double *col, double *row,
+                     unsigned *bad, unsigned *err, hipStream_t st, double dst_tlon)
 {
   const long np = (long)(nx + 1) * (ny + 1);
   const int g = (int)std::min<long>(1024, std::max<long>((np + 255) / 256, (std::max(nx, ny) + 1 + 255) / 256));
-  k_rect_tables<<<std::max(g, 1), 256, 0, st>>>(lon, lat, nx, ny, hdr, lat_ax, lon_ax, col, bad, err, dst_tlon);
+  k_rect_tables<<<std::max(g, 1), 256, 0, st>>>(lon, lat, nx, ny, hdr, lat_ax, lon_ax, col, row, bad, err, dst_tlon);
 }
 void fgd_cell_struct2r(const FgTileSet &ts, const FgTile *tiles_in, FgTile *tiles_out, int ntiles, int nsrc, int ndst, FgCells S, double *area_out,
                        FgRect R, const double *mask, int order, int *src_idx_f, double *sums, unsigned *err, hipStream_t st,
