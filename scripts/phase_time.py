@@ -30,7 +30,7 @@ def step():
     return p
 
 
-fg.lib().fg_set_profiling(1)
+fg.lib().fg_set_profiling(0 if os.environ.get('FG_NOPROF') else 1)
 for _ in range(5):
     step().destroy()
 acc = {}
