@@ -529,6 +529,10 @@ def main():
 
     # ---- headline: K steps per timed region, profiling events OFF; the region is repeated to show the spread
     fg.lib().fg_set_profiling(0)
+    # one rank, one destination tile: the plan's own per-cell sums are the totals, so the search queues its finalize work itself
+    # (fg_set_search_finalize; what setup_conserve_interp does in that case) -- same kernels, one host round trip less per step
+    fused = world == 1
+    fg.lib().fg_set_search_finalize(1 if fused else 0)
     for _ in range(args.warmup):
         step()
     reps = []
@@ -539,6 +543,16 @@ def main():
             p = step()
         torch.cuda.synchronize(); barrier()
         reps.append(time.perf_counter() - t0)
+    fg.lib().fg_set_search_finalize(0)
+    two_call_ms = None
+    if fused:                # the same steps as two calls (fg_plan_create_dev, then fg_plan_finalize): what a multi-tile / multi-rank job does
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        two_call_ms = (time.perf_counter() - t0) / args.steps * 1e3
     alt_ms = None
     if world > 1:            # the same steps with the cheaper, NOT bit-reproducible exchange (one sparse all-reduce of partial sums)
         for _ in range(2):
@@ -740,6 +754,10 @@ def main():
                                     f"several ranks ({100.0 * ex.nsh / ncell_in:.2f} % of {ncell_in}) handed from rank to rank by {world} broadcasts "
                                     "(parallel.CellSumExchange, conserve_interp.c:203-221's order: bit-identical to one rank)")},
             "exchange_check": exchange_check,
+            "step_calls": ("one: the search queues its finalize work itself before its single synchronisation (fg_set_search_finalize: one destination "
+                           "tile on one rank, the plan's own per-cell sums are the totals)" if fused else
+                           "fg_plan_create_dev, exchange of the shared cells' sums, fg_plan_finalize(totals)"),
+            "ms_per_step_two_calls": two_call_ms,
             "ms_per_step_allreduce_exchange": alt_ms,
             "allreduce_exchange_note": (None if world == 1 else "same steps with ONE sparse all-reduce of partial sums in place of the hand-over: "
                                         "cheaper, but the last bits of di / dj then depend on the rank count -- not the product's default"),

@@ -46,7 +46,7 @@ EXPORTS = [
     "fg_nc_inq_ndims", "fg_nc_inq_nvars", "fg_nc_inq_numrecs", "fg_nc_inq_dimid", "fg_nc_inq_dim", "fg_nc_inq_varid", "fg_nc_inq_var",
     "fg_nc_get_att_double", "fg_nc_get_att_text", "fg_nc_get_vara", "fg_nc_get_vara_double", "fg_nc_put_vara", "fg_nc_put_vara_double",
     "fg_nc_close", "fg_nc_last_error", "fg_dev_widen", "fg_dev_narrow", "fg_sweep_create", "fg_sweep_run", "fg_sweep_destroy", "fg_host_alloc", "fg_host_free",
-    "fg_plan_stats", "fg_set_search_mode", "fg_set_search_chunks", "fg_set_search_cull", "fg_set_search_rect", "fg_set_search_frame", "fg_set_apply_xcd", "fg_set_apply_vec", "fg_set_apply_ep", "fg_set_gc_split", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
+    "fg_plan_stats", "fg_set_search_mode", "fg_set_search_chunks", "fg_set_search_cull", "fg_set_search_finalize", "fg_set_search_rect", "fg_set_search_frame", "fg_set_apply_xcd", "fg_set_apply_vec", "fg_set_apply_ep", "fg_set_gc_split", "fg_set_profiling", "fg_plan_phase_ms", "fg_gnomonic_ed_corners", "fg_latlon_corners",
 ]
 
 

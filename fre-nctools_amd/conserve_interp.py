@@ -480,6 +480,10 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
     from .parallel import world_size
     cull = world_size() > 1 if cull is None else bool(cull)
     lib().fg_set_search_cull(1 if cull else 0)
+    # first order needs no sums from anybody, second order with one destination tile on one rank has them in its own plan: the
+    # search then queues its finalize work itself, without a host round trip in between (fg_set_search_finalize)
+    fused = (order == 1 and not great_circle) or (order == 2 and ntiles_out == 1 and world_size() == 1)
+    lib().fg_set_search_finalize(1 if fused else 0)
     try:
         for n in range(ntiles_out):
             if great_circle:                                           # conserve_interp.c:164-168 (whole tiles, no row trim)
@@ -488,6 +492,7 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
                 plans.append(XgridPlan.create(order, grid_in[:ntiles_in], grid_out[n], device=device))
     finally:
         lib().fg_set_search_cull(0)
+        lib().fg_set_search_finalize(0)
     if cull:
         # a culling search holds no area for the source cells it skipped
         get_input_output_cell_area(ntiles_in, grid_in, ntiles_out, grid_out, opcode)
@@ -501,7 +506,9 @@ def setup_conserve_interp(ntiles_in, grid_in, ntiles_out, grid_out, interp, opco
                 for g in grid_in[:ntiles_in]:
                     g.cell_area = a_in[off:off + g.nx * g.ny].copy()
                     off += g.nx * g.ny
-    if order == 2:
+    if order == 2 and fused:
+        plans[0].finalize(None)                    # (done by its search; returns at once)
+    elif order == 2:
         from .parallel import ordered_cell_sums
         total = ordered_cell_sums(plans, device)   # the one exchange step of the path, in the reference's order
         for p in plans:

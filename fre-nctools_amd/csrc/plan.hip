@@ -393,6 +393,7 @@ struct fg_plan {
   int nx_out = 0, ny_out = 0, ndst = 0;
   long f_stride = 0;            // elements in one level of the source field array
   bool searched = false, finalized = false, have_geom = false;
+  bool fused = false;            // finalized by its own search (fg_set_search_finalize): centroids from the plan's own per-cell sums
 
   std::vector<void *> owned;    // every pool block of this plan
   FgTile *tiles_dev = nullptr;
@@ -537,6 +538,7 @@ static const char *gc_clip_error(int code)
 // 3*ndst, pairs 8*max(nsrc, ndst)) fit every remap between grids of comparable resolution; every kernel clamps its writes
 // AND reads to them, the counters keep counting, and an attempt that outgrew one is repeated with the counted sizes.
 static int g_search_cull = 0;
+static int g_search_finalize = 0;     // fg_set_search_finalize: a search that can also queues the finalize work before its one synchronisation
 // great-circle clip: 1 = three passes (k_gc_screen / k_gc_solve / k_gc_walk) with the one-kernel clip for the unusual pairs,
 // 0 = the one-kernel clip for every pair (fg_set_gc_split; the tests compare the two)
 static int g_gc_split = 1;
@@ -864,6 +866,26 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     pt.end();
   }
   ptot.end();
+  // fg_set_search_finalize(1): the centroid pass and the CSR records of fg_plan_finalize queued HERE, behind the compaction and
+  // before the one synchronisation -- a single-plan job (one destination tile, one rank: the plan's own per-cell sums are the
+  // totals) then has no host round trip and no idle GPU between its search and its finalize (25-30 us of a 0.9 ms step; rocprofv3
+  // kernel timeline, scripts/band_trace.sh).  The records are sized by the capacity of the exchange-cell arrays (the count is
+  // not known yet); an attempt that has to be repeated drops them with everything else.
+  const bool fuse = g_search_finalize && early_rows && !pl->polys.npoly;
+  if (fuse) {
+    pt.begin(PH_FINALIZE);
+    if (order == 2) {
+      pl->cen = pl->alloc<double>(2 * (size_t)nsrc);
+      if (!pl->cen) return fail(FG_ERR_HIP, "out of device memory");
+      fgd_centroids(nsrc, pl->S, pl->sums, pl->cen, st);
+      pl->csr.e2 = pl->alloc<FgCsrEntry2>(nx_alloc + 1);
+    } else pl->csr.e1 = pl->alloc<FgCsrEntry1>(nx_alloc + 1);
+    if (!pl->csr.e1 && !pl->csr.e2) return fail(FG_ERR_HIP, "out of device memory");
+    // (the row-length heuristic of the record kernel wants the exchange-cell count: nsrc + ndst is within a factor of it)
+    fgd_csr_sortgather(order, ndst, (long)nsrc + ndst, pl->perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f,
+                       order == 2 ? pl->cen : nullptr, nsrc, pl->csr, st);
+    pt.end();
+  }
   HIPCHK(hipMemcpyAsync(hc, dc, sizeof(FgCounters), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));                              // the one synchronisation of a search (stream B's work is ordered before it)
   pt.collect(pl->phase_ms); ptot.collect(pl->phase_ms); ptb.collect(pl->phase_ms);   // (also hands the timing events back on every exit below)
@@ -907,6 +929,13 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pl->release(pl->x_rowpos); pl->x_rowpos = nullptr;
   pl->rows_built = true;
   pl->searched = true;
+  if (fuse) {
+    pl->release(pl->perm); pl->perm = nullptr;
+    if (!pl->red_partial) { pl->red_partial = pl->alloc<double>(1024); pl->red_result = pl->alloc<double>(260); }
+    if (!pl->red_partial || !pl->red_result) return fail(FG_ERR_HIP, "out of device memory");
+    pl->dist_pending = (order == 2);
+    pl->finalized = true; pl->fused = true;
+  }
   return pl->nx;
 }
 
@@ -919,6 +948,7 @@ extern "C" void fg_set_search_mode(int exact) { g_search_exact = exact; }
 // 1: source cells whose latitude range cannot meet the destination grid get no record (a rank of a banded multi-GPU job sees
 // a fraction of the source cells); fg_plan_get_cell_area then returns 0 for them.  Results are unchanged.
 extern "C" void fg_set_search_cull(int on) { g_search_cull = on ? 1 : 0; }
+extern "C" void fg_set_search_finalize(int on) { g_search_finalize = on ? 1 : 0; }
 static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double *const *d_lat_in,
                         const double *const *d_mask_in, const double *d_lon_out, const double *d_lat_out,
                         double mean_dlat, double mean_dlon, const GcXyz *gc_in = nullptr, const GcXyz *gc_out = nullptr,
@@ -948,7 +978,7 @@ static long plan_search(fg_plan *pl, const double *const *d_lon_in, const double
       while (pl->owned.size() > keep) { void *p = pl->owned.back(); pl->owned.pop_back(); g_pool.put(p); }
       pl->tiles_dev = nullptr; pl->mask_dev = nullptr; pl->S = FgCells{}; pl->D = FgCells{};
       pl->x_src = pl->x_dst = nullptr; pl->x_area = pl->x_c1 = pl->x_c2 = nullptr; pl->xoff = nullptr; pl->x_rowpos = nullptr;
-      pl->perm = nullptr; pl->csr.row_ptr = nullptr; pl->src_idx_f = nullptr; pl->sums = nullptr;
+      pl->perm = nullptr; pl->csr.row_ptr = nullptr; pl->csr.e1 = nullptr; pl->csr.e2 = nullptr; pl->cen = nullptr; pl->src_idx_f = nullptr; pl->sums = nullptr;
       pl->have_geom = false; pl->rect = false; pl->rect_tab = FgRect{};
     }
     rc = plan_search_core(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon, gc_in, gc_out, boxm, &caps);
@@ -1376,7 +1406,10 @@ extern "C" int fg_plan_finalize(fg_plan *pl, const double *total_cell_sums_dev)
 {
   if (!pl) return fail(FG_ERR_ARG, "null plan");
   if (!pl->searched) return fail(FG_ERR_STATE, "fg_plan_finalize: plan holds no search result");
-  if (pl->finalized) return fail(FG_ERR_STATE, "fg_plan_finalize: already finalized");
+  if (pl->finalized && pl->fused && !total_cell_sums_dev) return 0;         // its search did it (fg_set_search_finalize)
+  if (pl->finalized) return fail(FG_ERR_STATE, pl->fused ? "fg_plan_finalize: the plan was finalized by its search (fg_set_search_finalize) from its own "
+                                                          "per-cell sums; totals over several plans need the two-step sequence"
+                                                         : "fg_plan_finalize: already finalized");
   HIPCHK(hipSetDevice(pl->device));
   PhaseTimer pt; pt.start(g_profiling != 0, pl->stream);
   pt.begin(PH_FINALIZE);

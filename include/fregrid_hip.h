@@ -336,6 +336,12 @@ void fg_set_search_chunks(int chunks);
  * rank of a banded multi-GPU job meets a fraction of the source cells); fg_plan_get_cell_area / _cell_struct then return 0 /
  * unspecified values for those cells.  The exchange cells are unchanged.  Default 0. */
 void fg_set_search_cull(int on);
+/* 1: a search also queues its own fg_plan_finalize -- centroid pass from the plan's OWN per-source-cell sums, CSR records --
+ * before its one synchronisation, for jobs with one destination tile on one rank (conserve_interp.c:203-358 with ntiles_out = 1,
+ * npes = 1: the plan's sums are the totals).  The plan comes back finalized: fg_plan_finalize(plan, NULL) then returns 0 at once,
+ * with totals it is an error.  Applies to legacy-clip searches that run in one chunk (others finalize in fg_plan_finalize as
+ * before).  Results do not depend on it.  Default 0. */
+void fg_set_search_finalize(int on);
 /* Rectilinear destination grids -- lon_out a function of the column and lat_out of the row, bit for bit: every target
  * get_output_grid_by_size makes (fregrid_util.c:588-654), whole or a rank's band.  1 (default): the legacy search finds the
  * candidates of a source cell by index arithmetic on the two axes and builds destination cells from per-column / per-row tables

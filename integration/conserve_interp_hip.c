@@ -129,6 +129,10 @@ void setup_conserve_interp(int ntiles_in, const Grid_config *grid_in, int ntiles
     /* a rank of fregrid_parallel meets only the source cells near its band: the search skips the others when it builds its
      * per-cell records (the counterpart of the row trim, :169-184; the great-circle search culls by bounding caps) */
     fg_set_search_cull(mpp_npes() > 1);
+    /* first order takes no sums from anybody, second order with one output tile on one rank finds them in its own plan: the search
+     * then queues its finalize work itself (no host round trip in between); fg_plan_finalize(plan, NULL) below returns at once */
+    const int fused = (order == 1 && !(opcode & GREAT_CIRCLE)) || (order == 2 && ntiles_out == 1 && mpp_npes() == 1);
+    fg_set_search_finalize(fused);
     for (n = 0; n < ntiles_out; n++) {
       /* this rank's band of output tile n: nxc x nyc cells, corner arrays lonc / latc (get_output_grid_by_size,
        * fregrid_util.c:645-654).  All input tiles are searched in one call; the reference's row trim (:169-184) is an
@@ -143,7 +147,10 @@ void setup_conserve_interp(int ntiles_in, const Grid_config *grid_in, int ntiles
       if (nx < 0) hip_fatal("setup_conserve_interp");
     }
     fg_set_search_cull(0);
-    if (order == 2) {
+    fg_set_search_finalize(0);
+    if (order == 2 && fused) {
+      if (fg_plan_finalize(plans[0], NULL)) hip_fatal("setup_conserve_interp");
+    } else if (order == 2) {
       /* per-source-cell (area, clon, clat): :203-221 gathers the exchange cells of every rank and adds them to the accumulators
        * one by one, output tile after output tile, "for the purpose of bitwise reproducing".  One running total handed from
        * plan to plan (fg_plan_accumulate_cell_sums continues from the values it finds) does the same additions in the same
