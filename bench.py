@@ -600,6 +600,16 @@ def main():
     torch.cuda.synchronize(); barrier()
     dta = time.perf_counter() - ta
     apply_call_ms = p.phase_ms()["apply"]            # device time of one level-major call (2 transposes + sweep)
+    # one level per call: what fregrid's level loop does (fregrid.c:1045-1061: do_scalar_conserve_interp(..., nz = 1))
+    out1_t = out_t[:ny_band * nlon]
+    for _ in range(3):
+        p.apply(data_t, out1_t, nz=1, grad_x_t=gx_t, grad_y_t=gy_t)
+    barrier(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(apply_steps):
+        p.apply(data_t, out1_t, nz=1, grad_x_t=gx_t, grad_y_t=gy_t)
+    torch.cuda.synchronize(); barrier()
+    dt1 = time.perf_counter() - t1
     # the sweep kernel alone, on fields kept interleaved [cell][nz]
     nb = 16 if nz >= 16 else (8 if nz >= 8 else (4 if nz >= 4 else 2))
     il = lambda t, n: t[:nb].reshape(nb, n).t().contiguous()
@@ -665,12 +675,12 @@ def main():
     gsum_xgrid = float(np.sum(f0 * xg["area"]))
 
     # ---- reductions over ranks
-    red = torch.tensor([0.0, dta, dtb, dtl, dtf, dtr], dtype=torch.float64, device=dev)
+    red = torch.tensor([dt1, dta, dtb, dtl, dtf, dtr], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(nx_local), float(gsum_out), gsum_xgrid], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    _, dta, dtb, dtl, dtf, dtr = (float(red[k]) for k in range(6))
+    dt1, dta, dtb, dtl, dtf, dtr = (float(red[k]) for k in range(6))
     nx_total, gsum_out, gsum_xgrid = int(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if rank == 0:
@@ -762,6 +772,9 @@ def main():
             "allreduce_exchange_note": (None if world == 1 else "same steps with ONE sparse all-reduce of partial sums in place of the hand-over: "
                                         "cheaper, but the last bits of di / dj then depend on the rank count -- not the product's default"),
             "remapped_points_per_s": remap_pts, "apply_ms_per_call": dta / apply_steps * 1e3, "apply_levels": nz,
+            "apply_single_level_ms": dt1 / apply_steps * 1e3,
+            "remapped_points_per_s_single_level": apply_steps * ndst / dt1,
+            "single_level_note": "fg_plan_apply with nz = 1, what the reference's level loop calls (fregrid.c:1045-1061); entry-parallel kernel k_apply_ep1",
             "apply_device_ms_per_call": apply_call_ms,
             "remapped_points_per_s_interleaved": apply_steps * ndst * nb / dtb,
             "remapped_points_per_s_records": (apply_steps * ndst * nz / dtr) if dtr > 0 else None,

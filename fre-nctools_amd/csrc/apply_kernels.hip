@@ -228,6 +228,105 @@ __global__ __launch_bounds__(256) void k_apply1(int ndst, FgCsr csr, const doubl
   out[d] = r;
 }
 
+// The single-level sweep as fregrid's level loop calls it (fregrid.c:1045-1061: get_input_data, do_scalar_conserve_interp(..., 1),
+// write_field_data per level; also every field with missing values), entry-parallel like k_apply_ep8: a tile of EP1_ROWS rows
+// stages its CSR records with coalesced loads, a lane per exchange cell issues the tile's gathers (field, two gradients, the
+// gradient mask) in one round, the products area * (f + gx di + gy dj) go to LDS and one lane per row adds them in CSR order.
+// An exchange cell whose source value is missing adds +0.0 to both sums (x + 0.0 == x bit for bit) and does not count as
+// touched: k_apply1's `continue`.  k_apply1 (a lane walking its row: a record load and a gather round per exchange cell,
+// ~9 dependent memory rounds) took 0.137 ms for one level of C384 -> 0.25 deg second order, more than two levels together.
+#define EP1_ROWS 64
+template <int ORDER, bool MISSING, int TPB, int CAP>
+__global__ __launch_bounds__(TPB) void k_apply_ep1(int ndst, FgCsr csr, const double *f, const double *px, const double *py, const int *gmask,
+                                                    double missing, double *out, double *row_sum, int xcd_band)
+{
+  typedef typename std::conditional<ORDER == 2, FgCsrEntry2, FgCsrEntry1>::type Entry;
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  constexpr int W = sizeof(Entry) / 16, PASS = CAP / TPB;
+  __shared__ __attribute__((aligned(16))) Entry sh_e[CAP];
+  double *sh_p = reinterpret_cast<double *>(sh_e), *sh_a = sh_p + CAP;       // the products take the records' place (2 * 8 <= sizeof(Entry))
+  __shared__ unsigned char sh_fl[CAP];
+  const int t = threadIdx.x;
+  const int d0 = d_xcd_block(blockIdx.x, gridDim.x, xcd_band) * EP1_ROWS;
+  const int dl = min(d0 + EP1_ROWS, ndst);
+  const int q0 = csr.row_ptr[d0], q1 = csr.row_ptr[dl];
+  const int d = d0 + t, dc = min(d, ndst - 1);
+  int b = 0, e = 0;
+  if (t < EP1_ROWS) { b = csr.row_ptr[dc]; e = csr.row_ptr[dc + 1]; }
+  const int n = q1 - q0, nst = min(n, CAP);
+  {
+    const Entry *src = (ORDER == 2) ? (const Entry *)csr.e2 : (const Entry *)csr.e1;
+    const u4v *g = reinterpret_cast<const u4v *>(src + q0);
+    u4v *l = reinterpret_cast<u4v *>(sh_e);
+    for (int i = t; i < nst * W; i += TPB) l[i] = __builtin_nontemporal_load(g + i);
+  }
+  __syncthreads();
+  double acc = 0.0, asum = 0.0;
+  int touched = 0;
+  if (n <= CAP) {
+    Entry E[PASS];
+    double v[PASS], gxv[PASS], gyv[PASS];
+    int gm[PASS];
+#pragma unroll
+    for (int j = 0; j < PASS; j++) {
+      const int i = min(t + TPB * j, max(n - 1, 0));
+      E[j] = sh_e[i]; v[j] = 0.0; gxv[j] = 0.0; gyv[j] = 0.0; gm[j] = 0;
+      if (TPB * j < n) {                                  // (block-uniform)
+        v[j] = f[E[j].idx_f];
+        if constexpr (ORDER == 2) {
+          gxv[j] = px[E[j].idx_g]; gyv[j] = py[E[j].idx_g];
+          if (MISSING) gm[j] = gmask[E[j].idx_g];
+        }
+      }
+    }
+    __syncthreads();                                       // the records are in registers: the buffer becomes the product table
+#pragma unroll
+    for (int j = 0; j < PASS; j++) {
+      const int i = t + TPB * j;
+      if (i < n) {
+        double val = v[j], a = E[j].area, p;
+        unsigned char fl = 1;
+        if (MISSING && val == missing) { p = 0.0; a = 0.0; fl = 0; }
+        else {
+          if constexpr (ORDER == 2) { if (!(MISSING && gm[j] != 0)) val = (val + gxv[j] * E[j].di + gyv[j] * E[j].dj); }
+          p = val * a;
+        }
+        sh_p[i] = p; sh_a[i] = a; sh_fl[i] = fl;
+      }
+    }
+    __syncthreads();
+    if (t >= EP1_ROWS || d >= ndst) return;
+    for (int q = b - q0; q < e - q0; q++) { acc += sh_p[q]; asum += sh_a[q]; touched |= sh_fl[q]; }
+  } else {
+    if (t >= EP1_ROWS || d >= ndst) return;
+    for (int q = b; q < e; q++) {                          // a tile that outgrows the table (fine -> coarse): k_apply1's loop
+      const int ql = q - q0;
+      double a, val;
+      if constexpr (ORDER == 2) {
+        const FgCsrEntry2 E = (ql < CAP) ? ((const FgCsrEntry2 *)sh_e)[ql] : csr.e2[q];
+        a = E.area; val = f[E.idx_f];
+        if (MISSING) { if (val == missing) continue; }
+        bool flatgrad = false;
+        if (MISSING) flatgrad = gmask[E.idx_g] != 0;
+        if (!flatgrad) val = (val + px[E.idx_g] * E.di + py[E.idx_g] * E.dj);
+      } else {
+        const FgCsrEntry1 E = (ql < CAP) ? ((const FgCsrEntry1 *)sh_e)[ql] : csr.e1[q];
+        a = E.area; val = f[E.idx_f];
+        if (MISSING) { if (val == missing) continue; }
+      }
+      acc += val * a;
+      asum += a;
+      touched = 1;
+    }
+  }
+  if (row_sum) row_sum[d] = (asum > 0) ? acc : 0.0;           // conserve_interp.c:815-819
+  double r;                                                   // :831-839
+  if (asum > 0) r = acc / asum;
+  else if (touched) r = 0.0;
+  else r = missing;
+  out[d] = r;
+}
+
 // NB levels at once, fields interleaved [cell][NB]: every CSR entry is read once for NB levels and
 // each gather is NB*8 contiguous bytes (a full 64-byte sector for NB = 8).  A row is served by NB/V
 // adjacent lanes, each owning V consecutive levels (V = 2: one 16-byte load per field and entry):
@@ -763,10 +862,19 @@ void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsr
 {
   if (nsrc > 0) k_src_field_index<<<nblk(nsrc, 256), 256, 0, st>>>(order, tiles_dev, ntiles, nsrc, src_idx_f);
 }
+extern int g_apply_xcd, g_apply_ep;
 void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, const int *gmask,
-                int has_missing, double missing, double *out, double *row_sum, hipStream_t st)
+                int has_missing, double missing, double *out, double *row_sum, hipStream_t st, long nx)
 {
   if (ndst <= 0) return;
+  if (g_apply_ep && nx >= 0 && nx <= 6L * ndst) {          // rows of a few exchange cells: the entry-parallel single-level kernel
+    const int g1 = nblk(ndst, EP1_ROWS), xb = g_apply_xcd;
+#define EP1(O_, M_) k_apply_ep1<O_, M_, 256, 512><<<g1, 256, 0, st>>>(ndst, csr, f, gx, gy, gmask, missing, out, row_sum, xb)
+    if (order == 2) { if (has_missing) EP1(2, true); else EP1(2, false); }
+    else            { if (has_missing) EP1(1, true); else EP1(1, false); }
+#undef EP1
+    return;
+  }
   int grid = nblk(ndst, 256);
   if (order == 2) {
     if (has_missing) k_apply1<2, true><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, gmask, missing, out, row_sum);

@@ -1676,7 +1676,7 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
     const double *gy = grad_y ? grad_y + (size_t)k0 * pl->nsrc : nullptr;
     double *o = out + (size_t)k0 * ndst;
     if (nbv == 1) {
-      fgd_apply1(pl->order, ndst, pl->csr, f, gx, gy, grad_mask, has_missing, miss, o, gsum_out ? pl->row_sum : nullptr, st);
+      fgd_apply1(pl->order, ndst, pl->csr, f, gx, gy, grad_mask, has_missing, miss, o, gsum_out ? pl->row_sum : nullptr, st, pl->nx);
       if (gsum_out) fgd_reduce_sum(pl->row_sum, ndst, pl->red_partial, pl->red_result + nred++, st);
     } else {
       const int nbp = nbv > 4 ? 8 : (nbv > 2 ? 4 : 2);

@@ -226,7 +226,7 @@ void fgd_csr_sortgather(int order, int ndst, long nx, const int *perm, const int
                         const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr, hipStream_t st);
 void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsrc, int *src_idx_f, hipStream_t st);
 void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, const int *gmask,
-                int has_missing, double missing, double *out, double *row_sum, hipStream_t st);
+                int has_missing, double missing, double *out, double *row_sum, hipStream_t st, long nx = -1);
 void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
                   double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st);
 void fgd_interleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st);
