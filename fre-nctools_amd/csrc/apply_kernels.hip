@@ -229,49 +229,52 @@ __global__ __launch_bounds__(256) void k_apply1(int ndst, FgCsr csr, const doubl
 }
 
 // The single-level sweep as fregrid's level loop calls it (fregrid.c:1045-1061: get_input_data, do_scalar_conserve_interp(..., 1),
-// write_field_data per level; also every field with missing values), entry-parallel like k_apply_ep8: a tile of EP1_ROWS rows
-// stages its CSR records with coalesced loads, a lane per exchange cell issues the tile's gathers (field, two gradients, the
-// gradient mask) in one round, the products area * (f + gx di + gy dj) go to LDS and one lane per row adds them in CSR order.
-// An exchange cell whose source value is missing adds +0.0 to both sums (x + 0.0 == x bit for bit) and does not count as
-// touched: k_apply1's `continue`.  k_apply1 (a lane walking its row: a record load and a gather round per exchange cell,
-// ~9 dependent memory rounds) took 0.137 ms for one level of C384 -> 0.25 deg second order, more than two levels together.
-#define EP1_ROWS 64
-template <int ORDER, bool MISSING, int TPB, int CAP>
+// write_field_data per level; also every field with missing values), entry-parallel like k_apply_ep8: a tile of ROWS rows walks
+// its run of CSR records in chunks of CAP: the chunk is staged with coalesced loads, a lane per exchange cell issues the chunk's
+// gathers (field, two gradients, the gradient mask) in one round, the products area * (f + gx di + gy dj) go to LDS and the lane
+// of each row adds its part of the chunk in CSR order, carrying its sums from chunk to chunk -- so a row may be as long as it
+// likes (fine -> coarse remaps: ROWS shrinks with the mean row length, a row of thousands of exchange cells is one tile walking
+// many chunks).  An exchange cell whose source value is missing adds +0.0 to both sums (x + 0.0 == x bit for bit) and does not
+// count as touched: k_apply1's `continue`.  k_apply1 (a lane walking its row: a record load and a gather round per exchange cell)
+// took 0.137 ms for one level of C384 -> 0.25 deg second order -- more than two levels together -- and 0.142 ms for C384 -> 2 deg.
+template <int ORDER, bool MISSING, int TPB, int CAP, int ROWS>
 __global__ __launch_bounds__(TPB) void k_apply_ep1(int ndst, FgCsr csr, const double *f, const double *px, const double *py, const int *gmask,
                                                     double missing, double *out, double *row_sum, int xcd_band)
 {
   typedef typename std::conditional<ORDER == 2, FgCsrEntry2, FgCsrEntry1>::type Entry;
   typedef unsigned int u4v __attribute__((ext_vector_type(4)));
   constexpr int W = sizeof(Entry) / 16, PASS = CAP / TPB;
+  static_assert(ROWS <= TPB && CAP % TPB == 0, "tile shape");
   __shared__ __attribute__((aligned(16))) Entry sh_e[CAP];
   double *sh_p = reinterpret_cast<double *>(sh_e), *sh_a = sh_p + CAP;       // the products take the records' place (2 * 8 <= sizeof(Entry))
   __shared__ unsigned char sh_fl[CAP];
   const int t = threadIdx.x;
-  const int d0 = d_xcd_block(blockIdx.x, gridDim.x, xcd_band) * EP1_ROWS;
-  const int dl = min(d0 + EP1_ROWS, ndst);
+  const int d0 = d_xcd_block(blockIdx.x, gridDim.x, xcd_band) * ROWS;
+  const int dl = min(d0 + ROWS, ndst);
   const int q0 = csr.row_ptr[d0], q1 = csr.row_ptr[dl];
   const int d = d0 + t, dc = min(d, ndst - 1);
   int b = 0, e = 0;
-  if (t < EP1_ROWS) { b = csr.row_ptr[dc]; e = csr.row_ptr[dc + 1]; }
-  const int n = q1 - q0, nst = min(n, CAP);
-  {
-    const Entry *src = (ORDER == 2) ? (const Entry *)csr.e2 : (const Entry *)csr.e1;
-    const u4v *g = reinterpret_cast<const u4v *>(src + q0);
-    u4v *l = reinterpret_cast<u4v *>(sh_e);
-    for (int i = t; i < nst * W; i += TPB) l[i] = __builtin_nontemporal_load(g + i);
-  }
-  __syncthreads();
+  if (t < ROWS) { b = csr.row_ptr[dc]; e = csr.row_ptr[dc + 1]; }
+  const Entry *src = (ORDER == 2) ? (const Entry *)csr.e2 : (const Entry *)csr.e1;
   double acc = 0.0, asum = 0.0;
   int touched = 0;
-  if (n <= CAP) {
+  for (int c0 = q0; c0 < q1; c0 += CAP) {                  // (block-uniform)
+    const int n = min(CAP, q1 - c0);
+    if (c0 > q0) __syncthreads();                          // the previous chunk's products have been added
+    {
+      const u4v *g = reinterpret_cast<const u4v *>(src + c0);
+      u4v *l = reinterpret_cast<u4v *>(sh_e);
+      for (int i = t; i < n * W; i += TPB) l[i] = __builtin_nontemporal_load(g + i);
+    }
+    __syncthreads();
     Entry E[PASS];
     double v[PASS], gxv[PASS], gyv[PASS];
     int gm[PASS];
 #pragma unroll
     for (int j = 0; j < PASS; j++) {
-      const int i = min(t + TPB * j, max(n - 1, 0));
+      const int i = min(t + TPB * j, n - 1);
       E[j] = sh_e[i]; v[j] = 0.0; gxv[j] = 0.0; gyv[j] = 0.0; gm[j] = 0;
-      if (TPB * j < n) {                                  // (block-uniform)
+      if (TPB * j < n) {                                    // (block-uniform)
         v[j] = f[E[j].idx_f];
         if constexpr (ORDER == 2) {
           gxv[j] = px[E[j].idx_g]; gyv[j] = py[E[j].idx_g];
@@ -295,30 +298,22 @@ __global__ __launch_bounds__(TPB) void k_apply_ep1(int ndst, FgCsr csr, const do
       }
     }
     __syncthreads();
-    if (t >= EP1_ROWS || d >= ndst) return;
-    for (int q = b - q0; q < e - q0; q++) { acc += sh_p[q]; asum += sh_a[q]; touched |= sh_fl[q]; }
-  } else {
-    if (t >= EP1_ROWS || d >= ndst) return;
-    for (int q = b; q < e; q++) {                          // a tile that outgrows the table (fine -> coarse): k_apply1's loop
-      const int ql = q - q0;
-      double a, val;
-      if constexpr (ORDER == 2) {
-        const FgCsrEntry2 E = (ql < CAP) ? ((const FgCsrEntry2 *)sh_e)[ql] : csr.e2[q];
-        a = E.area; val = f[E.idx_f];
-        if (MISSING) { if (val == missing) continue; }
-        bool flatgrad = false;
-        if (MISSING) flatgrad = gmask[E.idx_g] != 0;
-        if (!flatgrad) val = (val + px[E.idx_g] * E.di + py[E.idx_g] * E.dj);
-      } else {
-        const FgCsrEntry1 E = (ql < CAP) ? ((const FgCsrEntry1 *)sh_e)[ql] : csr.e1[q];
-        a = E.area; val = f[E.idx_f];
-        if (MISSING) { if (val == missing) continue; }
+    if (t < ROWS) {
+      const int qa = max(b, c0) - c0, qb = min(e, c0 + n) - c0;
+      int q = qa;
+      for (; q + 8 <= qb; q += 8) {                        // (long rows: eight LDS reads in flight, then the adds in CSR order)
+        double pp[8], aa[8];
+        unsigned ff = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { pp[k] = sh_p[q + k]; aa[k] = sh_a[q + k]; ff |= sh_fl[q + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { acc += pp[k]; asum += aa[k]; }
+        touched |= (int)ff;
       }
-      acc += val * a;
-      asum += a;
-      touched = 1;
+      for (; q < qb; q++) { acc += sh_p[q]; asum += sh_a[q]; touched |= sh_fl[q]; }
     }
   }
+  if (t >= ROWS || d >= ndst) return;
   if (row_sum) row_sum[d] = (asum > 0) ? acc : 0.0;           // conserve_interp.c:815-819
   double r;                                                   // :831-839
   if (asum > 0) r = acc / asum;
@@ -698,6 +693,96 @@ __global__ __launch_bounds__(TPB) void k_apply_ep8(int ndst, FgCsr csr, const do
     *reinterpret_cast<VecD<LV> *>(out + (size_t)d * NB + lev) = r;
 }
 
+// The same for plans with longer rows (fine -> coarse remaps; k_apply_ep8 above is for rows of a few exchange cells): ROWS rows per
+// tile, fewer the longer the mean row, and the tile's run of CSR records walked in chunks of CAP, the (row, level) lanes carrying
+// their sums from chunk to chunk: any row length, every gather of a chunk in one round.  (Such plans took the row-serial
+// k_apply_il before: C384 -> 2 deg 0.117 ms per 8 levels on records, now 0.037.)  As a loop the kernel needs more registers than
+// k_apply_ep8 -- with 32 rows per tile on C384 -> 0.25 deg it runs in 0.117 ms against 0.083 -- so short rows keep the kernel above.
+template <int TPB, int CAP, int ROWS>
+__global__ __launch_bounds__(TPB) void k_apply_ep8g(int ndst, FgCsr csr, const double *rec, double missing, double *out, double *row_sum,
+                                                    long out_ld, int nb_valid, int xcd_band)
+{
+  constexpr int NB = 8;
+  constexpr int EPP = TPB / 2, PASS = CAP / EPP;          // gather phase: a lane pair per exchange cell, EPP cells per pass
+  static_assert(ROWS * NB <= TPB, "a lane per (row, level)");
+  // one buffer: the staged CSR records first, then (once every lane holds its records in registers) the products and areas
+  __shared__ __attribute__((aligned(16))) double sh_raw[CAP * (NB + 1)];
+  FgCsrEntry2 *sh_e = reinterpret_cast<FgCsrEntry2 *>(sh_raw);
+  double *sh_p = sh_raw, *sh_a = sh_raw + CAP * NB;
+  const int t = threadIdx.x;
+  const int d0 = d_xcd_block(blockIdx.x, gridDim.x, xcd_band) * ROWS;
+  const int dl = min(d0 + ROWS, ndst);
+  const int q0 = csr.row_ptr[d0], q1 = csr.row_ptr[dl];
+  const bool sumlane = t < ROWS * NB;                      // lane (row, level) of the sum phase
+  const int d = d0 + t / NB, lev = t % NB;
+  const int dc = min(d, ndst - 1);
+  int b = 0, e = 0;
+  if (sumlane) { b = csr.row_ptr[dc]; e = csr.row_ptr[dc + 1]; }
+  double acc = 0.0, asum = 0.0;
+  for (int c0 = q0; c0 < q1; c0 += CAP) {                  // (block-uniform)
+    const int n = min(CAP, q1 - c0);
+    if (c0 > q0) __syncthreads();                          // the previous chunk's products have been added
+    {
+      typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+      const u4v *g = reinterpret_cast<const u4v *>(csr.e2 + c0);
+      u4v *l = reinterpret_cast<u4v *>(sh_e);
+      for (int i = t; i < n * 2; i += TPB) l[i] = __builtin_nontemporal_load(g + i);
+    }
+    __syncthreads();
+    const int h = (t & 1) * 4;                             // four levels per lane of the pair
+    VecD<4> fv[PASS], gxv[PASS], gyv[PASS];
+    FgCsrEntry2 E[PASS];
+#pragma unroll
+    for (int j = 0; j < PASS; j++) {
+      if (EPP * j < n) {                                   // (block-uniform)
+        const int i = min(t / 2 + EPP * j, n - 1);
+        E[j] = sh_e[i];
+        const double *pf = rec + (size_t)E[j].idx_g * (3 * NB) + h;
+        fv[j] = *reinterpret_cast<const VecD<4> *>(pf);
+        gxv[j] = *reinterpret_cast<const VecD<4> *>(pf + NB);
+        gyv[j] = *reinterpret_cast<const VecD<4> *>(pf + 2 * NB);
+      }
+    }
+    __syncthreads();                                       // the records are in registers: the buffer becomes the product table
+#pragma unroll
+    for (int j = 0; j < PASS; j++) {
+      const int i = t / 2 + EPP * j;
+      if (EPP * j < n && i < n) {
+        VecD<4> pv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          double v = (fv[j].v[k] + gxv[j].v[k] * E[j].di + gyv[j].v[k] * E[j].dj);
+          pv.v[k] = v * E[j].area;
+        }
+        *reinterpret_cast<VecD<4> *>(sh_p + i * NB + h) = pv;
+        if (h == 0) sh_a[i] = E[j].area;
+      }
+    }
+    __syncthreads();
+    if (sumlane) {
+      const int qa = max(b, c0) - c0, qb = min(e, c0 + n) - c0;
+      int q = qa;
+      for (; q + 8 <= qb; q += 8) {                        // (long rows: eight LDS reads in flight, then the adds in CSR order)
+        double pp[8], aa[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { pp[k] = sh_p[(q + k) * NB + lev]; aa[k] = sh_a[q + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { acc += pp[k]; asum += aa[k]; }
+      }
+      for (; q < qb; q++) { acc += sh_p[q * NB + lev]; asum += sh_a[q]; }
+    }
+  }
+  if (!sumlane || d >= ndst) return;
+  const double rs = (asum > 0) ? acc : 0.0;
+  double r;
+  if (asum > 0) r = acc / asum;
+  else if (e > b) r = 0.0;
+  else r = missing;
+  if (row_sum) row_sum[(size_t)d * NB + lev] = rs;
+  if (out_ld > 0) { if (lev < nb_valid) out[(size_t)lev * out_ld + d] = r; }
+  else out[(size_t)d * NB + lev] = r;
+}
+
 // [nb][n] (level-major, row stride ld) <-> [n][NB] interleaved
 template <int NB>
 __global__ __launch_bounds__(256) void k_interleave(long n, const double *in, long ld, int nb, double *out)
@@ -867,11 +952,14 @@ void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *g
                 int has_missing, double missing, double *out, double *row_sum, hipStream_t st, long nx)
 {
   if (ndst <= 0) return;
-  if (g_apply_ep && nx >= 0 && nx <= 6L * ndst) {          // rows of a few exchange cells: the entry-parallel single-level kernel
-    const int g1 = nblk(ndst, EP1_ROWS), xb = g_apply_xcd;
-#define EP1(O_, M_) k_apply_ep1<O_, M_, 256, 512><<<g1, 256, 0, st>>>(ndst, csr, f, gx, gy, gmask, missing, out, row_sum, xb)
-    if (order == 2) { if (has_missing) EP1(2, true); else EP1(2, false); }
-    else            { if (has_missing) EP1(1, true); else EP1(1, false); }
+  if (g_apply_ep && nx >= 0) {                             // the entry-parallel single-level kernel; rows per tile by the mean row length
+    const long m = nx / ndst;
+    const int xb = g_apply_xcd;
+#define EP1(O_, M_, R_) k_apply_ep1<O_, M_, 256, 512, R_><<<nblk(ndst, R_), 256, 0, st>>>(ndst, csr, f, gx, gy, gmask, missing, out, row_sum, xb)
+#define EP1R(O_, M_) do { if (m <= 6) EP1(O_, M_, 64); else if (m <= 24) EP1(O_, M_, 16); else if (m <= 96) EP1(O_, M_, 4); else EP1(O_, M_, 1); } while (0)
+    if (order == 2) { if (has_missing) EP1R(2, true); else EP1R(2, false); }
+    else            { if (has_missing) EP1R(1, true); else EP1R(1, false); }
+#undef EP1R
 #undef EP1
     return;
   }
@@ -924,6 +1012,13 @@ void fgd_apply_il_merged(int nb, int ndst, long nx, FgCsr csr, const double *rec
   if (nb == 16) APM(16, 4);
   else if (nb == 8 && g_apply_ep && nx <= 6L * ndst)       // rows of ~4 exchange cells: a tile's cells fit the product table
     k_apply_ep8<256, 256><<<nblk(ndst, EP_ROWS), 256, 0, st>>>(ndst, csr, rec, missing, out, row_sum, out_ld, nb_valid, g_apply_xcd >= 2 ? 2 * g_apply_xcd : g_apply_xcd);
+  else if (nb == 8 && g_apply_ep) {                        // longer rows: chunked tiles, rows per tile by the mean row length
+    const long m = nx / ndst;
+    const int xb = g_apply_xcd >= 2 ? 2 * g_apply_xcd : g_apply_xcd;
+#define EP8(R_) k_apply_ep8g<256, 256, R_><<<nblk(ndst, R_), 256, 0, st>>>(ndst, csr, rec, missing, out, row_sum, out_ld, nb_valid, xb)
+    if (m <= 24) EP8(8); else if (m <= 96) EP8(2); else EP8(1);
+#undef EP8
+  }
   else if (nb == 8) { if (g_apply_vec == 2) APM(8, 2); else APM(8, 4); }   // 4 levels per lane: 0.0875 ms against 0.0936 with 2 (1440x720, 8 levels, chunked tiles)
   else if (nb == 4) APM(4, 2);
   else APM(2, 2);

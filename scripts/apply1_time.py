@@ -1,11 +1,13 @@
-"""Time of the single-level sweeps (what fregrid's level loop calls: do_scalar_conserve_interp(..., nz = 1)), C384 -> 1440x720."""
+"""Time of the level-major sweeps fg_plan_apply with nz = 1 (what fregrid's level loop calls: do_scalar_conserve_interp(..., nz = 1)), 2, 4, 8.
+usage: apply1_time.py [ni nlon nlat]   (default C384 -> 1440x720)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import __graft_entry__ as ge
 fg = ge.load_package()
-ni, nlon, nlat = 384, 1440, 720
+a = [int(v) for v in sys.argv[1:]]
+ni, nlon, nlat = (a + [384, 1440, 720][len(a):])[:3]
 lon, lat = fg.gnomonic_ed_corners(ni); lo, la = fg.latlon_corners(nlon, nlat)
 dev = "cuda:0"
 h2d = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)
@@ -27,5 +29,5 @@ for order in (2, 1):
         p.sync(); dt = (time.perf_counter() - t0) / 100
         W, S = (32, 24) if order == 2 else (16, 8)
         alg = p.nxgrid * W + nz * (nc * S + nlon * nlat * 8)          # CSR once per call, fields per level
-        print(f"order {order} nz {nz}: {dt * 1e3:.4f} ms per call, {dt * 1e3 / nz:.4f} per level; algorithmic {alg / 1e6:.0f} MB -> {alg / dt / 1e12:.2f} TB/s", flush=True)
+        print(f"C{ni} -> {nlon}x{nlat} ({p.nxgrid / (nlon * nlat):.1f} exchange cells per row) order {order} nz {nz}: {dt * 1e3:.4f} ms per call, {dt * 1e3 / nz:.4f} per level; algorithmic {alg / 1e6:.0f} MB -> {alg / dt / 1e12:.2f} TB/s", flush=True)
     p.destroy()

@@ -829,3 +829,45 @@ def test_remap_file_write_then_read_branch(fg, gpu_ok, tmp_path):
     torch.cuda.synchronize()
     interp3[0].plan.apply(data, o3, nz=1, grad_x_t=gx, grad_y_t=gy); interp3[0].plan.sync()
     assert np.array_equal(o3.cpu().numpy(), b.reshape(nlat, nlon)[j0:j1].ravel())
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("ni,nlon,nlat", [(48, 144, 90), (96, 90, 45), (96, 24, 12), (48, 6, 3)])
+def test_single_level_entry_parallel_sweep_keeps_the_bits(fg, gpu_ok, order, ni, nlon, nlat):
+    """k_apply_ep1 (what fregrid's level loop calls: one level per do_scalar_conserve_interp) against the lane-per-row kernel
+    k_apply1 (fg_set_apply_ep(0)), with and without missing values / gradient mask, on rows of ~4, ~20, ~300 and ~2000 exchange
+    cells (the last two walk a row in several chunks of the product table); the flux sum too."""
+    import torch
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    p = fg.XgridPlan.create(order, grids, fg.GridConfig(nlon, nlat, lo, la))
+    p.finalize()
+    nc = 6 * ni * ni
+    nf = 6 * (ni + 2) ** 2 if order == 2 else nc
+    rng = np.random.default_rng(21)
+    missing = -1.0e10
+    src = rng.standard_normal(nf)
+    src_m = src.copy(); src_m[rng.random(nf) < 0.2] = missing
+    gx, gy = rng.standard_normal(nc), rng.standard_normal(nc)
+    gm = (rng.random(nc) < 0.3).astype(np.int32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") if a is not None else None
+    res = {}
+    try:
+        for ep in (0, 1):
+            fg.lib().fg_set_apply_ep(ep)
+            for has_missing in (False, True):
+                out = torch.full((nlon * nlat,), np.nan, dtype=torch.float64, device="cuda:0")
+                g = p.apply(t(src_m if has_missing else src), out, nz=1, grad_x_t=t(gx) if order == 2 else None,
+                            grad_y_t=t(gy) if order == 2 else None, grad_mask_t=t(gm) if (order == 2 and has_missing) else None,
+                            has_missing=has_missing, missing=missing, want_gsum=True)
+                p.sync()
+                res[(ep, has_missing)] = (out.cpu().numpy(), g)
+    finally:
+        fg.lib().fg_set_apply_ep(1)
+        p.destroy()
+    for has_missing in (False, True):
+        a, ga = res[(0, has_missing)]; b, gb = res[(1, has_missing)]
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), has_missing
+        assert np.float64(ga).view(np.uint64) == np.float64(gb).view(np.uint64), has_missing
+    assert (res[(1, True)][0] == missing).sum() >= 0 and np.isfinite(res[(1, False)][0]).all()
