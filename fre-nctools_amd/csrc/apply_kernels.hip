@@ -262,9 +262,17 @@ __global__ __launch_bounds__(TPB) void k_apply_ep1(int ndst, FgCsr csr, const do
     const int n = min(CAP, q1 - c0);
     if (c0 > q0) __syncthreads();                          // the previous chunk's products have been added
     {
+      // every 16-byte word of the chunk in flight at once (a loop would wait for each load before it issues the next), no
+      // branches around the loads
       const u4v *g = reinterpret_cast<const u4v *>(src + c0);
       u4v *l = reinterpret_cast<u4v *>(sh_e);
-      for (int i = t; i < n * W; i += TPB) l[i] = __builtin_nontemporal_load(g + i);
+      constexpr int WPL = CAP * W / TPB;
+      const int nw = n * W;
+      u4v w[WPL];
+#pragma unroll
+      for (int j = 0; j < WPL; j++) w[j] = __builtin_nontemporal_load(g + min(t + TPB * j, nw - 1));
+#pragma unroll
+      for (int j = 0; j < WPL; j++) if (t + TPB * j < nw) l[t + TPB * j] = w[j];
     }
     __syncthreads();
     Entry E[PASS];
