@@ -394,6 +394,104 @@ __global__ __launch_bounds__(256) void k_apply_ex(int ndst, FgCsr csr, const dou
   out[d] = r;
 }
 
+// k_apply_ex entry-parallel, the way k_apply_ep1 is k_apply1: per exchange cell the three numbers the row's sums take -- its term of
+// the --target_grid area sum (taken before the missing test, as above), the product value * area' and area' (weight, cell_methods /
+// cell_measures scaling applied in the reference's order) -- go through LDS, a cell the loop above leaves with `continue` adds +0.0
+// to the last two and does not count as touched.  Rows of any length (chunks of CAP records, ROWS rows per tile).
+template <int ORDER, bool MONO, int TPB, int CAP, int ROWS>
+__global__ __launch_bounds__(TPB) void k_apply_epx(int ndst, FgCsr csr, const double *f, const double *px, const double *py,
+                                                    FgApplyEx o, double *out, double *row_sum, int *err, int xcd_band)
+{
+  typedef typename std::conditional<ORDER == 2, FgCsrEntry2, FgCsrEntry1>::type Entry;
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  constexpr int W = sizeof(Entry) / 16, PASS = CAP / TPB;
+  static_assert(ROWS <= TPB && CAP % TPB == 0, "tile shape");
+  __shared__ __attribute__((aligned(16))) double sh_raw[CAP * 4];     // CSR records (<= 32 B each), then [3][CAP] products
+  Entry *sh_e = reinterpret_cast<Entry *>(sh_raw);
+  double *sh_t = sh_raw, *sh_p = sh_raw + CAP, *sh_a = sh_raw + 2 * CAP;
+  __shared__ unsigned char sh_fl[CAP];
+  const int t = threadIdx.x;
+  const int d0 = d_xcd_block(blockIdx.x, gridDim.x, xcd_band) * ROWS;
+  const int dl = min(d0 + ROWS, ndst);
+  const int q0 = csr.row_ptr[d0], q1 = csr.row_ptr[dl];
+  const int d = d0 + t, dc = min(d, ndst - 1);
+  int b = 0, e = 0;
+  if (t < ROWS) { b = csr.row_ptr[dc]; e = csr.row_ptr[dc + 1]; }
+  const Entry *src = (ORDER == 2) ? (const Entry *)csr.e2 : (const Entry *)csr.e1;
+  double acc = 0.0, asum = 0.0, asum_t = 0.0;
+  int touched = 0;
+  for (int c0 = q0; c0 < q1; c0 += CAP) {                  // (block-uniform)
+    const int n = min(CAP, q1 - c0);
+    if (c0 > q0) __syncthreads();
+    {
+      const u4v *g = reinterpret_cast<const u4v *>(src + c0);
+      u4v *l = reinterpret_cast<u4v *>(sh_e);
+      constexpr int WPL = CAP * W / TPB;
+      const int nw = n * W;
+      u4v w[WPL];
+#pragma unroll
+      for (int j = 0; j < WPL; j++) w[j] = __builtin_nontemporal_load(g + min(t + TPB * j, nw - 1));
+#pragma unroll
+      for (int j = 0; j < WPL; j++) if (t + TPB * j < nw) l[t + TPB * j] = w[j];
+    }
+    __syncthreads();
+    double tq[PASS], pp[PASS], aa[PASS];
+    unsigned char fl[PASS];
+#pragma unroll
+    for (int j = 0; j < PASS; j++) {
+      const int i = min(t + TPB * j, n - 1);
+      double a, v, di = 0, dj = 0;
+      int s, jf;
+      if constexpr (ORDER == 2) { const FgCsrEntry2 E = ((const FgCsrEntry2 *)sh_e)[i]; a = E.area; jf = E.idx_f; s = E.idx_g; di = E.di; dj = E.dj; }
+      else                      { const FgCsrEntry1 E = ((const FgCsrEntry1 *)sh_e)[i]; a = E.area; jf = E.idx_f; s = E.idx_f; }
+      // every value the cell may need, in one round
+      const double wgt = o.weight ? o.weight[s] : 1.0;
+      const double ca = (o.sum || o.field_area) ? o.cell_area[s] : 1.0;
+      const double fa = o.field_area ? o.field_area[s] : 0.0;
+      const double gxv = (ORDER == 2 && !MONO) ? px[s] : 0.0, gyv = (ORDER == 2 && !MONO) ? py[s] : 0.0;
+      const int gm = (ORDER == 2 && !MONO && o.has_missing && o.gmask) ? o.gmask[s] : 0;
+      v = MONO ? o.xdata[c0 + i] : f[jf];
+      double tt = 0.0;
+      if (o.cell_area_out) tt = o.field_area ? (a * fa / ca) : a;            // :845-860 (plain exchange-cell area, no weight)
+      bool skip = false;
+      if (MONO) { if (v == o.missing) skip = true; else if (o.weight) a *= wgt; }
+      else { if (o.weight) a *= wgt; if (o.has_missing && v == o.missing) skip = true; }
+      if (!skip) {
+        if (o.sum) a /= ca;
+        else if (o.field_area) {
+          if (!MONO && o.has_missing && fa == o.area_missing) { if (t + TPB * j < n) atomicOr(err, FG_XERR_AREA_MISSING); skip = true; }
+          else a *= (fa / ca);
+        }
+      }
+      if (!skip && ORDER == 2 && !MONO) { if (gm == 0) v = (v + gxv * di + gyv * dj); }
+      tq[j] = tt; pp[j] = skip ? 0.0 : v * a; aa[j] = skip ? 0.0 : a; fl[j] = (skip || MONO) ? 0 : 1;
+    }
+    __syncthreads();                                       // the records have been read: the buffer becomes the product table
+#pragma unroll
+    for (int j = 0; j < PASS; j++) {
+      const int i = t + TPB * j;
+      if (i < n) { sh_t[i] = tq[j]; sh_p[i] = pp[j]; sh_a[i] = aa[j]; sh_fl[i] = fl[j]; }
+    }
+    __syncthreads();
+    if (t < ROWS) {
+      const int qa = max(b, c0) - c0, qb = min(e, c0 + n) - c0;
+      for (int q = qa; q < qb; q++) { asum_t += sh_t[q]; acc += sh_p[q]; asum += sh_a[q]; touched |= sh_fl[q]; }
+    }
+  }
+  if (t >= ROWS || d >= ndst) return;
+  if (row_sum) row_sum[d] = (asum > 0) ? acc : 0.0;             // :815-819
+  double r = acc;
+  if (o.sum) {                                                  // :821-830
+    if (asum == 0) r = touched ? 0.0 : o.missing;
+  } else {
+    if (asum > 0) r = acc / asum;                               // :832-839
+    else if (touched) r = 0.0;
+    else r = o.missing;
+    if (o.cell_area_out && r != o.missing) r *= (asum_t / o.cell_area_out[d]);
+  }
+  out[d] = r;
+}
+
 __device__ __forceinline__ void d_atomic_max_f64(double *p, double v)
 {
   unsigned long long *u = (unsigned long long *)p, old = *u;
@@ -1077,9 +1175,20 @@ void fgd_deinterleave(int nb_pad, long n, const double *in, long ld, int nb_vali
   else k_deinterleave<2><<<nblk(n, 256), 256, 0, st>>>(n, in, ld, nb_valid, out);
 }
 void fgd_apply_ex(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, FgApplyEx o,
-                  double *out, double *row_sum, int *err, hipStream_t st)
+                  double *out, double *row_sum, int *err, hipStream_t st, long nx)
 {
   if (ndst <= 0) return;
+  if (g_apply_ep && nx >= 0) {                             // entry-parallel; rows per tile by the mean row length
+    const long m = nx / ndst;
+    const int xb = g_apply_xcd;
+#define EPX(O_, M_, R_) k_apply_epx<O_, M_, 256, 512, R_><<<nblk(ndst, R_), 256, 0, st>>>(ndst, csr, f, gx, gy, o, out, row_sum, err, xb)
+#define EPXR(O_, M_) do { if (m <= 6) EPX(O_, M_, 64); else if (m <= 24) EPX(O_, M_, 16); else if (m <= 96) EPX(O_, M_, 4); else EPX(O_, M_, 1); } while (0)
+    if (order == 2) { if (o.xdata) EPXR(2, true); else EPXR(2, false); }
+    else EPXR(1, false);
+#undef EPXR
+#undef EPX
+    return;
+  }
   int grid = nblk(ndst, 256);
   if (order == 2) {
     if (o.xdata) k_apply_ex<2, true><<<grid, 256, 0, st>>>(ndst, csr, f, gx, gy, o, out, row_sum, err);

@@ -1842,7 +1842,7 @@ extern "C" int fg_plan_mono_end(fg_plan *pl, const fg_apply_opts *o, const doubl
   fgd_mono_limit(pl->nx, pl->csr, data, miss, b, b + n, b + 2 * n, b + 3 * n, pl->mono_x, pl->xerr, pl->stream);
   FgApplyEx x = ex_pack(pl, o, nullptr);
   x.xdata = pl->mono_x;
-  fgd_apply_ex(2, pl->ndst, pl->csr, data, nullptr, nullptr, x, out, gsum_out ? pl->row_sum : nullptr, pl->xerr, pl->stream);
+  fgd_apply_ex(2, pl->ndst, pl->csr, data, nullptr, nullptr, x, out, gsum_out ? pl->row_sum : nullptr, pl->xerr, pl->stream, pl->nx);
   if (gsum_out) {
     fgd_reduce_sum(pl->row_sum, pl->ndst, pl->red_partial, pl->red_result, pl->stream);
     HIPCHK(hipMemcpyAsync(gsum_out, pl->red_result, sizeof(double), hipMemcpyDeviceToHost, pl->stream));
@@ -1871,7 +1871,7 @@ extern "C" int fg_plan_apply_ex(fg_plan *pl, const fg_apply_opts *o, const doubl
   for (int k = 0; k < nz; k++) {
     fgd_apply_ex(pl->order, pl->ndst, pl->csr, data + (size_t)k * pl->f_stride, grad_x ? grad_x + (size_t)k * pl->nsrc : nullptr,
                  grad_y ? grad_y + (size_t)k * pl->nsrc : nullptr, x, out + (size_t)k * pl->ndst,
-                 gsum_out ? pl->row_sum : nullptr, pl->xerr, st);
+                 gsum_out ? pl->row_sum : nullptr, pl->xerr, st, pl->nx);
     if (gsum_out) fgd_reduce_sum(pl->row_sum, pl->ndst, pl->red_partial, pl->red_result + k, st);
   }
   HIPCHK(hipGetLastError());

@@ -257,7 +257,7 @@ struct FgApplyEx {
 #define FG_XERR_ABOVE 2
 #define FG_XERR_BELOW 4
 void fgd_apply_ex(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, FgApplyEx o,
-                  double *out, double *row_sum, int *err, hipStream_t st);
+                  double *out, double *row_sum, int *err, hipStream_t st, long nx = -1);
 // monotone limiter (:617-716): per-source-cell neighbourhood bounds, exchange-cell values + their per-cell
 // extremes (atomic min/max: order independent), then the limited values
 void fgd_mono_bounds(const FgTile *tiles_dev, int ntiles, int nsrc, const int *src_idx_f, const double *f, double missing,

@@ -871,3 +871,42 @@ def test_single_level_entry_parallel_sweep_keeps_the_bits(fg, gpu_ok, order, ni,
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), has_missing
         assert np.float64(ga).view(np.uint64) == np.float64(gb).view(np.uint64), has_missing
     assert (res[(1, True)][0] == missing).sum() >= 0 and np.isfinite(res[(1, False)][0]).all()
+
+
+@pytest.mark.parametrize("order,mono", [(1, False), (2, False), (2, True)])
+@pytest.mark.parametrize("ni,nlon,nlat", [(48, 144, 90), (96, 24, 12), (48, 6, 3)])
+def test_option_sweep_entry_parallel_keeps_the_bits(fg, gpu_ok, order, mono, ni, nlon, nlat):
+    """k_apply_epx (weight, cell_measures, --target_grid, missing values, gradient mask, the monotone limiter's values) against the
+    lane-per-row kernel k_apply_ex (fg_set_apply_ep(0)) on rows of ~4, ~300 and ~2000 exchange cells; the oracle pins the
+    lane-per-row semantics in test_sweep_every_option_bitwise, whose cases run through k_apply_epx as well."""
+    import torch
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    p = fg.XgridPlan.create(order, grids, fg.GridConfig(nlon, nlat, lo, la))
+    a_in, a_out = p.get_cell_area(nlon * nlat)
+    p.finalize()
+    nc = 6 * ni * ni
+    nf = 6 * (ni + 2) ** 2 if order == 2 else nc
+    rng = np.random.default_rng(31)
+    missing = 1.0e20
+    src = rng.standard_normal(nf); src[rng.random(nf) < 0.15] = missing
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    gx, gy = t(4.0 * rng.standard_normal(nc)), t(4.0 * rng.standard_normal(nc))
+    gm = t((rng.random(nc) < 0.3).astype(np.int32))
+    w = t(rng.uniform(0.2, 1.0, nc)); fa = t(np.asarray(a_in) * rng.uniform(0.3, 1.0, nc)); ca = t(np.asarray(a_in)); cao = t(np.asarray(a_out))
+    res = []
+    try:
+        for ep in (0, 1):
+            fg.lib().fg_set_apply_ep(ep)
+            out = torch.full((nlon * nlat,), np.nan, dtype=torch.float64, device="cuda:0")
+            g = p.apply_ex(t(src), out, nz=1, grad_x_t=gx if order == 2 else None, grad_y_t=gy if order == 2 else None,
+                           grad_mask_t=gm if order == 2 else None, has_missing=True, missing=missing, weight_t=w,
+                           field_area_t=fa, area_missing=-1e20, cell_area_in_t=ca, cell_area_out_t=cao, monotonic=mono, want_gsum=True)
+            p.sync()
+            res.append((out.cpu().numpy(), g))
+    finally:
+        fg.lib().fg_set_apply_ep(1)
+        p.destroy()
+    assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64))
+    assert np.float64(res[0][1]).view(np.uint64) == np.float64(res[1][1]).view(np.uint64)
