@@ -13,6 +13,7 @@ L = fg.lib()
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = "cuda:0"
+only = int(os.environ.get("FUZZ_ONLY", "-1"))
 
 
 def random_pair():
@@ -20,7 +21,7 @@ def random_pair():
     lon, lat = fg.gnomonic_ed_corners(ni)
     kind = rng.integers(0, 3)
     if kind == 0:
-        nx, ny = int(rng.integers(8, 300)), int(rng.integers(6, 150))
+        nx, ny = int(rng.integers(4, 300)), int(rng.integers(3, 150))
         lo, la = fg.latlon_corners(nx, ny)
     elif kind == 1:
         nx, ny = int(rng.integers(8, 200)), int(rng.integers(6, 100))
@@ -36,11 +37,17 @@ def random_pair():
 
 
 bits = lambda v: np.ascontiguousarray(v).view(np.uint64)
-norc = nlev = 0
+norc = nlev = n1 = n1o = 0
 try:
     for ci in range(ncase):
         ni, lon, lat, gout = random_pair()
         nx, ny = gout[0], gout[1]
+        if only >= 0 and ci != only:                         # FUZZ_ONLY=<case>: replay the generator, run one case
+            for nz in (8, 3):
+                rng.standard_normal((nz, 6, ni + 2, ni + 2)); rng.standard_normal((nz, 6, ni, ni)); rng.standard_normal((nz, 6, ni, ni))
+            rng.standard_normal((1, 6, ni + 2, ni + 2)); rng.random((1, 6, ni + 2, ni + 2)); rng.standard_normal((1, 6, ni, ni)); rng.standard_normal((1, 6, ni, ni))
+            rng.random((6, ni, ni))
+            continue
         plan = fg.XgridPlan.create(2, [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)], fg.GridConfig(*gout))
         plan.finalize()
         if plan.nxgrid == 0:
@@ -52,6 +59,7 @@ try:
             for ep, vec, xcd in ((0, 2, 0), (0, 4, 64), (0, 2, 1), (1, 0, 64), (1, 0, 7)):
                 L.fg_set_apply_ep(ep); L.fg_set_apply_vec(vec); L.fg_set_apply_xcd(xcd)
                 out = torch.full((nz, nx * ny), np.nan, dtype=torch.float64, device=dev)
+                torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
                 plan.apply(dt, out, nz=nz, grad_x_t=gxt, grad_y_t=gyt); plan.sync()
                 outs.append(out.cpu().numpy())
             for o in outs[1:]:
@@ -64,8 +72,43 @@ try:
                                        [gx[:, t].reshape(nz, -1) for t in range(6)], [gy[:, t].reshape(nz, -1) for t in range(6)], None, False, -1e20, nx, ny, nz)
                 assert np.array_equal(bits(ref.reshape(nz, -1)), bits(outs[0])), ci
                 norc += 1
+        # one level per call, with missing values and a gradient mask: lane-per-row kernel, entry-parallel kernel (two tile -> XCD
+        # mappings), oracle
+        missing = -1.0e10
+        d1 = rng.standard_normal((1, 6, ni + 2, ni + 2)); d1[rng.random(d1.shape) < 0.2] = missing
+        g1x = rng.standard_normal((1, 6, ni, ni)); g1y = rng.standard_normal((1, 6, ni, ni))
+        gm = (rng.random((6, ni, ni)) < 0.3).astype(np.int32)
+        d1t = torch.from_numpy(d1.reshape(1, -1)).to(dev); g1xt = torch.from_numpy(g1x.reshape(1, -1)).to(dev); g1yt = torch.from_numpy(g1y.reshape(1, -1)).to(dev)
+        gmt = torch.from_numpy(gm.reshape(-1)).to(dev)
+        o1 = []
+        for ep, xcd in ((0, 0), (1, 64), (1, 5)):
+            L.fg_set_apply_ep(ep); L.fg_set_apply_xcd(xcd)
+            out = torch.full((nx * ny,), np.nan, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
+            plan.apply(d1t, out, nz=1, grad_x_t=g1xt, grad_y_t=g1yt, grad_mask_t=gmt, has_missing=True, missing=missing); plan.sync()
+            o1.append(out.cpu().numpy())
+        for k, o in enumerate(o1[1:]):
+            if not np.array_equal(bits(o), bits(o1[0])):
+                bad = np.nonzero(bits(o) != bits(o1[0]))[0]
+                print(f"single level: variant {k + 1} differs in {bad.size} rows, first {bad[:5]}: {o[bad[:5]]} vs {o1[0][bad[:5]]}", flush=True)
+                if only >= 0:
+                    rp = plan.get_xgrid()
+                    for dd in bad[:3]:
+                        sel = np.nonzero(rp["j_out"].astype(np.int64) * nx + rp["i_out"] == dd)[0]
+                        print("row", dd, "entries", sel.size, "areas", rp["area"][sel][:8])
+            assert np.array_equal(bits(o), bits(o1[0])), (ci, "single level")
+        n1 += 1
+        if plan.nxgrid < 400000:
+            x = plan.get_xgrid()
+            xo = dict(t_in=x["t_in"], i_in=x["i_in"], j_in=x["j_in"], i_out=x["i_out"], j_out=x["j_out"], area=x["area"], di=x["c1"], dj=x["c2"])
+            ref, _ = orc.orc_apply(2, xo, [ni] * 6, [ni] * 6, [d1[:, t].reshape(1, -1) for t in range(6)],
+                                   [g1x[:, t].reshape(1, -1) for t in range(6)], [g1y[:, t].reshape(1, -1) for t in range(6)],
+                                   [gm[t] for t in range(6)], True, missing, nx, ny, 1)
+            assert np.array_equal(bits(ref.reshape(-1)), bits(o1[0])), (ci, "single level vs oracle")
+            n1o += 1
         print(f"case {ci}: C{ni} -> {nx}x{ny}: nxgrid {plan.nxgrid} ({plan.nxgrid / (nx * ny):.1f} per row)", flush=True)
         plan.destroy()
 finally:
     L.fg_set_apply_ep(1); L.fg_set_apply_vec(0); L.fg_set_apply_xcd(64)
-print(f"sweep_fuzz: {ncase} grid pairs, {nlev} remapped levels through 5 kernel variants each: all bit-identical; {norc} plans also equal to the CPU oracle's sweep")
+print(f"sweep_fuzz: {ncase} grid pairs, {nlev} remapped levels through 5 kernel variants each: all bit-identical; {norc} plans also equal to the CPU oracle's sweep; "
+      f"{n1} single-level sweeps with missing values and gradient mask through 3 variants: all bit-identical, {n1o} also equal to the oracle's")

@@ -163,6 +163,7 @@ def test_gradient_records_and_sweep_bitwise(fg, gpu_ok, nz):
     gy = torch.empty_like(gx)
     nb = fg.C2lPrep.records_nb(nz)
     rec = torch.full((prep.ncells, 3, nb), float("nan"), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
     out_a = torch.empty(nz, nlon * nlat, dtype=torch.float64, device=dev)
     out_b = torch.empty_like(out_a)
     torch.cuda.synchronize()
@@ -176,6 +177,7 @@ def test_gradient_records_and_sweep_bitwise(fg, gpu_ok, nz):
     assert np.array_equal(_bits(r[:, 2, :nz].T), _bits(gy.cpu().numpy()))
     assert np.all(r[:, :, nz:] == 0.0)
     rec1 = torch.full_like(rec, float("nan"))            # the one-pass variant straight from the unpadded levels
+    torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
     prep.records(src, nz, rec1)
     prep.sync()
     assert np.array_equal(_bits(rec1.cpu().numpy()), _bits(r))

@@ -26,6 +26,7 @@ def run(fg, order, grids, gout, fused, exact=False, masks=None):
     gx = torch.from_numpy(rng.standard_normal((8, ni))).to("cuda:0") if order == 2 else None
     gy = torch.from_numpy(rng.standard_normal((8, ni))).to("cuda:0") if order == 2 else None
     out = torch.full((8, gout.nx * gout.ny), np.nan, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
     if order == 2:
         p.apply(src, out, nz=8, grad_x_t=gx, grad_y_t=gy)
     else:

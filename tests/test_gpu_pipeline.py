@@ -512,6 +512,7 @@ def test_culled_plan_sweeps_like_the_unculled_one(fg, gpu_ok):
                 plan = fg.XgridPlan.create(2, grids, band)
                 plan.finalize()
                 out = torch.full((nz, nlon * (j1 - j0)), np.nan, dtype=torch.float64, device="cuda:0")
+                torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
                 plan.apply(src, out, nz=nz, grad_x_t=gx, grad_y_t=gy); plan.sync()
                 outs.append(out.cpu().numpy())
                 plan.destroy()
@@ -563,6 +564,7 @@ def test_sweep_tile_mapping_keeps_the_bits(fg, gpu_ok):
         for mode in (0, 1, 2, 3, 7, 64, 1000):
             fg.lib().fg_set_apply_xcd(mode)
             out = torch.full((8, nlon * nlat), np.nan, dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
             p.apply(src, out, nz=8); p.sync()
             outs.append(out.cpu().numpy())
     finally:
@@ -604,6 +606,7 @@ def test_entry_parallel_sweep_keeps_the_bits(fg, gpu_ok, ni, nlon, nlat):
         for ep in (0, 1):
             fg.lib().fg_set_apply_ep(ep)
             out = torch.full((8, nlon * nlat), np.nan, dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
             p.apply(src, out, nz=8, grad_x_t=gx, grad_y_t=gy); p.sync()
             outs.append(out.cpu().numpy())
     finally:
@@ -858,6 +861,7 @@ def test_single_level_entry_parallel_sweep_keeps_the_bits(fg, gpu_ok, order, ni,
             fg.lib().fg_set_apply_ep(ep)
             for has_missing in (False, True):
                 out = torch.full((nlon * nlat,), np.nan, dtype=torch.float64, device="cuda:0")
+                torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
                 g = p.apply(t(src_m if has_missing else src), out, nz=1, grad_x_t=t(gx) if order == 2 else None,
                             grad_y_t=t(gy) if order == 2 else None, grad_mask_t=t(gm) if (order == 2 and has_missing) else None,
                             has_missing=has_missing, missing=missing, want_gsum=True)
@@ -900,6 +904,7 @@ def test_option_sweep_entry_parallel_keeps_the_bits(fg, gpu_ok, order, mono, ni,
         for ep in (0, 1):
             fg.lib().fg_set_apply_ep(ep)
             out = torch.full((nlon * nlat,), np.nan, dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()                   # (the fill runs on torch's stream, the library on the plan's own)
             g = p.apply_ex(t(src), out, nz=1, grad_x_t=gx if order == 2 else None, grad_y_t=gy if order == 2 else None,
                            grad_mask_t=gm if order == 2 else None, has_missing=True, missing=missing, weight_t=w,
                            field_area_t=fa, area_missing=-1e20, cell_area_in_t=ca, cell_area_out_t=cao, monotonic=mono, want_gsum=True)
