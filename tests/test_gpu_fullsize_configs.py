@@ -57,6 +57,7 @@ def test_config4_c768_great_circle_full_size(fg, gpu_ok, tmp_path):
     # first-order sweep on the great-circle plan: constants preserved, conservation
     dev = "cuda:0"
     data = torch.full((2, 6 * ni * ni), 3.25, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()                   # (filled on torch's stream; the library works on the plan's own)
     data[1] = torch.from_numpy(np.random.default_rng(0).standard_normal(6 * ni * ni) + 4.0).to(dev)
     out = torch.empty(2, nlon * nlat, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
@@ -170,6 +171,7 @@ def test_config4b_c768_legacy_order2_full_size(fg, gpu_ok):
     F, ncell = 6 * (ni + 2) ** 2, 6 * ni * ni
     data = torch.full((4, F), 2.5, dtype=torch.float64, device=dev)
     z = torch.zeros(4, ncell, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()                   # (filled on torch's stream; the library works on the plan's own)
     out = torch.empty(4, nlon * nlat, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     plan.apply(data, out, nz=4, grad_x_t=z, grad_y_t=z)

@@ -170,6 +170,7 @@ def test_accumulate_cell_sums_waits_for_torchs_stream(fg, gpu_ok):
     torch.cuda.synchronize()
     p.accumulate_cell_sums(want); torch.cuda.synchronize()
     total = torch.full((3 * n,), 1.0e300, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()                   # (filled on torch's stream; the library works on the plan's own)
     big = torch.empty(1 << 28, dtype=torch.float64, device="cuda:0")          # 2 GiB: the fill takes ~1 ms
     torch.cuda.synchronize()
     big.fill_(1.0); big.mul_(2.0); total.zero_()

@@ -667,6 +667,7 @@ def test_degenerate_sizes_and_empty_overlap(fg, gpu_ok):
     plan.finalize()
     import torch
     d = torch.ones(1, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()                   # (filled on torch's stream; the library works on the plan's own)
     out = torch.empty(16, dtype=torch.float64, device="cuda:0")
     torch.cuda.synchronize()
     plan.apply(d, out, nz=1)
@@ -787,6 +788,7 @@ def test_full_size_properties_c384(fg, gpu_ok):
     # conservation with a positive field and zero gradient: sum(out*covered area) == sum(f*xarea)
     pos = torch.full((1, F), 1.0, dtype=torch.float64, device=dev)
     z = torch.zeros(1, ncell, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()                   # (filled on torch's stream; the library works on the plan's own)
     o1 = torch.empty(nlon * nlat, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     gs = plan.apply(pos, o1, nz=1, grad_x_t=z, grad_y_t=z, want_gsum=True)
