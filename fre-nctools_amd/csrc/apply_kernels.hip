@@ -804,7 +804,8 @@ __global__ __launch_bounds__(TPB) void k_apply_ep8(int ndst, FgCsr csr, const do
 // their sums from chunk to chunk: any row length, every gather of a chunk in one round.  (Such plans took the row-serial
 // k_apply_il before: C384 -> 2 deg 0.117 ms per 8 levels on records, now 0.037.)  As a loop the kernel needs more registers than
 // k_apply_ep8 -- with 32 rows per tile on C384 -> 0.25 deg it runs in 0.117 ms against 0.083 -- so short rows keep the kernel above.
-template <int TPB, int CAP, int ROWS>
+// (ORDER 1: `rec` is the interleaved field [cell][8], a 16-byte CSR record and one 64-byte gather per exchange cell.)
+template <int ORDER, int TPB, int CAP, int ROWS>
 __global__ __launch_bounds__(TPB) void k_apply_ep8g(int ndst, FgCsr csr, const double *rec, double missing, double *out, double *row_sum,
                                                     long out_ld, int nb_valid, int xcd_band)
 {
@@ -813,7 +814,9 @@ __global__ __launch_bounds__(TPB) void k_apply_ep8g(int ndst, FgCsr csr, const d
   static_assert(ROWS * NB <= TPB, "a lane per (row, level)");
   // one buffer: the staged CSR records first, then (once every lane holds its records in registers) the products and areas
   __shared__ __attribute__((aligned(16))) double sh_raw[CAP * (NB + 1)];
-  FgCsrEntry2 *sh_e = reinterpret_cast<FgCsrEntry2 *>(sh_raw);
+  typedef typename std::conditional<ORDER == 2, FgCsrEntry2, FgCsrEntry1>::type Entry;
+  constexpr int W = sizeof(Entry) / 16;
+  Entry *sh_e = reinterpret_cast<Entry *>(sh_raw);
   double *sh_p = sh_raw, *sh_a = sh_raw + CAP * NB;
   const int t = threadIdx.x;
   const int d0 = d_xcd_block(blockIdx.x, gridDim.x, xcd_band) * ROWS;
@@ -830,23 +833,27 @@ __global__ __launch_bounds__(TPB) void k_apply_ep8g(int ndst, FgCsr csr, const d
     if (c0 > q0) __syncthreads();                          // the previous chunk's products have been added
     {
       typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-      const u4v *g = reinterpret_cast<const u4v *>(csr.e2 + c0);
+      const Entry *src = (ORDER == 2) ? (const Entry *)csr.e2 : (const Entry *)csr.e1;
+      const u4v *g = reinterpret_cast<const u4v *>(src + c0);
       u4v *l = reinterpret_cast<u4v *>(sh_e);
-      for (int i = t; i < n * 2; i += TPB) l[i] = __builtin_nontemporal_load(g + i);
+      for (int i = t; i < n * W; i += TPB) l[i] = __builtin_nontemporal_load(g + i);
     }
     __syncthreads();
     const int h = (t & 1) * 4;                             // four levels per lane of the pair
     VecD<4> fv[PASS], gxv[PASS], gyv[PASS];
-    FgCsrEntry2 E[PASS];
+    Entry E[PASS];
 #pragma unroll
     for (int j = 0; j < PASS; j++) {
       if (EPP * j < n) {                                   // (block-uniform)
         const int i = min(t / 2 + EPP * j, n - 1);
         E[j] = sh_e[i];
-        const double *pf = rec + (size_t)E[j].idx_g * (3 * NB) + h;
-        fv[j] = *reinterpret_cast<const VecD<4> *>(pf);
-        gxv[j] = *reinterpret_cast<const VecD<4> *>(pf + NB);
-        gyv[j] = *reinterpret_cast<const VecD<4> *>(pf + 2 * NB);
+        if constexpr (ORDER == 2) {
+          const double *pf = rec + (size_t)E[j].idx_g * (3 * NB) + h;
+          fv[j] = *reinterpret_cast<const VecD<4> *>(pf);
+          gxv[j] = *reinterpret_cast<const VecD<4> *>(pf + NB);
+          gyv[j] = *reinterpret_cast<const VecD<4> *>(pf + 2 * NB);
+        } else
+          fv[j] = *reinterpret_cast<const VecD<4> *>(rec + (size_t)E[j].idx_f * NB + h);
       }
     }
     __syncthreads();                                       // the records are in registers: the buffer becomes the product table
@@ -857,7 +864,8 @@ __global__ __launch_bounds__(TPB) void k_apply_ep8g(int ndst, FgCsr csr, const d
         VecD<4> pv;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          double v = (fv[j].v[k] + gxv[j].v[k] * E[j].di + gyv[j].v[k] * E[j].dj);
+          double v = fv[j].v[k];
+          if constexpr (ORDER == 2) v = (v + gxv[j].v[k] * E[j].di + gyv[j].v[k] * E[j].dj);
           pv.v[k] = v * E[j].area;
         }
         *reinterpret_cast<VecD<4> *>(sh_p + i * NB + h) = pv;
@@ -1096,9 +1104,17 @@ int g_apply_ep = 1;    // entry-parallel kernel for 8-level sweeps on records (k
 int g_apply_vec = 0;   // levels per lane: 0 = auto (4 for nb >= 8, else 2: with chunked tiles 0.0986 against 0.1010 ms on interleaved arrays,
                        // 0.0875 against 0.0937 on records, 1440x720 x 8 levels), or force 1 / 2 / 4
 void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
-                  double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st)
+                  double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st, long nx)
 {
   if (ndst <= 0) return;
+  if (order == 1 && nb == 8 && g_apply_ep && nx > 6L * ndst) {   // first order, long rows (fine -> coarse): chunked entry-parallel tiles
+    const long m = nx / ndst;
+    const int xb = g_apply_xcd >= 2 ? 2 * g_apply_xcd : g_apply_xcd;
+#define EP8O1(R_) k_apply_ep8g<1, 256, 256, R_><<<nblk(ndst, R_), 256, 0, st>>>(ndst, csr, f, missing, out, row_sum, out_ld, nb_valid, xb)
+    if (m <= 24) EP8O1(8); else if (m <= 96) EP8O1(2); else EP8O1(1);
+#undef EP8O1
+    return;
+  }
   const int v = g_apply_vec ? g_apply_vec : (nb >= 8 ? 4 : 2);
 #define AP(NB_) do { if (v >= 4 && NB_ >= 4) apply_il_nb<NB_, (NB_ >= 4 ? 4 : 2)>(order, ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, st); \
                      else if (v >= 2) apply_il_nb<NB_, 2>(order, ndst, csr, f, gx, gy, missing, out, row_sum, out_ld, nb_valid, st); \
@@ -1121,7 +1137,7 @@ void fgd_apply_il_merged(int nb, int ndst, long nx, FgCsr csr, const double *rec
   else if (nb == 8 && g_apply_ep) {                        // longer rows: chunked tiles, rows per tile by the mean row length
     const long m = nx / ndst;
     const int xb = g_apply_xcd >= 2 ? 2 * g_apply_xcd : g_apply_xcd;
-#define EP8(R_) k_apply_ep8g<256, 256, R_><<<nblk(ndst, R_), 256, 0, st>>>(ndst, csr, rec, missing, out, row_sum, out_ld, nb_valid, xb)
+#define EP8(R_) k_apply_ep8g<2, 256, 256, R_><<<nblk(ndst, R_), 256, 0, st>>>(ndst, csr, rec, missing, out, row_sum, out_ld, nb_valid, xb)
     if (m <= 24) EP8(8); else if (m <= 96) EP8(2); else EP8(1);
 #undef EP8
   }

@@ -1690,7 +1690,7 @@ extern "C" int fg_plan_apply(fg_plan *pl, const double *data, const double *grad
         double *outs[3] = {pl->il_f, nullptr, nullptr};
         const long lds[3] = {pl->f_stride, 0, 0}, ns[3] = {pl->f_stride, 0, 0};
         fgd_interleave3(nbp, 1, ins, lds, ns, outs, nbv, st);
-        fgd_apply_il(1, nbp, ndst, pl->csr, pl->il_f, nullptr, nullptr, miss, o, rs, (long)ndst, nbv, st);
+        fgd_apply_il(1, nbp, ndst, pl->csr, pl->il_f, nullptr, nullptr, miss, o, rs, (long)ndst, nbv, st, pl->nx);
       }
       if (gsum_out) fgd_reduce_sum(pl->il_rs, (long)ndst * nbp, pl->red_partial, pl->red_result + nred++, st);
     }
@@ -1900,7 +1900,7 @@ extern "C" int fg_plan_apply_interleaved(fg_plan *pl, int nb, const double *data
   pl->apply_pt.start(g_profiling != 0 && pl->apply_spans < 256, pl->stream);
   pl->apply_pt.begin(PH_APPLY);
   fgd_apply_il(pl->order, nb, pl->ndst, pl->csr, data_il, grad_x_il, grad_y_il, -1.e20, out_il,
-               gsum_out ? pl->il_rs : nullptr, 0, nb, pl->stream);
+               gsum_out ? pl->il_rs : nullptr, 0, nb, pl->stream, pl->nx);
   pl->apply_pt.end();
   if (pl->apply_pt.on) pl->apply_spans++;
   if (gsum_out) {

@@ -228,7 +228,7 @@ void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsr
 void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, const int *gmask,
                 int has_missing, double missing, double *out, double *row_sum, hipStream_t st, long nx = -1);
 void fgd_apply_il(int order, int nb, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, double missing,
-                  double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st);
+                  double *out, double *row_sum, long out_ld, int nb_valid, hipStream_t st, long nx = -1);
 void fgd_interleave(int nb_pad, long n, const double *in, long ld, int nb_valid, double *out, hipStream_t st);
 void fgd_apply_il_merged(int nb, int ndst, long nx, FgCsr csr, const double *rec, double missing, double *out, double *row_sum, long out_ld,
                          int nb_valid, hipStream_t st);

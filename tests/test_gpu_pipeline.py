@@ -107,7 +107,7 @@ def test_sweep_bitwise_with_oracle_weights(fg, gpu_ok, order, nz, has_missing):
     _sweep_bitwise(fg, order, nz, has_missing, 24, 72, 36)
 
 
-@pytest.mark.parametrize("order,nz,ni,nlon,nlat", [(2, 3, 32, 6, 3), (1, 2, 64, 4, 2), (2, 8, 64, 4, 2)])
+@pytest.mark.parametrize("order,nz,ni,nlon,nlat", [(2, 3, 32, 6, 3), (1, 2, 64, 4, 2), (2, 8, 64, 4, 2), (1, 8, 64, 4, 2), (1, 7, 48, 24, 12), (2, 1, 64, 4, 2), (1, 1, 32, 6, 3)])
 def test_sweep_bitwise_long_rows(fg, gpu_ok, order, nz, ni, nlon, nlat):
     """Fine -> coarse: destination rows of ~400 exchange cells (sorted by a whole wave, k_csr_sort_rows) and of ~3400
     (beyond its LDS staging: the serial path), filled with one atomic per run of equal rows (k_csr_fill).  The row order must
@@ -917,3 +917,29 @@ def test_option_sweep_entry_parallel_keeps_the_bits(fg, gpu_ok, order, mono, ni,
         p.destroy()
     assert np.array_equal(res[0][0].view(np.uint64), res[1][0].view(np.uint64))
     assert np.float64(res[0][1]).view(np.uint64) == np.float64(res[1][1]).view(np.uint64)
+
+
+@pytest.mark.parametrize("ni,nlon,nlat", [(96, 90, 45), (96, 24, 12), (48, 6, 3)])
+def test_first_order_eight_level_sweep_long_rows_keeps_the_bits(fg, gpu_ok, ni, nlon, nlat):
+    """First order, 8 levels, fine -> coarse: k_apply_ep8g<1> (chunked entry-parallel tiles) against the row-serial k_apply_il
+    (fg_set_apply_ep(0)); rows of ~20, ~300, ~2000 exchange cells."""
+    import torch
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    p = fg.XgridPlan.create(1, [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)], fg.GridConfig(nlon, nlat, lo, la))
+    p.finalize()
+    src = torch.from_numpy(np.random.default_rng(4).standard_normal((8, 6 * ni * ni))).to("cuda:0")
+    outs = []
+    try:
+        for ep in (0, 1):
+            fg.lib().fg_set_apply_ep(ep)
+            out = torch.empty((8, nlon * nlat), dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            g = p.apply(src, out, nz=8, want_gsum=True); p.sync()
+            outs.append((out.cpu().numpy(), g))
+    finally:
+        fg.lib().fg_set_apply_ep(1)
+        p.destroy()
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0].view(np.uint64), outs[1][0].view(np.uint64))
+    assert np.float64(outs[0][1]).view(np.uint64) == np.float64(outs[1][1]).view(np.uint64)
