@@ -573,7 +573,10 @@ __device__ __forceinline__ bool d_box_pass(const FgBinEntry &E, double lat_in_mi
                               // give 0.31 / 0.27 / 0.28 / 0.305 / 0.38 ms for the candidate phase at C384 -> 0.25 deg; the lanes with the
                               // longest scans set the duration of the four-lanes-per-cell path)
 #define CAND_G 4          // lanes per source cell in the candidate scan (one bin row each)
-#define CP_SMALL 32       // pairs per cell up to which the lanes of k_compact rank by comparison; cells with more are "big"
+#define CP_SMALL 128      // pairs per cell up to which the lanes of k_compact rank by comparison; cells with more are "big"
+                          // (32 until round 3: every cell of a coarse -> fine remap -- ~100 pairs at C48 -> 0.25 deg -- then took a whole
+                          // block of the big-cell role: compaction 0.31 ms of a 0.83 ms search; 128: 0.17 of 0.67; 256: 0.14, but the
+                          // 256 halo lanes of every lane-per-pair block then cost the similar-resolution case 2 %)
 #define CAND_CHUNK 1     // consecutive waves (of 16 cells) that append to the same region: 1 = round robin, the best balance
                           // (16 was tried for the locality of the clip: no faster, and the great-circle search, whose pairs
                           // pile up around the poles, then overflowed a region and had to be repeated)
@@ -1896,7 +1899,7 @@ void fgd_candidates1(int c0, int c1, FgCells S, const double *mask, FgBins b, co
 {
   if (c1 <= c0) return;
   const int nbR = nblk((long)(c1 - c0) * CAND_G, 64);
-  const int H = min(HEAVY_BLOCKS, max(64, nblk(c1 - c0, 64)));
+  const int H = min(HEAVY_BLOCKS, max(64, nblk(c1 - c0, 8)));     // (as in fgd_candidates_rect)
   k_candidates1<<<nbR + H, 64, 0, st>>>(c0, c1, H, S, mask, b, slot_start, entries, ecap, ps, pair_beg, pair_cnt, heavy_list, heavy_cnt, big_list, big_cnt);
 }
 
@@ -1960,7 +1963,10 @@ void fgd_candidates_rect(int nsrc, FgCells S, const double *mask, FgRect R, FgPa
 {
   if (nsrc <= 0) return;
   const int nbR = nblk(nsrc, 64);
-  const int H = min(HEAVY_BLOCKS, max(64, nblk(nsrc, 64)));
+  // waves for the listed cells: on a coarse source grid over a fine target EVERY cell is listed (C48 -> 0.25 deg: 13 824 cells; with
+  // nsrc / 64 = 216 waves the candidates took 0.24 ms, with nsrc / 8 0.064 -- dealing a cell's (row, column) pairs to all 64 lanes
+  // through LDS instead of a lane per column made no difference on top of that)
+  const int H = min(HEAVY_BLOCKS, max(64, nblk(nsrc, 8)));
   k_candidates_rect<<<nbR + H, 64, 0, st>>>(nsrc, H, S, mask, R, ps, pair_beg, pair_cnt, heavy_list, heavy_cnt, big_list, big_cnt);
 }
 
