@@ -60,11 +60,32 @@ __global__ __launch_bounds__(256) void k_csr_fill_pos(long nx, const unsigned lo
 // four times as many waves are in flight.  Runs beyond the staging capacity are sorted in place in global memory.
 // DIST (order 2): x_c1/x_c2 still hold the centroid integrals; di = clon/area - cen_lon, dj = clat/area - cen_lat
 // (conserve_interp.c:256-257,355-356) are formed here, the operations k_distances applies to the arrays themselves.
-template <int ORDER, int RPW, bool DIST>
-__global__ __launch_bounds__(64) void k_csr_sortgather(int ndst, int *perm, const int *x_src, const double *x_area, const double *x_c1,
-                                                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr)
+// rank[k] += number of keys[0..n) below v[k]: one walk over the keys (LDS) for N values -- a walk per value waits for LDS once
+// per comparison
+template <int N>
+__device__ __forceinline__ void d_rank_count(const int *keys, int n, const int (&v)[N], int (&rank)[N])
 {
-  constexpr int SHORT = 12, CAP = (RPW >= 64) ? 512 : 2048, BT = 64;      // 4 KB of LDS per wave in the short-row case
+  int j = 0;
+  for (; j + 4 <= n; j += 4) {
+    const int x0 = keys[j], x1 = keys[j + 1], x2 = keys[j + 2], x3 = keys[j + 3];
+#pragma unroll
+    for (int k = 0; k < N; k++) rank[k] += ((x0 < v[k]) ? 1 : 0) + ((x1 < v[k]) ? 1 : 0) + ((x2 < v[k]) ? 1 : 0) + ((x3 < v[k]) ? 1 : 0);
+  }
+  for (; j < n; j++) {
+    const int x = keys[j];
+#pragma unroll
+    for (int k = 0; k < N; k++) rank[k] += (x < v[k]) ? 1 : 0;
+  }
+}
+
+template <int ORDER, int RPW, bool DIST, int BT>
+__global__ __launch_bounds__(BT) void k_csr_sortgather(int ndst, int *perm, const int *x_src, const double *x_area, const double *x_c1,
+                                                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr,
+                                                        int *tmp, long ntmp)
+{
+  constexpr int SHORT = 12, CAP = (RPW >= 64) ? 512 : 2048;                // 4 KB of LDS per wave in the short-row case
+  // (BT: 64 lanes for 64 short rows; 256 for 16 long rows -- their ~1000 records leave through three dependent gathers each, and
+  // with one wave that was 18 rounds of them per block: C384 -> 2 deg finalize 0.186 ms)
   __shared__ int sh[CAP], sh2[CAP];
   __shared__ int long_b[RPW], long_n[RPW];
   __shared__ int nlong;
@@ -90,11 +111,23 @@ __global__ __launch_bounds__(64) void k_csr_sortgather(int ndst, int *perm, cons
     const int nl = nlong;
     for (int q = 0; q < nl; q++) {
       const int rb = long_b[q], n = long_n[q];
-      for (int i = threadIdx.x; i < n; i += BT) {
-        const int v = sh[rb + i];
-        int rank = 0;
-        for (int j = 0; j < n; j++) rank += (sh[rb + j] < v) ? 1 : 0;
-        sh2[rb + rank] = v;
+      // every lane ranks up to CAP / BT = 8 elements of the row in ONE walk over its keys (a walk per element waits for LDS
+      // once per comparison: 0.82 ms for the 1 850-entry rows of C384 -> 10 deg)
+      constexpr int OWN = CAP / BT;
+      if (n <= BT) {                                       // (block-uniform) one element per lane at most
+        if ((int)threadIdx.x < n) {
+          const int v = sh[rb + threadIdx.x];
+          int rank = 0;
+          for (int j = 0; j < n; j++) rank += (sh[rb + j] < v) ? 1 : 0;
+          sh2[rb + rank] = v;
+        }
+      } else {
+        int v[OWN], rank[OWN];
+#pragma unroll
+        for (int k = 0; k < OWN; k++) { const int i = threadIdx.x + BT * k; v[k] = (i < n) ? sh[rb + i] : 0x7fffffff; rank[k] = 0; }
+        d_rank_count<OWN>(sh + rb, n, v, rank);
+#pragma unroll
+        for (int k = 0; k < OWN; k++) if ((int)threadIdx.x + BT * k < n) sh2[rb + rank[k]] = v[k];
       }
       __syncthreads();
       for (int i = threadIdx.x; i < n; i += BT) sh[rb + i] = sh2[rb + i];
@@ -123,7 +156,31 @@ __global__ __launch_bounds__(64) void k_csr_sortgather(int ndst, int *perm, cons
           perm[rb + rank] = v;
         }
         __syncthreads();
-      } else if (threadIdx.x == 0) {                       // serial, as a last resort
+      } else if (tmp) {
+        // a row longer than the staging buffer (C384 -> 10 deg: 1 850 exchange cells): its keys pass through LDS a buffer-full at
+        // a time, every element counts the smaller keys of each tile into its rank (kept in tmp), then the row is written out in
+        // rank order (second half of tmp) and copied back.  (Until round 3 one lane sorted such a row by insertion, in global
+        // memory: 1.9 SECONDS for that remap's finalize.)
+        int *rk = tmp + rb, *srt = tmp + ntmp + rb;
+        for (int t0 = 0; t0 < n; t0 += CAP) {
+          const int m = min(CAP, n - t0);
+          for (int j = threadIdx.x; j < m; j += BT) sh[j] = perm[rb + t0 + j];
+          __syncthreads();
+          for (int i0 = threadIdx.x; i0 < n; i0 += 8 * BT) {           // eight elements per lane and walk over the tile
+            int v[8], r[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int i = i0 + BT * k; v[k] = (i < n) ? perm[rb + i] : 0x7fffffff; r[k] = (i < n && t0) ? rk[i] : 0; }
+            d_rank_count<8>(sh, m, v, r);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int i = i0 + BT * k; if (i < n) rk[i] = r[k]; }
+          }
+          __syncthreads();
+        }
+        for (int i = threadIdx.x; i < n; i += BT) srt[rk[i]] = perm[rb + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += BT) perm[rb + i] = srt[i];
+        __syncthreads();
+      } else if (threadIdx.x == 0) {                       // serial, as a last resort (no scratch: the plan's mean row is short)
         for (int i = rb + 1; i < rb + n; i++) {
           int v = perm[i], j = i - 1;
           while (j >= rb && perm[j] > v) { perm[j + 1] = perm[j]; j--; }
@@ -1045,16 +1102,17 @@ void fgd_csr_fill_pos(long nx_cap, const unsigned long long *nx_dev, const int *
   if (nx_cap > 0) k_csr_fill_pos<<<nblk(nx_cap, 256), 256, 0, st>>>(nx_cap, nx_dev, x_dst, row_ptr, x_rowpos, perm);
 }
 void fgd_csr_sortgather(int order, int ndst, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
-                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr, hipStream_t st)
+                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr, hipStream_t st, int *tmp, long ntmp)
 {
   if (ndst <= 0) return;
   int *pm = const_cast<int *>(perm);                       // sorted in place only for runs beyond the LDS staging capacity
-  const bool longrows = nx > 8 * (long)ndst;
-#define SG(O_, R_, D_) k_csr_sortgather<O_, R_, D_><<<nblk(ndst, R_), 64, 0, st>>>(ndst, pm, x_src, x_area, x_c1, x_c2, src_idx_f, cen, nsrc, csr)
-  if (order == 2) {
-    if (cen) { if (longrows) SG(2, 16, true); else SG(2, 64, true); }
-    else     { if (longrows) SG(2, 16, false); else SG(2, 64, false); }
-  } else     { if (longrows) SG(1, 16, false); else SG(1, 64, false); }
+  // rows per block: 64 short rows for one wave; 16 long ones, or a single very long one (fine -> very coarse), for four waves
+  const int mode = nx > 256 * (long)ndst ? 2 : (nx > 8 * (long)ndst ? 1 : 0);
+#define SG(O_, R_, D_) k_csr_sortgather<O_, R_, D_, (R_ >= 64 ? 64 : 256)><<<nblk(ndst, R_), (R_ >= 64 ? 64 : 256), 0, st>>>(ndst, pm, x_src, x_area, x_c1, x_c2, src_idx_f, cen, nsrc, csr, tmp, ntmp)
+#define SGM(O_, D_) do { if (mode == 2) SG(O_, 1, D_); else if (mode == 1) SG(O_, 16, D_); else SG(O_, 64, D_); } while (0)
+  if (order == 2) { if (cen) SGM(2, true); else SGM(2, false); }
+  else SGM(1, false);
+#undef SGM
 #undef SG
 }
 void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsrc, int *src_idx_f, hipStream_t st)

@@ -872,6 +872,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   // kernel timeline, scripts/band_trace.sh).  The records are sized by the capacity of the exchange-cell arrays (the count is
   // not known yet); an attempt that has to be repeated drops them with everything else.
   const bool fuse = g_search_finalize && early_rows && !pl->polys.npoly;
+  int *fused_tmp = nullptr;
   if (fuse) {
     pt.begin(PH_FINALIZE);
     if (order == 2) {
@@ -882,8 +883,10 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     } else pl->csr.e1 = pl->alloc<FgCsrEntry1>(nx_alloc + 1);
     if (!pl->csr.e1 && !pl->csr.e2) return fail(FG_ERR_HIP, "out of device memory");
     // (the row-length heuristic of the record kernel wants the exchange-cell count: nsrc + ndst is within a factor of it)
+    int *sg_tmp = ((long)nsrc > 7L * ndst) ? pl->alloc<int>(2 * (size_t)(nx_alloc + 1)) : nullptr;   // (scratch for very long rows; released with the plan's blocks)
     fgd_csr_sortgather(order, ndst, (long)nsrc + ndst, pl->perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f,
-                       order == 2 ? pl->cen : nullptr, nsrc, pl->csr, st);
+                       order == 2 ? pl->cen : nullptr, nsrc, pl->csr, st, sg_tmp, nx_alloc + 1);
+    fused_tmp = sg_tmp;
     pt.end();
   }
   HIPCHK(hipMemcpyAsync(hc, dc, sizeof(FgCounters), hipMemcpyDeviceToHost, st));
@@ -930,7 +933,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
   pl->rows_built = true;
   pl->searched = true;
   if (fuse) {
-    pl->release(pl->perm); pl->perm = nullptr;
+    pl->release(pl->perm); pl->perm = nullptr; pl->release(fused_tmp);
     if (!pl->red_partial) { pl->red_partial = pl->alloc<double>(1024); pl->red_result = pl->alloc<double>(260); }
     if (!pl->red_partial || !pl->red_result) return fail(FG_ERR_HIP, "out of device memory");
     pl->dist_pending = (order == 2);
@@ -1393,10 +1396,13 @@ static int build_csr(fg_plan *pl, const double *cen)
   if (pl->order == 2) pl->csr.e2 = pl->alloc<FgCsrEntry2>(nx + 1);
   else pl->csr.e1 = pl->alloc<FgCsrEntry1>(nx + 1);
   if (!pl->csr.e1 && !pl->csr.e2) return fail(FG_ERR_HIP, "out of device memory");
-  fgd_csr_sortgather(pl->order, ndst, nx, pl->perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, cen, pl->nsrc, pl->csr, st);
+  int *sg_tmp = nullptr;                                   // rows longer than the kernel's LDS staging are sorted through this
+  if (nx > 8 * (long)ndst) sg_tmp = pl->alloc<int>(2 * (size_t)(nx + 1));
+  fgd_csr_sortgather(pl->order, ndst, nx, pl->perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, cen, pl->nsrc, pl->csr, st,
+                     sg_tmp, nx + 1);
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
-  pl->release(scratch); pl->release(pl->perm); pl->perm = nullptr;
+  pl->release(scratch); pl->release(pl->perm); pl->perm = nullptr; pl->release(sg_tmp);
   if (!pl->red_partial) { pl->red_partial = pl->alloc<double>(1024); pl->red_result = pl->alloc<double>(260); }
   if (!pl->red_partial || !pl->red_result) return fail(FG_ERR_HIP, "out of device memory");
   return 0;
