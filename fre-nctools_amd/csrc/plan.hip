@@ -883,7 +883,7 @@ static long plan_search_core(fg_plan *pl, const double *const *d_lon_in, const d
     } else pl->csr.e1 = pl->alloc<FgCsrEntry1>(nx_alloc + 1);
     if (!pl->csr.e1 && !pl->csr.e2) return fail(FG_ERR_HIP, "out of device memory");
     // (the row-length heuristic of the record kernel wants the exchange-cell count: nsrc + ndst is within a factor of it)
-    int *sg_tmp = ((long)nsrc > 7L * ndst) ? pl->alloc<int>(2 * (size_t)(nx_alloc + 1)) : nullptr;   // (scratch for very long rows; released with the plan's blocks)
+    int *sg_tmp = pl->alloc<int>(2 * (size_t)(nx_alloc + 1));   // (scratch for rows beyond the LDS staging; null = the serial last resort)
     fgd_csr_sortgather(order, ndst, (long)nsrc + ndst, pl->perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f,
                        order == 2 ? pl->cen : nullptr, nsrc, pl->csr, st, sg_tmp, nx_alloc + 1);
     fused_tmp = sg_tmp;
@@ -1017,6 +1017,83 @@ static void sample_extents(int nx, int ny, const double *lon, const double *lat,
   if (*mdlon < 1e-7) *mdlon = 1e-7;
 }
 
+// The same estimate for corner arrays that live on the device: the sampled cells' corners are gathered into a compact buffer
+// (<= 4096 cells), copied and put through the host routine above -- a quarter of a megabyte instead of the whole grid (the whole
+// 0.25-degree target copied into a fresh std::vector took 29 ms, thirty times the search it was preparing).
+__global__ void k_sample_corners(int nx, int ny, long step, int nsamp, int narr, const double *a0, const double *a1, const double *a2, double *out)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nsamp) return;
+  const long c = (long)k * step;
+  const int i = (int)(c % nx), j = (int)(c / nx);
+  const long n0 = (long)j * (nx + 1) + i, n1 = n0 + 1, n3 = n0 + nx + 1, n2 = n3 + 1;
+  const double *arr[3] = {a0, a1, a2};
+  for (int a = 0; a < narr; a++) {
+    double *o = out + ((size_t)a * nsamp + k) * 4;
+    o[0] = arr[a][n0]; o[1] = arr[a][n1]; o[2] = arr[a][n2]; o[3] = arr[a][n3];
+  }
+}
+// (the buffer holds, per array, the four corners SW, SE, NE, NW of every sampled cell)
+static int sample_extents_dev(fg_plan *pl, int nx, int ny, const double *d_lon, const double *d_lat, double *mdlat, double *mdlon)
+{
+  const double PI = 3.14159265358979323846;
+  const long ncell = (long)nx * ny;
+  long step = ncell / 4096; if (step < 1) step = 1;
+  const int nsamp = (int)((ncell + step - 1) / step);
+  double *d_q = (double *)g_pool.get(pl->device, (size_t)nsamp * 8 * sizeof(double));
+  if (!d_q) return fail(FG_ERR_HIP, "out of device memory");
+  std::vector<double> q((size_t)nsamp * 8);
+  k_sample_corners<<<(nsamp + 255) / 256, 256, 0, pl->stream>>>(nx, ny, step, nsamp, 2, d_lon, d_lat, nullptr, d_q);
+  hipError_t e = hipMemcpyAsync(q.data(), d_q, q.size() * sizeof(double), hipMemcpyDeviceToHost, pl->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(pl->stream);
+  g_pool.put(d_q);
+  if (e != hipSuccess) return fail(FG_ERR_HIP, "sampling the destination corners failed: %s", hipGetErrorString(e));
+  double sl = 0, sw = 0; long cnt = 0;
+  for (int k = 0; k < nsamp; k++) {
+    const double *x = &q[(size_t)k * 4], *y = &q[((size_t)nsamp + k) * 4];
+    double ymin = y[0], ymax = y[0], w = 0;
+    for (int m = 1; m < 4; m++) { if (y[m] < ymin) ymin = y[m]; if (y[m] > ymax) ymax = y[m]; }
+    for (int m = 0; m < 4; m++) { const double d = fabs(remainder(x[(m + 1) & 3] - x[m], 2.0 * PI)); if (d > w) w = d; }
+    if (w > PI / 2) continue;      // polar caps: not representative
+    sl += ymax - ymin; sw += w; cnt++;
+  }
+  if (cnt == 0) { *mdlat = PI / 180; *mdlon = PI / 180; return 0; }
+  *mdlat = sl / cnt; *mdlon = sw / cnt;
+  if (*mdlat < 1e-7) *mdlat = 1e-7;
+  if (*mdlon < 1e-7) *mdlon = 1e-7;
+  return 0;
+}
+static int sample_extents_xyz_dev(fg_plan *pl, int nx, int ny, const double *d_x, const double *d_y, const double *d_z, double *mdlat, double *mdlon)
+{
+  const double PI = 3.14159265358979323846;
+  const long ncell = (long)nx * ny;
+  long step = ncell / 4096; if (step < 1) step = 1;
+  const int nsamp = (int)((ncell + step - 1) / step);
+  double *d_q = (double *)g_pool.get(pl->device, (size_t)nsamp * 12 * sizeof(double));
+  if (!d_q) return fail(FG_ERR_HIP, "out of device memory");
+  std::vector<double> q((size_t)nsamp * 12);
+  k_sample_corners<<<(nsamp + 255) / 256, 256, 0, pl->stream>>>(nx, ny, step, nsamp, 3, d_x, d_y, d_z, d_q);
+  hipError_t e = hipMemcpyAsync(q.data(), d_q, q.size() * sizeof(double), hipMemcpyDeviceToHost, pl->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(pl->stream);
+  g_pool.put(d_q);
+  if (e != hipSuccess) return fail(FG_ERR_HIP, "sampling the destination corners failed: %s", hipGetErrorString(e));
+  double sl = 0, sw = 0; long cnt = 0;
+  for (int k = 0; k < nsamp; k++) {                        // (corner 0 and the opposite corner 2, as sample_extents_xyz)
+    const double *x = &q[(size_t)k * 4], *y = &q[((size_t)nsamp + k) * 4], *z = &q[((size_t)2 * nsamp + k) * 4];
+    const double dx = x[0] - x[2], dy = y[0] - y[2], dz = z[0] - z[2];
+    const double diag = sqrt(dx * dx + dy * dy + dz * dz);
+    const double zc = 0.5 * (z[0] + z[2]);
+    const double coslat = sqrt(fmax(0.0, 1.0 - zc * zc));
+    if (coslat < 0.2) continue;
+    sl += diag; sw += diag / coslat; cnt++;
+  }
+  if (cnt == 0) { *mdlat = PI / 180; *mdlon = PI / 180; return 0; }
+  *mdlat = sl / cnt; *mdlon = sw / cnt;
+  if (*mdlat < 1e-7) *mdlat = 1e-7;
+  if (*mdlon < 1e-7) *mdlon = 1e-7;
+  return 0;
+}
+
 extern "C" long fg_plan_create(int order, int ntiles_in, const int *nx_in, const int *ny_in,
                                const double *const *lon_in, const double *const *lat_in,
                                const double *const *mask_in,
@@ -1076,13 +1153,9 @@ extern "C" long fg_plan_create_dev(int order, int ntiles_in, const int *nx_in, c
     pl->stream = (hipStream_t)stream; pl->own_stream = false;
   }
   if (!(mean_dlat > 0) || !(mean_dlon > 0)) {
-    size_t npo = (size_t)(nx_out + 1) * (ny_out + 1);
-    std::vector<double> hl(npo), ha(npo);
-    if (hipMemcpy(hl.data(), d_lon_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(ha.data(), d_lat_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
-      fg_plan_destroy(pl); return fail(FG_ERR_HIP, "copy of destination corners failed");
+    if (hipSetDevice(pl->device) != hipSuccess || sample_extents_dev(pl, nx_out, ny_out, d_lon_out, d_lat_out, &mean_dlat, &mean_dlon)) {
+      fg_plan_destroy(pl); return FG_ERR_HIP;
     }
-    sample_extents(nx_out, ny_out, hl.data(), ha.data(), &mean_dlat, &mean_dlon);
   }
   long nx = plan_search(pl, d_lon_in, d_lat_in, d_mask_in, d_lon_out, d_lat_out, mean_dlat, mean_dlon);
   if (nx < 0) { fg_plan_destroy(pl); return nx; }
@@ -1130,14 +1203,9 @@ extern "C" long fg_plan_create_great_circle_dev(int ntiles_in, const int *nx_in,
     pl->stream = (hipStream_t)stream; pl->own_stream = false;
   }
   if (!(mean_dlat > 0) || !(mean_dlon > 0)) {
-    size_t npo = (size_t)(nx_out + 1) * (ny_out + 1);
-    std::vector<double> hx(npo), hy(npo), hz(npo);
-    if (hipMemcpy(hx.data(), d_x_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(hy.data(), d_y_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(hz.data(), d_z_out, npo * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
-      fg_plan_destroy(pl); return fail(FG_ERR_HIP, "copy of destination corners failed");
+    if (hipSetDevice(pl->device) != hipSuccess || sample_extents_xyz_dev(pl, nx_out, ny_out, d_x_out, d_y_out, d_z_out, &mean_dlat, &mean_dlon)) {
+      fg_plan_destroy(pl); return FG_ERR_HIP;
     }
-    sample_extents_xyz(nx_out, ny_out, hx.data(), hy.data(), hz.data(), &mean_dlat, &mean_dlon);
   }
   std::vector<GcXyz> gin(ntiles_in);
   for (int m = 0; m < ntiles_in; m++) gin[m] = GcXyz{d_x_in[m], d_y_in[m], d_z_in[m]};
@@ -1396,8 +1464,10 @@ static int build_csr(fg_plan *pl, const double *cen)
   if (pl->order == 2) pl->csr.e2 = pl->alloc<FgCsrEntry2>(nx + 1);
   else pl->csr.e1 = pl->alloc<FgCsrEntry1>(nx + 1);
   if (!pl->csr.e1 && !pl->csr.e2) return fail(FG_ERR_HIP, "out of device memory");
-  int *sg_tmp = nullptr;                                   // rows longer than the kernel's LDS staging are sorted through this
-  if (nx > 8 * (long)ndst) sg_tmp = pl->alloc<int>(2 * (size_t)(nx + 1));
+  // rows longer than the kernel's LDS staging are sorted through this -- also in plans whose MEAN row is short: the cells around a
+  // pole of a cubed-sphere target hold a whole row of a lat-lon source each (1 440 exchange cells: a lane sorting that by insertion
+  // took 17 ms)
+  int *sg_tmp = pl->alloc<int>(2 * (size_t)(nx + 1));
   fgd_csr_sortgather(pl->order, ndst, nx, pl->perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, cen, pl->nsrc, pl->csr, st,
                      sg_tmp, nx + 1);
   HIPCHK(hipStreamSynchronize(st));
