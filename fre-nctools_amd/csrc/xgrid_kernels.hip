@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(CLIP_THREADS) __attribute__((amdgpu_waves_per_eu(CL
 #endif
   // ---- second half: area (+ centroid integrals) of polygon `src`
   bool below = false, acc = false;
-  int s = -1;
+  int s = -1, d_acc = -1;
   if (n_cur > 0) {
     const int p = p0 + src;
     s = ps.src[p];
@@ -1483,10 +1483,31 @@ __global__ __launch_bounds__(CLIP_THREADS) __attribute__((amdgpu_waves_per_eu(CL
       acc = true;
       tmp_area[p] = o.area;
       if (ORDER == 2) { tmp_clon[p] = o.clon; tmp_clat[p] = o.clat; }
-      if (row_cnt) tmp_rowpos[p] = atomicAdd(&row_cnt[d], 1);
+      d_acc = d;
     } else {
       ps.dst[p] = -1;
       below = (o.area == -2.0);                                  // rare (slivers below the 1e-6 ratio)
+    }
+  }
+  // the destination-row slot of an accepted pair.  Over a coarse target the pairs of a wave belong to a few destination cells
+  // (C384 -> 10 deg: 1 450 exchange cells per row) and value-returning atomics on one address queue up behind each other (that
+  // clip ran SEVEN times slower per pair than the headline's, with or without its arithmetic): one atomic per run of lanes with
+  // the same destination cell (a lane that was not accepted ends a run).
+  if (row_cnt) {
+    const int key = acc ? d_acc : -1 - lane;               // (distinct for the lanes that take no slot)
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = (lane == 0) || (key != prev);
+    const unsigned long long hm = __ballot(head), am = __ballot(acc);
+    if (am && 2 * __popcll(hm & am) > __popcll(am)) {     // (wave-uniform) hardly any runs: similar resolutions -- a lane an atomic
+      if (acc) tmp_rowpos[p0 + src] = atomicAdd(&row_cnt[d_acc], 1);
+    } else if (am) {
+      const int start = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));      // head of this lane's run
+      const unsigned long long above = (start == 63) ? 0ull : (hm & ~((2ull << start) - 1ull));
+      const int end = above ? (__ffsll((long long)above) - 1) : 64;
+      int base = 0;
+      if (lane == start && acc) base = atomicAdd(&row_cnt[d_acc], end - start);
+      base = __shfl(base, start);
+      if (acc) tmp_rowpos[p0 + src] = base + (lane - start);
     }
   }
   // nacc[s]: accepted pairs of source cell s.  Lanes are pair-ordered (before and after the move), so one atomic per
