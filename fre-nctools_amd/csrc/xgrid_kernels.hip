@@ -1413,6 +1413,7 @@ __device__ __forceinline__ int d_clip_quad_sh(double2 (*sh_poly)[T], const int t
 #ifndef CLIP_COMPACT
 #define CLIP_COMPACT 0
 #endif
+__device__ __forceinline__ int d_row_slot(int *row_cnt, bool take, int d, int lane);   // (below, with the compaction)
 template <int ORDER, bool RECT>
 __global__ __launch_bounds__(CLIP_THREADS) __attribute__((amdgpu_waves_per_eu(CLIP_WAVES, CLIP_WAVES))) void k_clip_quad(FgPairSpace ps, FgCells S, const double *mask, FgCells D, FgRect R,
                                                  double *tmp_area, double *tmp_clon, double *tmp_clat, int *nacc,
@@ -1494,21 +1495,8 @@ __global__ __launch_bounds__(CLIP_THREADS) __attribute__((amdgpu_waves_per_eu(CL
   // clip ran SEVEN times slower per pair than the headline's, with or without its arithmetic): one atomic per run of lanes with
   // the same destination cell (a lane that was not accepted ends a run).
   if (row_cnt) {
-    const int key = acc ? d_acc : -1 - lane;               // (distinct for the lanes that take no slot)
-    const int prev = __shfl_up(key, 1, 64);
-    const bool head = (lane == 0) || (key != prev);
-    const unsigned long long hm = __ballot(head), am = __ballot(acc);
-    if (am && 2 * __popcll(hm & am) > __popcll(am)) {     // (wave-uniform) hardly any runs: similar resolutions -- a lane an atomic
-      if (acc) tmp_rowpos[p0 + src] = atomicAdd(&row_cnt[d_acc], 1);
-    } else if (am) {
-      const int start = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));      // head of this lane's run
-      const unsigned long long above = (start == 63) ? 0ull : (hm & ~((2ull << start) - 1ull));
-      const int end = above ? (__ffsll((long long)above) - 1) : 64;
-      int base = 0;
-      if (lane == start && acc) base = atomicAdd(&row_cnt[d_acc], end - start);
-      base = __shfl(base, start);
-      if (acc) tmp_rowpos[p0 + src] = base + (lane - start);
-    }
+    const int slot = d_row_slot(row_cnt, acc, d_acc, lane);
+    if (acc) tmp_rowpos[p0 + src] = slot;
   }
   // nacc[s]: accepted pairs of source cell s.  Lanes are pair-ordered (before and after the move), so one atomic per
   // (wave, source cell) run does it.
@@ -1675,6 +1663,30 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
 
 struct CpPair { int s, d, beg, cnt, li, p; long x0; int na; double a, l, t; bool mine; };
 
+// Slot of an exchange cell in its destination row: atomicAdd(&row_cnt[d], 1) for every lane with take -- or, where the lanes of
+// the wave come in runs with the same d (a coarse target: value-returning atomics on one address queue up), one atomic per run.
+// Every lane of the wave must call it.
+__device__ __forceinline__ int d_row_slot(int *row_cnt, bool take, int d, int lane)
+{
+  const int key = take ? d : -1 - lane;                    // (distinct for the lanes that take no slot)
+  const int prev = __shfl_up(key, 1, 64);
+  const bool head = (lane == 0) || (key != prev);
+  const unsigned long long hm = __ballot(head), am = __ballot(take);
+  int slot = 0;
+  if (am && 2 * __popcll(hm & am) > __popcll(am)) {        // (wave-uniform) hardly any runs: a lane an atomic
+    if (take) slot = atomicAdd(&row_cnt[d], 1);
+  } else if (am) {
+    const int start = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));      // head of this lane's run
+    const unsigned long long above = (start == 63) ? 0ull : (hm & ~((2ull << start) - 1ull));
+    const int end = above ? (__ffsll((long long)above) - 1) : 64;
+    int base = 0;
+    if (lane == start && take) base = atomicAdd(&row_cnt[d], end - start);
+    base = __shfl(base, start);
+    slot = base + (lane - start);
+  }
+  return slot;
+}
+
 template <int ORDER>
 __device__ __forceinline__ CpPair d_cp_load(const FgPairSpace &ps, const FgCompactIo &io, int p, int p0, unsigned live_end, bool halo)
 {
@@ -1694,10 +1706,11 @@ __device__ __forceinline__ CpPair d_cp_load(const FgPairSpace &ps, const FgCompa
   return c;
 }
 
+// returns the exchange cell's position if its row slot is still to be taken (no slots from the clip kernels), else -1
 template <int ORDER>
-__device__ __forceinline__ void d_cp_place(const FgCompactIo &io, const CpPair &c, int p0, const int *sh_d, double (*sh_v)[CP_SPAN])
+__device__ __forceinline__ long d_cp_place(const FgCompactIo &io, const CpPair &c, int p0, const int *sh_d, double (*sh_v)[CP_SPAN])
 {
-  if (!c.mine || c.d < 0 || c.x0 + c.na > io.xcap) return;
+  if (!c.mine || c.d < 0 || c.x0 + c.na > io.xcap) return -1;
   int rank = 0;
   const int lb = c.beg - p0;
   for (int j = 0; j < c.cnt; j++) rank += ((unsigned)sh_d[lb + j] < (unsigned)c.d) ? 1 : 0;       // rejected entries are 0xffffffff
@@ -1705,7 +1718,8 @@ __device__ __forceinline__ void d_cp_place(const FgCompactIo &io, const CpPair &
   io.x_src[pos] = c.s; io.x_dst[pos] = c.d; io.x_area[pos] = c.a;
   if (ORDER == 2) { io.x_c1[pos] = c.l; io.x_c2[pos] = c.t; sh_v[0][lb + rank] = c.a; sh_v[1][lb + rank] = c.l; sh_v[2][lb + rank] = c.t; }
   if (io.tmp_rowpos) io.perm[io.row_ptr[c.d] + io.tmp_rowpos[c.p]] = (int)pos;        // the row slot was taken by the clip kernel
-  else io.x_rowpos[pos] = atomicAdd(&io.row_cnt[c.d], 1);
+  else return pos;
+  return -1;
 }
 
 #define RANK_WORDS 1024      // 65536 destination indices: 45 rows of a 1440-column grid
@@ -1830,8 +1844,14 @@ __global__ __launch_bounds__(256) void k_compact(int nsrc, FgPairSpace ps, FgCom
   sh_d[tid] = c.d;
   __syncthreads();
   const bool first = (unsigned)(p0 + tid) < live_end && p0 + tid == c.beg;
-  d_cp_place<ORDER>(io, c, p0, sh_d, sh_v);
-  if (tid < CP_SMALL) d_cp_place<ORDER>(io, h, p0, sh_d, sh_v);
+  {
+    const long pos = d_cp_place<ORDER>(io, c, p0, sh_d, sh_v);
+    if (!io.tmp_rowpos) { const int slot = d_row_slot(io.row_cnt, pos >= 0, c.d, tid & 63); if (pos >= 0) io.x_rowpos[pos] = slot; }
+  }
+  if (tid < CP_SMALL) {                                    // (whole waves: CP_SMALL is a multiple of 64)
+    const long pos = d_cp_place<ORDER>(io, h, p0, sh_d, sh_v);
+    if (!io.tmp_rowpos) { const int slot = d_row_slot(io.row_cnt, pos >= 0, h.d, tid & 63); if (pos >= 0) io.x_rowpos[pos] = slot; }
+  }
   if (ORDER != 2 || !io.sums) return;
   __syncthreads();
   if (!first || !c.mine || c.x0 + c.na > io.xcap) return;
