@@ -128,6 +128,9 @@ long fg_plan_create(int order, int ntiles_in, const int *nx_in, const int *ny_in
  * used to size the search bins (<= 0: derived from a strided sample copied back to the host).
  * use_caller_stream != 0: all work is queued on `stream` (a hipStream_t, e.g. PyTorch's
  * current stream; NULL = the legacy default stream) instead of a private stream.
+ * A plan's private stream is NON-BLOCKING: it does not wait for the legacy default stream.  Device buffers a caller hands to
+ * a plan (fields, outputs it has just filled or zeroed on another stream) must be complete on that stream first -- or put the
+ * plan on the caller's stream (this argument, fg_plan_set_stream).
  */
 long fg_plan_create_dev(int order, int ntiles_in, const int *nx_in, const int *ny_in,
                         const double *const *d_lon_in, const double *const *d_lat_in,
