@@ -1871,7 +1871,9 @@ __global__ __launch_bounds__(256) void k_centroids(int nsrc, FgCells S, const do
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsrc) return;
   double a = sums[s], cl = 0, ct = 0;
-  if (a > 0) {
+  // (a source cell a culling search left out -- nv = 0 -- has no exchange cell on this rank: its centroid is never read, though
+  // the totals handed over by the other ranks are there)
+  if (a > 0 && S.nv[s] > 0) {
     double ca = S.area[s];
     if (fabs(a - ca) / ca < 1.e-3) {
       cl = sums[nsrc + s] / a;

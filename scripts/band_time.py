@@ -26,6 +26,13 @@ if clip == "gc":
 else:
     lon_t = [h2d(lon[t]) for t in range(6)]; lat_t = [h2d(lat[t]) for t in range(6)]
 w = fg.row_cost(la, 90.0 / ni) if mode == "cost" else None
+# second order: a rank finalizes with the TOTAL per-source-cell sums (its own + what the exchange brought, conserve_interp.c:203-221);
+# the emulation takes them from one un-banded search, so that the centroid pass sees complete cells as it does under ranks
+total = None
+if clip != "gc":
+    pf = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, nlat, h2d(lo), h2d(la), np.pi / nlat, 2 * np.pi / nlon)
+    total = torch.empty(3 * 6 * ni * ni, dtype=torch.float64, device=dev)
+    pf.copy_cell_sums(total); pf.destroy(); torch.cuda.synchronize()
 fg.lib().fg_set_search_cull(1)
 what = "create_xgrid_great_circle semantics, order 1" if clip == "gc" else "order 2"
 print(f"bands: {mode}; C{ni} -> {nlon}x{nlat} {what}; wall ms of search + finalize per rank (best of 5), culling on")
@@ -45,7 +52,7 @@ for N in [int(a) for a in args] or [1, 2, 4, 8]:
                 p = fg.XgridPlan.create_great_circle_dev([ni] * 6, [ni] * 6, xin, nlon, j1 - j0, bx, np.pi / nlat, 2 * np.pi / nlon)
             else:
                 p = fg.XgridPlan.create_dev(2, [ni] * 6, [ni] * 6, lon_t, lat_t, nlon, j1 - j0, blo, bla, np.pi / nlat, 2 * np.pi / nlon)
-            p.finalize(); p.sync()
+            p.finalize(total.data_ptr() if total is not None else None); p.sync()
             wall = (time.perf_counter() - t0) * 1e3
             n = p.nxgrid
             p.destroy()
