@@ -1660,6 +1660,7 @@ __global__ __launch_bounds__(GEN_THREADS) void k_clip_general(const int *defer_l
 // kernel: 320-430 us -- its per-cell loads of the pair list are strided, and a chain of dependent round trips per block does not
 // hide behind five blocks per CU; a lane-per-pair version that left the cells cut by a block boundary to one lane: 245 us.)
 #define CP_SPAN (256 + CP_SMALL)
+static_assert(CP_SMALL % 64 == 0 && CP_SMALL <= 256, "the halo lanes of k_compact are whole waves of its 256-lane block");
 
 struct CpPair { int s, d, beg, cnt, li, p; long x0; int na; double a, l, t; bool mine; };
 
