@@ -755,13 +755,16 @@ __global__ __launch_bounds__(256) void k_apply_il(int ndst, FgCsr csr, const dou
 // (A persistent version -- blocks walking over tiles, the next tile's row pointers and records prefetched into registers while
 //  the current tile's gathers fly, no LDS staging -- was measured: 0.119 ms against 0.0833.  Its 108 VGPRs halve the occupancy
 //  (4 waves per SIMD against 7), and the occupancy is what hides the gather latency.)
+#ifndef EP_ROWS
 #define EP_ROWS 32
+#endif
 template <int TPB, int CAP>
 __global__ __launch_bounds__(TPB) void k_apply_ep8(int ndst, FgCsr csr, const double *rec, double missing, double *out, double *row_sum,
                                                     long out_ld, int nb_valid, int xcd_band)
 {
   constexpr int NB = 8;
-  constexpr int LPR = TPB / EP_ROWS, LV = NB / LPR;      // sum phase: LPR lanes per row, LV levels each
+  constexpr int LPR = NB, LV = 1;                          // sum phase: a lane per (row, level); EP_ROWS * NB <= TPB lanes take part
+  static_assert(EP_ROWS * NB <= TPB, "rows per tile");
   constexpr int EPP = TPB / 2, PASS = CAP / EPP;          // gather phase: a lane pair per exchange cell, EPP cells per pass
   // one buffer: the staged CSR records first, then (once every lane holds its records in registers) the products and areas
   __shared__ __attribute__((aligned(16))) double sh_raw[CAP * (NB + 1)];
@@ -816,7 +819,7 @@ __global__ __launch_bounds__(TPB) void k_apply_ep8(int ndst, FgCsr csr, const do
       }
     }
     __syncthreads();
-    if (d >= ndst) return;
+    if (d >= ndst || t >= EP_ROWS * NB) return;
     for (int q = b - q0; q < e - q0; q++) {
       const VecD<LV> pv = *reinterpret_cast<const VecD<LV> *>(sh_p + q * NB + lev);
 #pragma unroll
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(TPB) void k_apply_ep8(int ndst, FgCsr csr, const do
       asum += sh_a[q];
     }
   } else {
-    if (d >= ndst) return;
+    if (d >= ndst || t >= EP_ROWS * NB) return;
     for (int q = b; q < e; q++) {
       const int ql = q - q0;
       const FgCsrEntry2 E = (ql < CAP) ? sh_e[ql] : csr.e2[q];
