@@ -132,10 +132,17 @@ int fg_remap_write(const char *path, int order, long ncells, const int *tile1, c
     d.n = 0;
     const int *iv = (k == 0) ? tile1 : (k == 1) ? tile1_cell : tile2_cell;
     long cnt = (k == 0 || k == 3) ? ncells : 2 * ncells;
-    if (k < 3) for (long q = 0; q < cnt; q++) b_u32(&d, (uint32_t)iv[q]);
-    else {
+    /* one reservation per variable, then whole-word byte swaps (element by element through b_u32 this ran at 1.2 GB/s) */
+    if (b_need(&d, (size_t)cnt * (k < 3 ? 4 : 8) + 8)) { ok = 0; break; }
+    if (k < 3) {
+      uint32_t *o = (uint32_t *)d.p;
+      for (long q = 0; q < cnt; q++) o[q] = __builtin_bswap32((uint32_t)iv[q]);
+      d.n = (size_t)cnt * 4;
+    } else {
       const double *dv = (k == 3) ? xgrid_area : tile1_distance;
-      for (long q = 0; q < cnt; q++) { uint64_t u; memcpy(&u, &dv[q], 8); b_u64(&d, u); }
+      uint64_t *o = (uint64_t *)d.p;
+      for (long q = 0; q < cnt; q++) { uint64_t u; memcpy(&u, &dv[q], 8); o[q] = __builtin_bswap64(u); }
+      d.n = (size_t)cnt * 8;
     }
     ok = fwrite(d.p, 1, d.n, f) == d.n;
   }
@@ -258,17 +265,14 @@ static int get_ints(const unsigned char *b, size_t n, const RVar *v, long cnt, i
 {
   if (!v || v->type != T_INT || v->nelem != cnt || v->begin + 4ull * cnt > n) return -1;
   const unsigned char *q = b + v->begin;
-  for (long k = 0; k < cnt; k++, q += 4) out[k] = (int)(((uint32_t)q[0] << 24) | (q[1] << 16) | (q[2] << 8) | q[3]);
+  for (long k = 0; k < cnt; k++, q += 4) { uint32_t u; memcpy(&u, q, 4); out[k] = (int)__builtin_bswap32(u); }
   return 0;
 }
 static int get_doubles(const unsigned char *b, size_t n, const RVar *v, long cnt, double *out)
 {
   if (!v || v->type != T_DOUBLE || v->nelem != cnt || v->begin + 8ull * cnt > n) return -1;
   const unsigned char *q = b + v->begin;
-  for (long k = 0; k < cnt; k++, q += 8) {
-    uint64_t u = 0; for (int i = 0; i < 8; i++) u = (u << 8) | q[i];
-    memcpy(&out[k], &u, 8);
-  }
+  for (long k = 0; k < cnt; k++, q += 8) { uint64_t u; memcpy(&u, q, 8); u = __builtin_bswap64(u); memcpy(&out[k], &u, 8); }
   return 0;
 }
 
