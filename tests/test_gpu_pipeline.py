@@ -943,3 +943,34 @@ def test_first_order_eight_level_sweep_long_rows_keeps_the_bits(fg, gpu_ok, ni, 
     assert np.isfinite(outs[0][0]).all()
     assert np.array_equal(outs[0][0].view(np.uint64), outs[1][0].view(np.uint64))
     assert np.float64(outs[0][1]).view(np.uint64) == np.float64(outs[1][1]).view(np.uint64)
+
+
+@pytest.mark.parametrize("ni,nlon,nlat", [(12, 360, 180), (64, 8, 4), (48, 36, 18)])
+@pytest.mark.parametrize("order", [1, 2])
+def test_extreme_resolution_ratios_vs_oracle(fg, gpu_ok, order, ni, nlon, nlat):
+    """The paths only mismatched resolutions reach, end to end against the oracle: a coarse source over a fine target (every source
+    cell listed for the wave-per-cell candidate scan, ~150 candidate pairs per cell: big-cell compaction) and a fine source over a
+    very coarse target (destination rows of ~300 and ~3000 exchange cells: one atomic per run of lanes in the clip, rows ranked
+    tile by tile in the CSR build, chunked entry-parallel sweeps) -- exchange cells, areas, di / dj and the remapped field of one
+    level and of eight, bit for bit."""
+    import torch
+    lon, lat = fg.gnomonic_ed_corners(ni)
+    lo, la = fg.latlon_corners(nlon, nlat)
+    grids = [fg.GridConfig(ni, ni, lon[t], lat[t]) for t in range(6)]
+    o = orc.orc_setup(order, [(ni, ni, lon[t], lat[t]) for t in range(6)], [(nlon, nlat, lo, la)])
+    p = fg.XgridPlan.create(order, grids, fg.GridConfig(nlon, nlat, lo, la))
+    p.finalize()
+    check_xgrid(p.get_xgrid(), o, order, True)
+    for nz in (1, 8):
+        data, gx, gy = make_fields(ni, lon, lat, nz, order, seed=5 + nz)
+        pack = lambda arrs: torch.from_numpy(np.ascontiguousarray(np.stack(
+            [np.concatenate([a[k].ravel() for a in arrs]) for k in range(nz)]))).to("cuda:0")
+        out = torch.empty(nz * nlon * nlat, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        p.apply(pack(data), out, nz=nz, grad_x_t=pack(gx) if order == 2 else None, grad_y_t=pack(gy) if order == 2 else None)
+        p.sync()
+        ref, _ = orc.orc_apply(order, o, [ni] * 6, [ni] * 6, [d.reshape(nz, -1) for d in data],
+                               [g.reshape(nz, -1) for g in gx] if order == 2 else None,
+                               [g.reshape(nz, -1) for g in gy] if order == 2 else None, None, False, -1e20, nlon, nlat, nz)
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(np.asarray(ref).reshape(-1))), nz
+    p.destroy()
