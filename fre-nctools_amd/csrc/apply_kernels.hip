@@ -597,8 +597,10 @@ __global__ __launch_bounds__(256) void k_mono_xdata(long nx, FgCsr csr, const do
   if (v != missing) {
     if (gmask && gmask[E.idx_g]) x = v;
     else x = v + px[E.idx_g] * E.di + py[E.idx_g] * E.dj;
-    d_atomic_max_f64(fmax + E.idx_g, x);
-    d_atomic_min_f64(fmin + E.idx_g, x);
+    // (the hardware's own FP64 max / min, no value returned: a compare-and-swap loop per value -- a read, then a CAS round, twice per
+    // exchange cell -- made this kernel 0.415 of the 0.485 ms of a monotone sweep)
+    (void)atomicMax(fmax + E.idx_g, x);
+    (void)atomicMin(fmin + E.idx_g, x);
   } else
     x = missing;
   xdata[q] = x;
