@@ -549,25 +549,6 @@ __global__ __launch_bounds__(TPB) void k_apply_epx(int ndst, FgCsr csr, const do
   out[d] = r;
 }
 
-__device__ __forceinline__ void d_atomic_max_f64(double *p, double v)
-{
-  unsigned long long *u = (unsigned long long *)p, old = *u;
-  while (__longlong_as_double((long long)old) < v) {
-    unsigned long long seen = atomicCAS(u, old, (unsigned long long)__double_as_longlong(v));
-    if (seen == old) break;
-    old = seen;
-  }
-}
-__device__ __forceinline__ void d_atomic_min_f64(double *p, double v)
-{
-  unsigned long long *u = (unsigned long long *)p, old = *u;
-  while (__longlong_as_double((long long)old) > v) {
-    unsigned long long seen = atomicCAS(u, old, (unsigned long long)__double_as_longlong(v));
-    if (seen == old) break;
-    old = seen;
-  }
-}
-
 // :622-645: bounds of the 3x3 halo'd neighbourhood, ignoring missing values
 __global__ __launch_bounds__(256) void k_mono_bounds(const FgTile *tiles, int ntiles, int nsrc, const int *src_idx_f, const double *f,
                                                       double missing, double *fbmax, double *fbmin, double *fmax, double *fmin)
