@@ -1664,9 +1664,9 @@ static_assert(CP_SMALL % 64 == 0 && CP_SMALL <= 256, "the halo lanes of k_compac
 
 struct CpPair { int s, d, beg, cnt, li, p; long x0; int na; double a, l, t; bool mine; };
 
-// Slot of an exchange cell in its destination row: atomicAdd(&row_cnt[d], 1) for every lane with take -- or, where the lanes of
-// the wave come in runs with the same d (a coarse target: value-returning atomics on one address queue up), one atomic per run.
-// Every lane of the wave must call it.
+// Slot of an exchange cell in its destination row: atomicAdd(&row_cnt[d], 1) for every lane with take -- or, where many lanes of
+// the wave share a destination cell (a coarse target: value-returning atomics on one address queue up), one atomic per group of
+// lanes with the same d.  Every lane of the wave must call it.
 __device__ __forceinline__ int d_row_slot(int *row_cnt, bool take, int d, int lane)
 {
   const int key = take ? d : -1 - lane;                    // (distinct for the lanes that take no slot)
@@ -1674,17 +1674,25 @@ __device__ __forceinline__ int d_row_slot(int *row_cnt, bool take, int d, int la
   const bool head = (lane == 0) || (key != prev);
   const unsigned long long hm = __ballot(head), am = __ballot(take);
   int slot = 0;
-  if (am && 2 * __popcll(hm & am) > __popcll(am)) {        // (wave-uniform) hardly any runs: a lane an atomic
+  if (!am) return 0;
+  // similar resolutions: neighbouring lanes hardly ever share a cell -- a lane an atomic.  (Adjacent equal keys are the cheap sign
+  // of sharing; with rejected pairs in between -- the great-circle search -- a third of the takers still have an equal neighbour.)
+  if (4 * __popcll(hm & am) > 3 * __popcll(am)) {          // (wave-uniform)
     if (take) slot = atomicAdd(&row_cnt[d], 1);
-  } else if (am) {
-    const int start = 63 - __clzll((long long)(hm & ((2ull << lane) - 1ull)));      // head of this lane's run
-    const unsigned long long above = (start == 63) ? 0ull : (hm & ~((2ull << start) - 1ull));
-    const int end = above ? (__ffsll((long long)above) - 1) : 64;
-    int base = 0;
-    if (lane == start && take) base = atomicAdd(&row_cnt[d], end - start);
-    base = __shfl(base, start);
-    slot = base + (lane - start);
+    return slot;
   }
+  unsigned long long rem = am;
+  for (int it = 0; rem && it < 8; it++) {                  // groups by VALUE (not only runs), the first eight distinct cells
+    const int lead = __ffsll((long long)rem) - 1;
+    const int d0 = __shfl(d, lead);
+    const unsigned long long grp = __ballot(take && d == d0) & rem;
+    int base = 0;
+    if (lane == lead) base = atomicAdd(&row_cnt[d0], __popcll(grp));
+    base = __shfl(base, lead);
+    if ((grp >> lane) & 1ull) slot = base + __popcll(grp & ((1ull << lane) - 1ull));
+    rem &= ~grp;
+  }
+  if ((rem >> lane) & 1ull) slot = atomicAdd(&row_cnt[d], 1);       // (more than eight distinct cells in the wave: the rest one by one)
   return slot;
 }
 
