@@ -1876,18 +1876,22 @@ __global__ __launch_bounds__(256) void k_compact(int nsrc, FgPairSpace ps, FgCom
 // cen[0][s], cen[1][s] = centroid lon/lat of source cell s (conserve_interp.c:327-348)
 __global__ __launch_bounds__(256) void k_centroids(int nsrc, FgCells S, const double *sums, double *cen)
 {
-  d_load_trig_table();
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nsrc) return;
-  double a = sums[s], cl = 0, ct = 0;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  double a = 0, ca = 1, cl = 0, ct = 0;
+  bool whole = false;                                      // the cell's own integrals are needed (covered area off by >= 1e-3)
   // (a source cell a culling search left out -- nv = 0 -- has no exchange cell on this rank: its centroid is never read, though
   // the totals handed over by the other ranks are there)
-  if (a > 0 && S.nv[s] > 0) {
-    double ca = S.area[s];
+  if (s < nsrc && (a = sums[s]) > 0 && S.nv[s] > 0) {
+    ca = S.area[s];
     if (fabs(a - ca) / ca < 1.e-3) {
       cl = sums[nsrc + s] / a;
       ct = sums[2 * (size_t)nsrc + s] / a;
-    } else {
+    } else whole = true;
+  }
+  // the sine table (3.5 KB into LDS, a barrier) only for blocks that hold such a cell: none in a global remap of similar grids
+  if (__syncthreads_or(whole)) {
+    d_load_trig_table();
+    if (whole) {
       double x[G_MAXV], y[G_MAXV];
       int n = S.nv[s];
       const double *vp = S.verts + (size_t)s * 16;
@@ -1896,7 +1900,7 @@ __global__ __launch_bounds__(256) void k_centroids(int nsrc, FgCells S, const do
       ct = d_poly_ctrlat<1>(x, y, n) / ca;
     }
   }
-  cen[s] = cl; cen[nsrc + s] = ct;
+  if (s < nsrc) { cen[s] = cl; cen[nsrc + s] = ct; }
 }
 
 // di = clon/area - cen_lon, dj = clat/area - cen_lat (conserve_interp.c:256-257,355-356)
