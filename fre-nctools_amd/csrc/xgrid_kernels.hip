@@ -366,6 +366,24 @@ __device__ __forceinline__ int d_slot_position(int *slot_cnt, int key)
   return base + (lane - start);
 }
 
+#define BIN_COPIES 16      // columns a cell may cover and still live in the bins (one copy per column but the last)
+#define BIN_ROW_COPIES 4   // rows, likewise
+
+// Is this bin record the first copy of its cell inside the query's window of rows [ra, rb] x columns [c_start, c_start + count)?
+// Columns: p = the record's place in the window taken round the ring of nblon columns, o = the copy's number, flen = copies of the
+// cell.  A copy o >= 1 has its predecessor one column earlier -- inside the window unless p == 0; copy 0 is preceded by a later
+// copy only if the cell's run of columns passes the window's start going round the ring (p + flen > nblon).  Rows do not wrap: a
+// copy that is not its cell's first has its predecessor one row earlier, inside the window unless this is the window's first row.
+// Single-copy records always pass.
+__device__ __forceinline__ bool d_copy_first(int word, int c_start, int nblon, bool first_row)
+{
+  const int col = word & 0xffff, o = (word >> 16) & 15, flen = ((word >> 20) & 15) + 1;
+  if (((word >> 24) & 1) && !first_row) return false;
+  int p = col - c_start;
+  if (p < 0) p += nblon;
+  return p == 0 || (o == 0 && p + flen <= nblon);
+}
+
 // Count (FILL = false) or store (FILL = true) destination cell d in its bin / wide lists.  Wave-wide: every lane of the
 // wave must call it (live = false for lanes without a cell).
 template <bool FILL>
@@ -381,13 +399,36 @@ __device__ __forceinline__ void d_bin_insert(bool live, int d, double lat_min, d
     E.row0 = r0;
   }
   const int nbins = b.nblat * b.nblon;
-  const bool regular = live && r1 - r0 <= 1 && l1 - l0 <= 1;
-  const int slot = regular ? r0 * b.nblon + d_colmod(l0, b.nblon) : -1;
-  if (FILL) {
-    const int pos = d_slot_position(slot_cnt, slot);
-    if (regular) { const int at = slot_start[slot] + pos; if ((unsigned)at < (unsigned)cap) entries[at] = E; }
-  } else if (regular)
-    atomicAdd(&slot_cnt[slot], 1);
+  // A cell whose box covers rows r0..r1 and columns l0..l1 is stored at rows r0 .. r1 - 1 x columns l0 .. l1 - 1 (at least one of
+  // each): with r1 - r0 <= 1 and l1 - l0 <= 1 that is the single record described above; cells that are "long" -- the rings of a
+  // cubed-sphere tile around its pole (up to BIN_COPIES columns), its cells along the diagonals, which lie at 45 degrees to the bin rows
+  // (up to BIN_ROW_COPIES + 1 rows) -- get one copy per row and column, and a query takes the FIRST copy its window meets (d_copy_first).  Before round 3
+  // such cells went to the wide lists, which every source cell of the row scans whatever its longitude (0.25 deg -> C384 polar tile:
+  // 21 k wide cells, 188 k source cells listed for the wave-per-cell path, 2.1 ms against 0.7 ms for an equatorial tile).
+  const int maxcopies = (b.nblon <= 0xffff) ? min(BIN_COPIES, b.nblon) : 1, maxrows_c = (b.nblon <= 0xffff) ? BIN_ROW_COPIES : 1;
+  const bool regular = live && r1 - r0 <= maxrows_c && l1 - l0 <= maxcopies;
+  const int ccopies = regular ? max(1, (int)(l1 - l0)) : 0, rcopies = regular ? max(1, r1 - r0) : 0;
+  const int ncopies = ccopies * rcopies;
+  int maxc = ncopies;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+  for (int k = 0; k < maxc; k++) {
+    const bool on = k < ncopies;
+    const int kr = on ? k / ccopies : 0, kc = on ? k - kr * ccopies : 0;
+    const int col = on ? d_colmod(l0 + kc, b.nblon) : 0;
+    const int slot = on ? (r0 + kr) * b.nblon + col : -1;
+    if (FILL) {
+      const int pos = d_slot_position(slot_cnt, slot);
+      if (on) {
+        const int at = slot_start[slot] + pos;
+        // bin records: column, column-copy number, column copies - 1, "not the first row copy" (wide records: first row)
+        E.row0 = (col & 0xffff) | (kc << 16) | ((ccopies - 1) << 20) | ((kr > 0) << 24);
+        if ((unsigned)at < (unsigned)cap) entries[at] = E;
+      }
+    } else if (on)
+      atomicAdd(&slot_cnt[slot], 1);
+  }
+  E.row0 = r0;
   // wide cells go into the per-row lists of every row they span.  Neighbouring cells of a grid row span the same rows, so a
   // whole wave often targets one list: the rows are walked in lockstep and each step takes one atomic per run of equal lists
   // (the great-circle search, whose cap-derived boxes are wide near the poles, spent 0.45 ms here on same-address atomics).
@@ -632,6 +673,7 @@ __device__ __forceinline__ int d_heavy_scan(const SrcQuery &q, FgBins b, const i
   const int nrows_reg = q.rb - q.ra + 1, nrows_wide = q.r1 - q.r0 + 1;
   for (int it = 0; it < 2 * nrows_reg + nrows_wide; it++) {
     int e0, e1, wide_row = -1;
+    const bool first_row = it < 2;
     if (it < 2 * nrows_reg) {
       int r = q.ra + (it >> 1), seg = it & 1, base = r * b.nblon;
       if (seg && !q.n1) continue;
@@ -650,7 +692,7 @@ __device__ __forceinline__ int d_heavy_scan(const SrcQuery &q, FgBins b, const i
         const FgBinEntry E = entries[e];
         dcell = E.d;
         pass = d_box_pass(E, lat_in_min, lat_in_max, lon_in_min, lon_in_max, lon_in_avg);
-        if (wide_row >= 0 && wide_row != max(q.r0, E.row0)) pass = false;
+        if (wide_row >= 0 ? wide_row != max(q.r0, E.row0) : !d_copy_first(E.row0, q.c_start, b.nblon, first_row)) pass = false;
       }
       unsigned long long m = __ballot(pass);
       if (FILL && pass) {
@@ -680,23 +722,24 @@ __device__ __forceinline__ int d_lane_scan(const SrcQuery &q, int sub, FgBins b,
     else { ids[0] = cnt == 0 ? E.d : ids[0]; ids[1] = cnt == 1 ? E.d : ids[1]; ids[2] = cnt == 2 ? E.d : ids[2]; ids[3] = cnt == 3 ? E.d : ids[3]; }
     cnt++;
   };
-  auto range = [&](int e0, int e1, int wide_row) {
+  auto range = [&](int e0, int e1, int wide_row, bool first_row) {
     for (int eb = e0; eb < e1; eb += 4) {
       FgBinEntry E[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) E[k] = entries[min(eb + k, e1 - 1)];
 #pragma unroll
-      for (int k = 0; k < 4; k++) visit(E[k], eb + k < e1 && (wide_row < 0 || wide_row == max(q.r0, E[k].row0)));   // a wide cell sits in every row it spans
+      for (int k = 0; k < 4; k++)            // a wide cell sits in every row it spans, a long one in every column but its last
+        visit(E[k], eb + k < e1 && (wide_row < 0 ? d_copy_first(E[k].row0, q.c_start, b.nblon, first_row) : wide_row == max(q.r0, E[k].row0)));
     }
   };
   for (int r = q.ra + sub; r <= q.rb; r += CAND_G) {
     const int base = r * b.nblon;
     const int a0 = slot_start[base + q.c_start], a1 = slot_start[base + q.c_start + q.n0];
     const int b0 = q.n1 ? slot_start[base] : 0, b1 = q.n1 ? slot_start[base + q.n1] : 0;
-    range(a0, min(a1, ecap), -1);                        // a search may have outgrown its record buffer (it is then repeated)
-    range(b0, min(b1, ecap), -1);
+    range(a0, min(a1, ecap), -1, r == q.ra);             // a search may have outgrown its record buffer (it is then repeated)
+    range(b0, min(b1, ecap), -1, r == q.ra);
   }
-  for (int r = q.r0 + sub; r <= q.r1; r += CAND_G) range(slot_start[nbins + r], min(slot_start[nbins + r + 1], ecap), r);
+  for (int r = q.r0 + sub; r <= q.r1; r += CAND_G) range(slot_start[nbins + r], min(slot_start[nbins + r + 1], ecap), r, false);
   return cnt;
 }
 

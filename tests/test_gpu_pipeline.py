@@ -333,6 +333,26 @@ def test_curvilinear_target_with_pole_caps(fg, gpu_ok):
     assert n > 0
 
 
+def test_polar_tile_targets_with_long_cells_in_the_bins(fg, gpu_ok):
+    """1-degree lat-lon source -> the two polar tiles of C48: the target's cells around the pole cover many bin columns (rings) or
+    three and more bin rows (the tile's diagonals) and are stored as several copies in the bins, of which a query takes the first
+    one its window meets (d_copy_first in xgrid_kernels.hip).  Every exchange cell against the oracle, both orders; the source
+    window that straddles the 0/360 seam and the rows next to the poles are part of the global source grid."""
+    lon, lat = fg.gnomonic_ed_corners(48)
+    lo, la = fg.latlon_corners(360, 180)
+    for t, order in ((2, 1), (5, 2)):
+        n, st = _plan_vs_oracle(fg, order, [(360, 180, lo, la)], (48, 48, lon[t], lat[t]))
+        assert n > 48 * 48
+    lon96, lat96 = fg.gnomonic_ed_corners(96)            # finer on both sides: more copies per ring cell
+    lo5, la5 = fg.latlon_corners(720, 360)
+    n, st = _plan_vs_oracle(fg, 2, [(720, 360, lo5, la5)], (96, 96, lon96[2], lat96[2]))
+    assert n > 96 * 96
+    # a source whose longitudes start at -280 (the tripolar convention) meets the copies through the +-2 pi shifts
+    lo2, la2 = fg.latlon_corners(180, 90, -280.0, 80.0, -90.0, 90.0)
+    n, st = _plan_vs_oracle(fg, 1, [(180, 90, lo2, la2)], (48, 48, lon[2], lat[2]))
+    assert n > 48 * 48
+
+
 def test_tripolar_both_directions(fg, gpu_ok):
     """BASELINE config 5 scaled down: tripolar ocean grid (longitudes -280..80, bipolar Arctic cap with the fold
     along the top row) <-> cubed-sphere tiles, neither side lat-lon.  The generator is unpinned input synthesis
