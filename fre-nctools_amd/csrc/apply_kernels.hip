@@ -1088,12 +1088,14 @@ void fgd_csr_fill_pos(long nx_cap, const unsigned long long *nx_dev, const int *
   if (nx_cap > 0) k_csr_fill_pos<<<nblk(nx_cap, 256), 256, 0, st>>>(nx_cap, nx_dev, x_dst, row_ptr, x_rowpos, perm);
 }
 void fgd_csr_sortgather(int order, int ndst, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
-                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr, hipStream_t st, int *tmp, long ntmp)
+                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr, hipStream_t st, int *tmp, long ntmp,
+                        int long_rows)
 {
   if (ndst <= 0) return;
   int *pm = const_cast<int *>(perm);                       // sorted in place only for runs beyond the LDS staging capacity
   // rows per block: 64 short rows for one wave; 16 long ones, or a single very long one (fine -> very coarse), for four waves
-  const int mode = nx > 256 * (long)ndst ? 2 : (nx > 8 * (long)ndst ? 1 : 0);
+  // (long_rows: the caller knows of a region of long rows under a short mean -- the cells round the pole of a curvilinear target)
+  const int mode = nx > 256 * (long)ndst ? 2 : ((nx > 8 * (long)ndst || long_rows) ? 1 : 0);
 #define SG(O_, R_, D_) k_csr_sortgather<O_, R_, D_, (R_ >= 64 ? 64 : 256)><<<nblk(ndst, R_), (R_ >= 64 ? 64 : 256), 0, st>>>(ndst, pm, x_src, x_area, x_c1, x_c2, src_idx_f, cen, nsrc, csr, tmp, ntmp)
 #define SGM(O_, D_) do { if (mode == 2) SG(O_, 1, D_); else if (mode == 1) SG(O_, 16, D_); else SG(O_, 64, D_); } while (0)
   if (order == 2) { if (cen) SGM(2, true); else SGM(2, false); }

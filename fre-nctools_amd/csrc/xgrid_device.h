@@ -223,7 +223,8 @@ void fgd_csr_fill_pos(long nx_cap, const unsigned long long *nx_dev, const int *
 // rows of perm into ascending exchange-cell order, then the packed CSR records; cen != null (order 2): x_c1/x_c2 still hold the
 // centroid integrals and di/dj are formed here (conserve_interp.c:256-257,355-356), else they are taken as they are
 void fgd_csr_sortgather(int order, int ndst, long nx, const int *perm, const int *x_src, const double *x_area, const double *x_c1,
-                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr, hipStream_t st, int *tmp = nullptr, long ntmp = 0);   // tmp: 2 * ntmp ints of scratch for rows beyond the LDS staging (ntmp > exchange cells), or null
+                        const double *x_c2, const int *src_idx_f, const double *cen, int nsrc, FgCsr csr, hipStream_t st, int *tmp = nullptr, long ntmp = 0,
+                        int long_rows = 0);   // tmp: 2 * ntmp ints of scratch for rows beyond the LDS staging (ntmp > exchange cells), or null
 void fgd_src_field_index(int order, const FgTile *tiles_dev, int ntiles, int nsrc, int *src_idx_f, hipStream_t st);
 void fgd_apply1(int order, int ndst, FgCsr csr, const double *f, const double *gx, const double *gy, const int *gmask,
                 int has_missing, double missing, double *out, double *row_sum, hipStream_t st, long nx = -1);
