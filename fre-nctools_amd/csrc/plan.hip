@@ -1005,8 +1005,9 @@ static void sample_extents(int nx, int ny, const double *lon, const double *lat,
     double ymin = y[0], ymax = y[0], w = 0;
     for (int k = 1; k < 4; k++) { if (y[k] < ymin) ymin = y[k]; if (y[k] > ymax) ymax = y[k]; }
     for (int k = 0; k < 4; k++) {
-      double d = fabs(remainder(x[(k + 1) & 3] - x[k], 2.0 * PI));
-      if (d > w) w = d;
+      double d = fabs(x[(k + 1) & 3] - x[k]);              // |remainder(dx, 2 pi)|: the subtraction is exact for pi <= |dx| <= 4 pi (Sterbenz),
+      if (d > 3.0 * PI) d = fabs(remainder(d, 2.0 * PI)); else if (d > PI) d = fabs(2.0 * PI - d);   // so the same bits as the library call,
+      if (d > w) w = d;                                    // which took 0.12 ms per plan for the 16 k differences of the sample
     }
     if (w > PI / 2) continue;      // polar caps: not representative
     sl += ymax - ymin; sw += w; cnt++;
@@ -1059,7 +1060,11 @@ static int sample_extents_dev(fg_plan *pl, int nx, int ny, const double *d_lon, 
     if (memcmp(&x[0], &x[3], 8) || memcmp(&x[1], &x[2], 8) || memcmp(&y[0], &y[1], 8) || memcmp(&y[3], &y[2], 8)) *curvilinear = 1;
     double ymin = y[0], ymax = y[0], w = 0;
     for (int m = 1; m < 4; m++) { if (y[m] < ymin) ymin = y[m]; if (y[m] > ymax) ymax = y[m]; }
-    for (int m = 0; m < 4; m++) { const double d = fabs(remainder(x[(m + 1) & 3] - x[m], 2.0 * PI)); if (d > w) w = d; }
+    for (int m = 0; m < 4; m++) {                         // |remainder(dx, 2 pi)| without the library call where |dx| <= 3 pi (16 k calls per plan)
+      double d = fabs(x[(m + 1) & 3] - x[m]);
+      if (d > 3.0 * PI) d = fabs(remainder(d, 2.0 * PI)); else if (d > PI) d = fabs(2.0 * PI - d);
+      if (d > w) w = d;
+    }
     if (w > PI / 2) continue;      // polar caps: not representative
     sl += ymax - ymin; sw += w; cnt++;
   }
