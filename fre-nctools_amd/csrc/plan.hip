@@ -1483,7 +1483,7 @@ static int build_csr(fg_plan *pl, const double *cen)
   // a curvilinear target with cells that went to the general clip (pole vertices): its rows round the pole are long -- hundreds of
   // exchange cells -- under a mean of 6.6, and the 64-rows-per-wave mode ranks them one after another (0.25 deg -> C384 tile 3:
   // 0.23 ms of the tile's 1.1); the 16-rows-per-block mode costs the short rows of such a tile little
-  const int long_rows = !pl->rect && pl->stats[FG_STAT_DEFERRED] > 0 && nx > 4 * (long)ndst;
+  const int long_rows = !pl->rect && !pl->great_circle && pl->stats[FG_STAT_DEFERRED] > 0 && nx > 4 * (long)ndst;
   fgd_csr_sortgather(pl->order, ndst, nx, pl->perm, pl->x_src, pl->x_area, pl->x_c1, pl->x_c2, pl->src_idx_f, cen, pl->nsrc, pl->csr, st,
                      sg_tmp, nx + 1, long_rows);
   HIPCHK(hipStreamSynchronize(st));
