@@ -368,6 +368,7 @@ __device__ __forceinline__ int d_slot_position(int *slot_cnt, int key)
 
 #define BIN_COPIES 16      // columns a cell may cover and still live in the bins (one copy per column but the last)
 #define BIN_ROW_COPIES 4   // rows, likewise
+static_assert(BIN_COPIES >= 1 && BIN_COPIES <= 16, "a bin record keeps the copy number and copies - 1 in four bits each");
 
 // Is this bin record the first copy of its cell inside the query's window of rows [ra, rb] x columns [c_start, c_start + count)?
 // Columns: p = the record's place in the window taken round the ring of nblon columns, o = the copy's number, flen = copies of the
